@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the MeshFlow hot path (Jacobi smoothing + mesh warp) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4shard|small]
+
+A "step" is one pass of the hot path over one synthetic clip whose inputs (frames, vertex
+displacements) are already resident in HBM: Jacobi coefficient setup (host, O(F)) -> Jacobi sweep ->
+per-cell homography table -> mesh warp + crop scan -> clip-level crop bounds.  N = 1 runs
+BASELINE.json configs[1] (1080p, 300 frames, 16x16 mesh, 100 Jacobi sweeps, ORIGINAL weights).
+N > 1 (launched by torch.distributed.run, one rank per GPU) shards ONE clip of 300*N frames by contiguous
+frame range: Jacobi replicated, each rank warps its own 300 frames, one 16-byte all-reduce of the crop
+bounds (weak scaling; no frame gather inside the timed region -- see DESIGN.md).
+
+Rank 0 prints ONE JSON line (fields: see the task's bench contract) including
+  roofline:     warp kernel, algorithmic bytes 2*H*W*3 per frame over its HIP-event time, vs 8 TB/s HBM
+  cpu_baseline: the C oracle (oracle/warp_oracle.c, OpenMP) timed on this box's host cores on a bounded
+                sample of the same workload (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+WORKLOADS = {
+    # name: (H, W, frames per GPU, mesh R, mesh C, omega, iters)
+    'cfg2': (1080, 1920, 300, 16, 16, 10, 100),
+    'cfg3': (1080, 1920, 600, 32, 32, 30, 200),
+    'cfg4shard': (2160, 3840, 150, 16, 16, 10, 100),
+    'small': (360, 640, 64, 16, 16, 10, 100),
+}
+HBM_PEAK_BYTES_PER_S = 8.0e12     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, budget_frames):
+    """Time the C oracle on the host: Jacobi for the whole clip + warp of `budget_frames` frames (scaled
+    linearly to F frames).  The oracle is only the thing timed here, never part of the product path."""
+    from meshflow_amd import synthetic
+    from oracle import clib, meshflow_oracle as mo
+    threads = os.cpu_count() or 1
+    taps, lam, on = mo.jacobi_band_coefficients(F, W, H, 0, hom, omega)
+    b = np.ascontiguousarray(disp.reshape(F, -1))
+    t0 = time.perf_counter()
+    stab = clib.jacobi_banded(b, taps, lam, np.reciprocal(on), omega, iters, openmp=True).reshape(disp.shape)
+    t_jac = time.perf_counter() - t0
+    sel = np.linspace(0, F - 1, budget_frames).astype(int)
+    frames = synthetic.frames_numpy(1, H, W, seed=0, kind='pattern')
+    frames = np.ascontiguousarray(np.broadcast_to(frames, (len(sel), H, W, 3)))
+    t0 = time.perf_counter()
+    clib.warp_clip(frames, R, C, disp[sel], stab[sel], use_bbox=True, openmp=True)
+    t_warp = time.perf_counter() - t0
+    per_clip = t_jac + t_warp * (F / len(sel))
+    return {
+        'value': F / per_clip, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+        'sample': f'C oracle (OpenMP, {threads} threads, bbox-culled single-pass warp): Jacobi of the full clip '
+                  f'({t_jac:.2f} s) + warp of {len(sel)} of {F} frames ({t_warp:.2f} s), warp scaled linearly',
+        'jacobi_s': t_jac, 'warp_s_per_frame': t_warp / len(sel),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+    ap.add_argument('--frames-kind', default='pattern', choices=['pattern', 'noise'])
+    ap.add_argument('--cpu-frames', type=int, default=8, help='frames warped by the CPU baseline (0 = skip)')
+    ap.add_argument('--gather', action='store_true', help='also time one RCCL gather of all frames to rank 0')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from meshflow_amd import dist as mfdist, host, ops, synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+
+    rank, world, device = mfdist.init_from_env('cuda')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    H, W, per_gpu, R, C, omega, iters = WORKLOADS[args.workload]
+    F = per_gpu * world
+    lo, hi = host.shard_range(F, world, rank)
+
+    stab = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=omega,
+                              optimization_num_iterations=iters, device=str(device))
+    disp, hom = synthetic.motion(F, R, C, seed=0)
+    d_disp = torch.from_numpy(disp).to(device)
+    d_frames = synthetic.frames_torch(hi - lo, H, W, device, seed=0, kind=args.frames_kind, first_frame=lo)
+    d_out = torch.empty_like(d_frames)
+    table = ops.CellTable(hi - lo, W, H, R, C, device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    jev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            jev[i][0].record()
+        d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
+        if i is not None:
+            jev[i][1].record()
+        ops.cell_table(d_disp[lo:hi], d_stab[lo:hi], W, H, R, C, table=table)
+        if i is not None:
+            ev[i][0].record()
+        ops.warp(d_frames, table, stab.color_outside_image_area_bgr, out=d_out)
+        if i is not None:
+            ev[i][1].record()
+        bounds = mfdist.allreduce_crop(ops.crop_reduce(table.crop, W, H))
+        table.check()                      # degenerate-mesh check: one 4-byte D2H, synchronises the step
+        return d_stab, bounds
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        d_stab, bounds = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    warp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    jac_ms = float(np.mean([a.elapsed_time(b) for a, b in jev]))
+    gather_ms = None
+    if args.gather and world > 1:
+        barrier()
+        t1 = time.perf_counter()
+        mfdist.gather_frames(d_out, F)
+        barrier()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+
+    if rank == 0:
+        algo_bytes = 2.0 * H * W * 3 * (hi - lo)
+        achieved = algo_bytes / (warp_ms * 1e-3)
+        result = {
+            'metric': 'frames/sec stabilize() hot path (Jacobi + mesh warp + crop scan), inputs resident in HBM',
+            'value': F * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64 paths + u8 pixels (f64 coordinates)',
+            'data': f'synthetic ({args.frames_kind} frames, injected random mesh motion, seed 0)',
+            'config': {'workload': f'{args.workload}: {W}x{H}, {per_gpu} frames/GPU ({F} total), {R}x{C} mesh, '
+                                   f'omega={omega}, {iters} Jacobi sweeps, ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL',
+                       'parallelism': f'frame-range shards x{world}, Jacobi replicated, 16-byte crop all-reduce'},
+            'roofline': {'kernel': 'warp_kernel', 'bound': 'hbm', 'achieved': achieved / 1e9,
+                         'peak': HBM_PEAK_BYTES_PER_S / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_BYTES_PER_S,
+                         'traffic': None, 'algorithmic_bytes_per_launch': algo_bytes, 'avg_launch_ms': warp_ms},
+            'jacobi': {'avg_ms_incl_host_setup': jac_ms, 'series': int(d_disp[0].numel()), 'frames': F},
+            'crop_bounds': [int(v) for v in bounds.tolist()],
+        }
+        if gather_ms is not None:
+            result['gather_to_rank0_ms'] = gather_ms
+        if world == 1 and args.cpu_frames > 0:
+            result['cpu_baseline'] = cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, args.cpu_frames)
+        else:
+            result['cpu_baseline'] = None
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

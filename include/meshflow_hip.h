@@ -1,0 +1,118 @@
+/* meshflow_hip.h -- C ABI of libmeshflow_hip.so (MI355X / gfx950).
+ *
+ * The reference (how4rd/meshflow, `mfs.py` = meshflowstabilizer.py) is pure Python and has no FFI layer;
+ * its drop-in boundary is the pair of private methods called from stabilize() at mfs.py:150-158:
+ *
+ *   _get_stabilized_vertex_displacements        mfs.py:632-710   -> mf_jacobi_f64
+ *   _get_stabilized_frames_and_crop_boundaries  mfs.py:909-1108  -> mf_cell_table_f64 + mf_warp_u8c3
+ *
+ * and, next on the path:
+ *
+ *   _crop_frames                                mfs.py:1111-1157 -> mf_crop_resize_u8c3
+ *
+ * Every entry point takes plain pointers and sizes.  Pointers named d_* are DEVICE pointers
+ * (hipMalloc / torch tensors' data_ptr()); `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).  Kernel entry points are asynchronous on `stream`.  Return value: 0 on success,
+ * a negative MF_ERR_* otherwise; mf_last_error() gives a thread-local message.  No CPU fallback
+ * exists: without a GPU every compute entry point fails with MF_ERR_HIP.
+ *
+ * The Python binding is meshflow_amd/_lib.py (ctypes); INTEGRATION.md shows the stub a maintainer of
+ * the reference would add.
+ */
+#ifndef MESHFLOW_HIP_H
+#define MESHFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MF_ABI_VERSION 1
+
+#define MF_OK 0
+#define MF_ERR_INVALID_ARG (-1)   /* bad size / null pointer / unsupported shape */
+#define MF_ERR_HIP (-2)           /* a HIP runtime call failed (see mf_last_error) */
+#define MF_ERR_DEGENERATE (-3)    /* a mesh cell has no homography (cv2.findHomography would return None) */
+
+/* Per-cell record written by mf_cell_table_f64 and read by mf_warp_u8c3: MF_CELL_DOUBLES float64.
+ *   [0..8]   M    = inverse of the unstabilized->stabilized homography (what cv2.warpPerspective
+ *                   evaluates, mfs.py:1041, 1052)
+ *   [9..17]  Hi   = stabilized->unstabilized homography (cv2.perspectiveTransform, mfs.py:1042, 1054)
+ *   [18..21] rect = L, T, Rt, B: inclusive pixel rect of the unstabilized cell (mfs.py:1045-1048)
+ *   [22..25] bbox = x0, y0, x1, y1: inclusive, frame-clamped box outside which the cell's warped mask
+ *                   is certainly zero (x0 > x1: empty)
+ *   [26]     status: 0 ok, 1 degenerate
+ *   [27..31] reserved
+ * The table of n frames is n*R*C records followed by n*R*C compact boxes (4 x int16 each). */
+#define MF_CELL_DOUBLES 32
+#define MF_CELL_OFF_M 0
+#define MF_CELL_OFF_HI 9
+#define MF_CELL_OFF_RECT 18
+#define MF_CELL_OFF_BBOX 22
+#define MF_CELL_OFF_STATUS 26
+
+int mf_abi_version(void);
+const char* mf_last_error(void);
+
+/* ---- device plumbing (for hosts that do not bring their own allocator) ---- */
+int mf_device_count(int* count);
+int mf_set_device(int device);
+int mf_malloc(void** d_ptr, size_t bytes);
+int mf_free(void* d_ptr);
+int mf_malloc_host(void** h_ptr, size_t bytes);          /* pinned host memory */
+int mf_free_host(void* h_ptr);
+int mf_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
+int mf_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
+int mf_stream_synchronize(void* stream);
+
+/* ---- kernel 1: Jacobi temporal smoothing (mfs.py:844-878 for every vertex, mfs.py:695-704) ----
+ * d_b, d_x: [F][S] float64, frame-major, S = (R+1)*(C+1)*2 independent series (the layout of the
+ * reference's (F, R+1, C+1, 2) arrays).  x_start = b (mfs.py:699-703).  `iters` true Jacobi sweeps of
+ *   x_new[t] = inv_on[t] * (b[t] + 2*lam[t] * sum_{d=-omega..omega, 0<=t+d<F} taps[d+omega]*x[t+d])
+ * i.e. x <- diag(1/on) (b - off x) with off[t,t+d] = -2*lam[t]*taps[d+omega] (band includes d = 0,
+ * mfs.py:767-781).  d_taps: [2*omega+1], d_lam, d_inv_on: [F].  d_b and d_x may not alias. */
+int mf_jacobi_f64(const double* d_b, double* d_x, const double* d_taps, const double* d_lam,
+                  const double* d_inv_on, int F, int S, int omega, int iters, void* stream);
+
+/* ---- kernel 2a: per-cell homography table (mfs.py:881-906, 964-967, 1025-1027, 1039-1048) ----
+ * d_unstab, d_stab: [n][(R+1)*(C+1)][2] float64 vertex displacements of the n frames to warp.
+ * d_table: mf_cell_table_bytes(n, R, C) bytes.  d_crop: [n][4] int32, initialised here to the
+ * per-frame defaults {0, 0, W-1, H-1} = {left, top, right, bottom} (mfs.py:992-995).
+ * d_status: one int32, incremented once per degenerate cell (zero it before the call). */
+size_t mf_cell_table_bytes(int n, int R, int C);
+int mf_cell_table_f64(const double* d_unstab, const double* d_stab, int n, int W, int H, int R, int C,
+                      void* d_table, int32_t* d_crop, int32_t* d_status, void* stream);
+
+/* ---- kernel 2b: mesh warp + crop-boundary scan (mfs.py:1017-1019, 1050-1098) ----
+ * d_frames, d_out: [n][H][W][3] uint8 (BGR).  For every output pixel: owner = last cell in row-major
+ * order whose warped mask is non-zero (mfs.py:1060-1061); source coordinates from that cell's Hi
+ * (mfs.py:1054); cv2.remap bilinear, constant border colour (mfs.py:1063-1069); the four edge scans
+ * of mfs.py:1075-1098 are folded into d_crop[f] = {left, top, right, bottom} with atomic max/min.
+ * d_frames and d_out may not alias. */
+int mf_warp_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, int n, int W, int H,
+                 int R, int C, const uint8_t border_bgr[3], int32_t* d_crop, void* stream);
+
+/* Clip-level crop bounds (mfs.py:1103-1106): {max left, max top, min right, min bottom} over n frames.
+ * d_bounds: [4] int32. */
+int mf_crop_reduce(const int32_t* d_crop, int n, int W, int H, int32_t* d_bounds, void* stream);
+
+/* ---- next row: crop + bilinear resize (mfs.py:1111-1157, cv2.resize INTER_LINEAR to (W, H)) ----
+ * Crops every frame to the inclusive bounds {left, top, right, bottom} and scales back to W x H. */
+int mf_crop_resize_u8c3(const uint8_t* d_frames, uint8_t* d_out, int n, int W, int H,
+                        int left, int top, int right, int bottom, void* stream);
+
+/* ---- host-buffer convenience wrappers (synchronous; H2D, kernels, D2H on an internal stream) ----
+ * These are what a ctypes stub inside the reference's two methods would call.
+ * kernel_ms (optional) receives the device time of the kernels alone, measured with HIP events. */
+int mf_jacobi_f64_host(const double* b, double* x, const double* taps, const double* lam,
+                       const double* inv_on, int F, int S, int omega, int iters, float* kernel_ms);
+int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab, const double* stab,
+                      int n, int W, int H, int R, int C, const uint8_t border_bgr[3],
+                      int32_t* crop /* [n][4] */, float* kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MESHFLOW_HIP_H */

@@ -1,0 +1,209 @@
+// C ABI of libmeshflow_hip.so: argument checking, error reporting, device plumbing and the
+// host-buffer convenience wrappers.  Declarations and reference citations: include/meshflow_hip.h.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "mf_common.h"
+
+namespace mf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return MF_OK;
+    set_error("%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+    return MF_ERR_HIP;
+}
+
+static uint32_t pack_border(const uint8_t b[3]) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16); }
+
+}  // namespace mf
+
+using namespace mf;
+
+extern "C" {
+
+int mf_abi_version(void) { return MF_ABI_VERSION; }
+const char* mf_last_error(void) { return g_err; }
+
+int mf_device_count(int* count)
+{
+    if (!count) { set_error("mf_device_count: null"); return MF_ERR_INVALID_ARG; }
+    *count = 0;
+    MF_HIP_TRY(hipGetDeviceCount(count));
+    return MF_OK;
+}
+
+int mf_set_device(int device) { MF_HIP_TRY(hipSetDevice(device)); return MF_OK; }
+
+int mf_malloc(void** d_ptr, size_t bytes)
+{
+    if (!d_ptr) { set_error("mf_malloc: null"); return MF_ERR_INVALID_ARG; }
+    MF_HIP_TRY(hipMalloc(d_ptr, bytes));
+    return MF_OK;
+}
+int mf_free(void* d_ptr) { MF_HIP_TRY(hipFree(d_ptr)); return MF_OK; }
+int mf_malloc_host(void** h_ptr, size_t bytes)
+{
+    if (!h_ptr) { set_error("mf_malloc_host: null"); return MF_ERR_INVALID_ARG; }
+    MF_HIP_TRY(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
+    return MF_OK;
+}
+int mf_free_host(void* h_ptr) { MF_HIP_TRY(hipHostFree(h_ptr)); return MF_OK; }
+int mf_memcpy_h2d(void* d, const void* h, size_t bytes, void* stream)
+{
+    MF_HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return MF_OK;
+}
+int mf_memcpy_d2h(void* h, const void* d, size_t bytes, void* stream)
+{
+    MF_HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return MF_OK;
+}
+int mf_stream_synchronize(void* stream) { MF_HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return MF_OK; }
+
+int mf_jacobi_f64(const double* d_b, double* d_x, const double* d_taps, const double* d_lam,
+                  const double* d_inv_on, int F, int S, int omega, int iters, void* stream)
+{
+    if (!d_b || !d_x || !d_taps || !d_lam || !d_inv_on) { set_error("mf_jacobi_f64: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (d_b == d_x) { set_error("mf_jacobi_f64: d_b and d_x alias"); return MF_ERR_INVALID_ARG; }
+    return launch_jacobi(d_b, d_x, d_taps, d_lam, d_inv_on, F, S, omega, iters, (hipStream_t)stream);
+}
+
+size_t mf_cell_table_bytes(int n, int R, int C)
+{
+    if (n <= 0 || R <= 0 || C <= 0) return 0;
+    return table_records(n, R, C) * (MF_CELL_DOUBLES * sizeof(double) + sizeof(CellBox));
+}
+
+int mf_cell_table_f64(const double* d_unstab, const double* d_stab, int n, int W, int H, int R, int C,
+                      void* d_table, int32_t* d_crop, int32_t* d_status, void* stream)
+{
+    if (!d_unstab || !d_stab || !d_table || !d_crop || !d_status) { set_error("mf_cell_table_f64: null pointer"); return MF_ERR_INVALID_ARG; }
+    double* records = (double*)d_table;
+    CellBox* boxes = (CellBox*)(records + table_records(n, R, C) * MF_CELL_DOUBLES);
+    return launch_cell_table(d_unstab, d_stab, n, W, H, R, C, records, boxes, d_crop, d_status, (hipStream_t)stream);
+}
+
+int mf_warp_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, int n, int W, int H,
+                 int R, int C, const uint8_t border_bgr[3], int32_t* d_crop, void* stream)
+{
+    if (!d_frames || !d_out || !d_table || !border_bgr || !d_crop) { set_error("mf_warp_u8c3: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (d_frames == d_out) { set_error("mf_warp_u8c3: d_frames and d_out alias"); return MF_ERR_INVALID_ARG; }
+    const double* records = (const double*)d_table;
+    const CellBox* boxes = (const CellBox*)(records + table_records(n, R, C) * MF_CELL_DOUBLES);
+    return launch_warp(d_frames, d_out, records, boxes, n, W, H, R, C, pack_border(border_bgr), d_crop, (hipStream_t)stream);
+}
+
+int mf_crop_reduce(const int32_t* d_crop, int n, int W, int H, int32_t* d_bounds, void* stream)
+{
+    if (!d_crop || !d_bounds) { set_error("mf_crop_reduce: null pointer"); return MF_ERR_INVALID_ARG; }
+    return launch_crop_reduce(d_crop, n, W, H, d_bounds, (hipStream_t)stream);
+}
+
+int mf_crop_resize_u8c3(const uint8_t* d_frames, uint8_t* d_out, int n, int W, int H,
+                        int left, int top, int right, int bottom, void* stream)
+{
+    if (!d_frames || !d_out) { set_error("mf_crop_resize_u8c3: null pointer"); return MF_ERR_INVALID_ARG; }
+    return launch_crop_resize(d_frames, d_out, n, W, H, left, top, right, bottom, (hipStream_t)stream);
+}
+
+// ---- host-buffer wrappers ------------------------------------------------------------------------
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+};
+struct Stream {
+    hipStream_t s = nullptr;
+    ~Stream() { if (s) (void)hipStreamDestroy(s); }
+};
+struct Event {
+    hipEvent_t e = nullptr;
+    ~Event() { if (e) (void)hipEventDestroy(e); }
+};
+}  // namespace
+
+int mf_jacobi_f64_host(const double* b, double* x, const double* taps, const double* lam,
+                       const double* inv_on, int F, int S, int omega, int iters, float* kernel_ms)
+{
+    if (!b || !x || !taps || !lam || !inv_on) { set_error("mf_jacobi_f64_host: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (F <= 0 || S <= 0 || omega <= 0) { set_error("mf_jacobi_f64_host: bad sizes"); return MF_ERR_INVALID_ARG; }
+    const size_t nb = (size_t)F * S * sizeof(double);
+    DevBuf db, dx, dt, dl, di;
+    Stream st; Event e0, e1;
+    MF_HIP_TRY(hipStreamCreate(&st.s));
+    MF_HIP_TRY(hipEventCreate(&e0.e));
+    MF_HIP_TRY(hipEventCreate(&e1.e));
+    MF_HIP_TRY(db.alloc(nb)); MF_HIP_TRY(dx.alloc(nb));
+    MF_HIP_TRY(dt.alloc((2 * omega + 1) * sizeof(double)));
+    MF_HIP_TRY(dl.alloc(F * sizeof(double))); MF_HIP_TRY(di.alloc(F * sizeof(double)));
+    MF_HIP_TRY(hipMemcpyAsync(db.p, b, nb, hipMemcpyHostToDevice, st.s));
+    MF_HIP_TRY(hipMemcpyAsync(dt.p, taps, (2 * omega + 1) * sizeof(double), hipMemcpyHostToDevice, st.s));
+    MF_HIP_TRY(hipMemcpyAsync(dl.p, lam, F * sizeof(double), hipMemcpyHostToDevice, st.s));
+    MF_HIP_TRY(hipMemcpyAsync(di.p, inv_on, F * sizeof(double), hipMemcpyHostToDevice, st.s));
+    MF_HIP_TRY(hipEventRecord(e0.e, st.s));
+    int rc = mf_jacobi_f64((const double*)db.p, (double*)dx.p, (const double*)dt.p, (const double*)dl.p,
+                           (const double*)di.p, F, S, omega, iters, st.s);
+    if (rc != MF_OK) return rc;
+    MF_HIP_TRY(hipEventRecord(e1.e, st.s));
+    MF_HIP_TRY(hipMemcpyAsync(x, dx.p, nb, hipMemcpyDeviceToHost, st.s));
+    MF_HIP_TRY(hipStreamSynchronize(st.s));
+    if (kernel_ms) MF_HIP_TRY(hipEventElapsedTime(kernel_ms, e0.e, e1.e));
+    return MF_OK;
+}
+
+int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab, const double* stab,
+                      int n, int W, int H, int R, int C, const uint8_t border_bgr[3], int32_t* crop,
+                      float* kernel_ms)
+{
+    if (!frames || !out || !unstab || !stab || !border_bgr || !crop) { set_error("mf_warp_u8c3_host: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (n <= 0 || W < 2 || H < 2 || R <= 0 || C <= 0) { set_error("mf_warp_u8c3_host: bad sizes"); return MF_ERR_INVALID_ARG; }
+    const size_t fb = (size_t)n * W * H * 3;
+    const size_t vb = (size_t)n * (R + 1) * (C + 1) * 2 * sizeof(double);
+    DevBuf dfr, dout, du, ds, dtab, dcrop, dstat;
+    Stream st; Event e0, e1;
+    MF_HIP_TRY(hipStreamCreate(&st.s));
+    MF_HIP_TRY(hipEventCreate(&e0.e));
+    MF_HIP_TRY(hipEventCreate(&e1.e));
+    MF_HIP_TRY(dfr.alloc(fb)); MF_HIP_TRY(dout.alloc(fb));
+    MF_HIP_TRY(du.alloc(vb)); MF_HIP_TRY(ds.alloc(vb));
+    MF_HIP_TRY(dtab.alloc(mf_cell_table_bytes(n, R, C)));
+    MF_HIP_TRY(dcrop.alloc((size_t)n * 4 * sizeof(int32_t)));
+    MF_HIP_TRY(dstat.alloc(sizeof(int32_t)));
+    MF_HIP_TRY(hipMemsetAsync(dstat.p, 0, sizeof(int32_t), st.s));
+    MF_HIP_TRY(hipMemcpyAsync(dfr.p, frames, fb, hipMemcpyHostToDevice, st.s));
+    MF_HIP_TRY(hipMemcpyAsync(du.p, unstab, vb, hipMemcpyHostToDevice, st.s));
+    MF_HIP_TRY(hipMemcpyAsync(ds.p, stab, vb, hipMemcpyHostToDevice, st.s));
+    MF_HIP_TRY(hipEventRecord(e0.e, st.s));
+    int rc = mf_cell_table_f64((const double*)du.p, (const double*)ds.p, n, W, H, R, C, dtab.p, (int32_t*)dcrop.p,
+                               (int32_t*)dstat.p, st.s);
+    if (rc != MF_OK) return rc;
+    rc = mf_warp_u8c3((const uint8_t*)dfr.p, (uint8_t*)dout.p, dtab.p, n, W, H, R, C, border_bgr, (int32_t*)dcrop.p, st.s);
+    if (rc != MF_OK) return rc;
+    MF_HIP_TRY(hipEventRecord(e1.e, st.s));
+    int32_t status = 0;
+    MF_HIP_TRY(hipMemcpyAsync(out, dout.p, fb, hipMemcpyDeviceToHost, st.s));
+    MF_HIP_TRY(hipMemcpyAsync(crop, dcrop.p, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st.s));
+    MF_HIP_TRY(hipMemcpyAsync(&status, dstat.p, sizeof(int32_t), hipMemcpyDeviceToHost, st.s));
+    MF_HIP_TRY(hipStreamSynchronize(st.s));
+    if (kernel_ms) MF_HIP_TRY(hipEventElapsedTime(kernel_ms, e0.e, e1.e));
+    if (status != 0) {
+        set_error("mf_warp_u8c3_host: %d degenerate mesh cell(s): no homography exists (cv2.findHomography would return None)", status);
+        return MF_ERR_DEGENERATE;
+    }
+    return MF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+// Kernel 2a: per-cell homography table.  One thread per (frame, cell).
+//
+// Reference (meshflowstabilizer.py): vertex grid :881-906; stabilized vertex positions :964-967, :1025;
+// two independent cv2.findHomography calls per cell :1041-1042; cell rect :1045-1048; and the matrix
+// inversion cv2.warpPerspective applies to the forward homography (:1052).
+//
+// cv2.findHomography with 4 points is the normalised DLT (OpenCV calib3d/fundam.cpp runKernel): inputs
+// rounded to float32, zero-centroid / unit-mean-absolute-deviation normalisation, 8 equations in 9
+// unknowns, de-normalisation invHnorm * H0 * Hnorm2 and scaling by 1/H[2][2].  The null vector is taken
+// here by Gaussian elimination with partial pivoting on the 8x8 system with h8 = 1, in a fixed operation
+// order shared with the CPU oracle, float64, no FMA contraction (the file is compiled with
+// -ffp-contract=off) so the table is bit-identical to the oracle's.
+//
+// The work is tiny (2*R*C 8x8 solves per frame); the kernel exists so that the Jacobi output never leaves
+// the device between the two halves of the path.
+#include "mf_common.h"
+
+namespace mf {
+
+__device__ static bool solve8(double A[8][8], double r[8], double h[8])
+{
+    for (int k = 0; k < 8; ++k) {
+        int p = k;
+        double best = fabs(A[k][k]);
+        for (int i = k + 1; i < 8; ++i)
+            if (fabs(A[i][k]) > best) { best = fabs(A[i][k]); p = i; }
+        if (best == 0.0) return false;
+        if (p != k) {
+            for (int j = 0; j < 8; ++j) { double t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
+            double t = r[k]; r[k] = r[p]; r[p] = t;
+        }
+        for (int i = k + 1; i < 8; ++i) {
+            const double f = A[i][k] / A[k][k];
+            for (int j = k + 1; j < 8; ++j) A[i][j] = A[i][j] - f * A[k][j];
+            r[i] = r[i] - f * r[k];
+        }
+    }
+    for (int i = 7; i >= 0; --i) {
+        double s = r[i];
+        for (int j = i + 1; j < 8; ++j) s = s - A[i][j] * h[j];
+        h[i] = s / A[i][i];
+    }
+    return true;
+}
+
+__device__ static void matmul3(const double a[9], const double b[9], double c[9])
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = a[i * 3 + 0] * b[0 * 3 + j];
+            s = s + a[i * 3 + 1] * b[1 * 3 + j];
+            s = s + a[i * 3 + 2] * b[2 * 3 + j];
+            c[i * 3 + j] = s;
+        }
+}
+
+// src/dst: 4 points (x, y) each, already exactly representable in float32.
+__device__ static bool homography4(const double src[8], const double dst[8], double H[9])
+{
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0;
+    for (int i = 0; i < 4; ++i) { cmx += dst[2 * i]; cmy += dst[2 * i + 1]; cMx += src[2 * i]; cMy += src[2 * i + 1]; }
+    cmx /= 4; cmy /= 4; cMx /= 4; cMy /= 4;
+    double smx = 0, smy = 0, sMx = 0, sMy = 0;
+    for (int i = 0; i < 4; ++i) {
+        smx += fabs(dst[2 * i] - cmx); smy += fabs(dst[2 * i + 1] - cmy);
+        sMx += fabs(src[2 * i] - cMx); sMy += fabs(src[2 * i + 1] - cMy);
+    }
+    const double eps = 2.220446049250313e-16;   // DBL_EPSILON
+    if (fabs(smx) < eps || fabs(smy) < eps || fabs(sMx) < eps || fabs(sMy) < eps) return false;
+    smx = 4 / smx; smy = 4 / smy; sMx = 4 / sMx; sMy = 4 / sMy;
+    const double invHnorm[9] = { 1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1 };
+    const double Hnorm2[9] = { sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1 };
+    double A[8][8], r[8], h[8];
+    for (int i = 0; i < 4; ++i) {
+        const double x = (dst[2 * i] - cmx) * smx, y = (dst[2 * i + 1] - cmy) * smy;
+        const double X = (src[2 * i] - cMx) * sMx, Y = (src[2 * i + 1] - cMy) * sMy;
+        const double Lx[9] = { X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x };
+        const double Ly[9] = { 0, 0, 0, X, Y, 1, -y * X, -y * Y, -y };
+        for (int j = 0; j < 8; ++j) { A[2 * i][j] = Lx[j]; A[2 * i + 1][j] = Ly[j]; }
+        r[2 * i] = -Lx[8]; r[2 * i + 1] = -Ly[8];
+    }
+    if (!solve8(A, r, h)) return false;
+    const double H0[9] = { h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], 1.0 };
+    double Ht[9], Hd[9];
+    matmul3(invHnorm, H0, Ht);
+    matmul3(Ht, Hnorm2, Hd);
+    const double sc = 1.0 / Hd[8];
+    for (int i = 0; i < 9; ++i) H[i] = Hd[i] * sc;
+    return true;
+}
+
+// cv::invert 3x3 closed form (what cv2.warpPerspective applies to the forward homography).
+__device__ static void invert3x3(const double S[9], double t[9])
+{
+#define Sd(y, x) S[(y) * 3 + (x)]
+    double d = Sd(0,0) * (Sd(1,1) * Sd(2,2) - Sd(1,2) * Sd(2,1))
+             - Sd(0,1) * (Sd(1,0) * Sd(2,2) - Sd(1,2) * Sd(2,0))
+             + Sd(0,2) * (Sd(1,0) * Sd(2,1) - Sd(1,1) * Sd(2,0));
+    if (d == 0.0) { for (int i = 0; i < 9; ++i) t[i] = 0; return; }
+    d = 1.0 / d;
+    t[0] = (Sd(1,1) * Sd(2,2) - Sd(1,2) * Sd(2,1)) * d;
+    t[1] = (Sd(0,2) * Sd(2,1) - Sd(0,1) * Sd(2,2)) * d;
+    t[2] = (Sd(0,1) * Sd(1,2) - Sd(0,2) * Sd(1,1)) * d;
+    t[3] = (Sd(1,2) * Sd(2,0) - Sd(1,0) * Sd(2,2)) * d;
+    t[4] = (Sd(0,0) * Sd(2,2) - Sd(0,2) * Sd(2,0)) * d;
+    t[5] = (Sd(0,2) * Sd(1,0) - Sd(0,0) * Sd(1,2)) * d;
+    t[6] = (Sd(1,0) * Sd(2,1) - Sd(1,1) * Sd(2,0)) * d;
+    t[7] = (Sd(0,1) * Sd(2,0) - Sd(0,0) * Sd(2,1)) * d;
+    t[8] = (Sd(0,0) * Sd(1,1) - Sd(0,1) * Sd(1,0)) * d;
+#undef Sd
+}
+
+// Conservative box of the pixels where the cell's warped mask can be non-zero: the forward image of the
+// rect dilated by one pixel is a convex quad when the forward denominator is positive on its corners, and
+// every pixel passing the mask test maps (projectively) into that dilated rect; +-2 px of slack covers the
+// rounding of M = inverse(H_fwd).  Anything odd falls back to the whole frame.
+__device__ static void cell_bbox(const double Hf[9], const double M[9], double L, double T, double Rt, double B,
+                                 int W, int H, double bbox[4])
+{
+    const double qx[4] = { L - 1, Rt + 1, L - 1, Rt + 1 };
+    const double qy[4] = { T - 1, T - 1, B + 1, B + 1 };
+    const double fx[4] = { 0, (double)(W - 1), 0, (double)(W - 1) };
+    const double fy[4] = { 0, 0, (double)(H - 1), (double)(H - 1) };
+    bool ok = true;
+    double x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    for (int i = 0; i < 4 && ok; ++i) {
+        const double den = (Hf[6] * qx[i] + Hf[7] * qy[i]) + Hf[8];
+        const double wf = (M[6] * fx[i] + M[7] * fy[i]) + M[8];
+        if (!(den > 1e-3) || !(wf > 1e-3)) { ok = false; break; }
+        const double px = ((Hf[0] * qx[i] + Hf[1] * qy[i]) + Hf[2]) / den;
+        const double py = ((Hf[3] * qx[i] + Hf[4] * qy[i]) + Hf[5]) / den;
+        if (!(fabs(px) < 1e9) || !(fabs(py) < 1e9)) { ok = false; break; }
+        if (i == 0) { x0 = x1 = px; y0 = y1 = py; }
+        else {
+            if (px < x0) x0 = px;
+            if (px > x1) x1 = px;
+            if (py < y0) y0 = py;
+            if (py > y1) y1 = py;
+        }
+    }
+    if (!ok) { bbox[0] = 0; bbox[1] = 0; bbox[2] = W - 1; bbox[3] = H - 1; return; }
+    x0 = floor(x0) - 2; y0 = floor(y0) - 2; x1 = ceil(x1) + 2; y1 = ceil(y1) + 2;
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 > W - 1) x1 = W - 1;
+    if (y1 > H - 1) y1 = H - 1;
+    if (x0 > x1 || y0 > y1) { bbox[0] = 1; bbox[1] = 1; bbox[2] = 0; bbox[3] = 0; return; }
+    bbox[0] = x0; bbox[1] = y0; bbox[2] = x1; bbox[3] = y1;
+}
+
+__global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict__ unstab,
+                                                        const double* __restrict__ stab, int n, int W, int H, int R,
+                                                        int C, double* __restrict__ records,
+                                                        CellBox* __restrict__ boxes, int32_t* __restrict__ crop,
+                                                        int32_t* __restrict__ status)
+{
+    const int ncell = R * C;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < n) {                         // per-frame crop defaults, meshflowstabilizer.py:992-995
+        crop[4 * gid + 0] = 0; crop[4 * gid + 1] = 0; crop[4 * gid + 2] = W - 1; crop[4 * gid + 3] = H - 1;
+    }
+    if (gid >= (long long)n * ncell) return;
+    const int f = (int)(gid / ncell);
+    const int k = (int)(gid % ncell);
+    const int r = k / C, c = k % C;
+    const size_t vbase = (size_t)f * (R + 1) * (C + 1);
+    double ub[8], sb[8];
+    for (int q = 0; q < 4; ++q) {          // TL, TR, BL, BR
+        const int rr = r + (q >> 1), cc = c + (q & 1);
+        const size_t v = vbase + (size_t)rr * (C + 1) + cc;
+        const double gx = (double)(float)ceil((double)(W - 1) * ((double)cc / (double)C));
+        const double gy = (double)(float)ceil((double)(H - 1) * ((double)rr / (double)R));
+        ub[2 * q] = gx; ub[2 * q + 1] = gy;
+        // stabilized vertex = grid + (stabilized - unstabilized displacement) in float64, then float32
+        sb[2 * q] = (double)(float)(gx + (stab[2 * v] - unstab[2 * v]));
+        sb[2 * q + 1] = (double)(float)(gy + (stab[2 * v + 1] - unstab[2 * v + 1]));
+    }
+    double Hf[9], Hi[9];
+    const bool ok = homography4(ub, sb, Hf) && homography4(sb, ub, Hi);
+    double* rec = records + (size_t)gid * MF_CELL_DOUBLES;
+    for (int i = 0; i < MF_CELL_DOUBLES; ++i) rec[i] = 0.0;
+    const double L = floor(fmin(fmin(ub[0], ub[2]), fmin(ub[4], ub[6])));
+    const double Rt = ceil(fmax(fmax(ub[0], ub[2]), fmax(ub[4], ub[6])));
+    const double T = floor(fmin(fmin(ub[1], ub[3]), fmin(ub[5], ub[7])));
+    const double B = ceil(fmax(fmax(ub[1], ub[3]), fmax(ub[5], ub[7])));
+    rec[MF_CELL_OFF_RECT + 0] = L; rec[MF_CELL_OFF_RECT + 1] = T;
+    rec[MF_CELL_OFF_RECT + 2] = Rt; rec[MF_CELL_OFF_RECT + 3] = B;
+    CellBox box;
+    if (!ok) {
+        rec[MF_CELL_OFF_STATUS] = 1.0;
+        rec[MF_CELL_OFF_BBOX + 0] = 1; rec[MF_CELL_OFF_BBOX + 1] = 1; rec[MF_CELL_OFF_BBOX + 2] = 0; rec[MF_CELL_OFF_BBOX + 3] = 0;
+        box.x0 = 1; box.y0 = 1; box.x1 = 0; box.y1 = 0;
+        atomicAdd(status, 1);
+    } else {
+        double M[9], bb[4];
+        invert3x3(Hf, M);
+        cell_bbox(Hf, M, L, T, Rt, B, W, H, bb);
+        for (int i = 0; i < 9; ++i) { rec[MF_CELL_OFF_M + i] = M[i]; rec[MF_CELL_OFF_HI + i] = Hi[i]; }
+        for (int i = 0; i < 4; ++i) rec[MF_CELL_OFF_BBOX + i] = bb[i];
+        box.x0 = (int16_t)bb[0]; box.y0 = (int16_t)bb[1]; box.x1 = (int16_t)bb[2]; box.y1 = (int16_t)bb[3];
+    }
+    boxes[gid] = box;
+}
+
+int launch_cell_table(const double* unstab, const double* stab, int n, int W, int H, int R, int C,
+                      double* records, CellBox* boxes, int32_t* crop, int32_t* status, hipStream_t st)
+{
+    if (n <= 0 || R <= 0 || C <= 0 || W < 2 || H < 2 || W > 32767 || H > 32767 || R * C > 4096) {
+        set_error("mf_cell_table_f64: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
+        return MF_ERR_INVALID_ARG;
+    }
+    const long long total = (long long)n * R * C;
+    const long long threads = total > n ? total : n;
+    const unsigned blocks = (unsigned)((threads + 63) / 64);
+    hipLaunchKernelGGL(cell_table_kernel, dim3(blocks), dim3(64), 0, st, unstab, stab, n, W, H, R, C, records, boxes,
+                       crop, status);
+    return hip_fail(hipGetLastError(), "cell_table_kernel launch");
+}
+
+}  // namespace mf

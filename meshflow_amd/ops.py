@@ -1,0 +1,122 @@
+"""Device-level operators: torch tensors in, torch tensors out, HIP kernels underneath.
+
+torch is used only for device memory, streams and (in `dist.py`) torch.distributed; every operator
+hands raw device pointers to libmeshflow_hip.so through the C ABI (`_lib.py`) on torch's current
+stream, so torch.cuda events and synchronisation see the kernels."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_lib_ = _lib.lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _need(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f'{name} must be a CUDA/HIP torch tensor')
+    if t.dtype != dtype:
+        raise ValueError(f'{name} must have dtype {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name} must be contiguous')
+
+
+def jacobi(b, taps, lam, inv_on, omega, iters, out=None):
+    """`iters` Jacobi sweeps for all S series at once (mfs.py:844-878 x every vertex).
+    b: (F, S) float64 device tensor, frame-major.  Returns x (F, S)."""
+    _need(b, torch.float64, 'b')
+    for name, t in (('taps', taps), ('lam', lam), ('inv_on', inv_on)):
+        _need(t, torch.float64, name)
+    F, S = b.shape
+    if taps.numel() != 2 * omega + 1 or lam.numel() != F or inv_on.numel() != F:
+        raise ValueError('coefficient sizes do not match (F, omega)')
+    x = out if out is not None else torch.empty_like(b)
+    _need(x, torch.float64, 'out')
+    _lib.check(_lib_.mf_jacobi_f64(_ptr(b), _ptr(x), _ptr(taps), _ptr(lam), _ptr(inv_on), F, S, int(omega),
+                                   int(iters), _stream()))
+    return x
+
+
+class CellTable:
+    """Per-cell records + compact boxes of n frames (layout: include/meshflow_hip.h)."""
+
+    def __init__(self, n, W, H, R, C, device):
+        self.n, self.W, self.H, self.R, self.C = n, W, H, R, C
+        nbytes = _lib_.mf_cell_table_bytes(n, R, C)
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.crop = torch.empty((n, 4), dtype=torch.int32, device=device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def records(self):
+        """(n, R*C, 32) float64 view of the records (for tests)."""
+        nrec = self.n * self.R * self.C
+        return self.buf[:nrec * _lib.CELL_DOUBLES * 8].view(torch.float64).view(self.n, self.R * self.C, _lib.CELL_DOUBLES)
+
+    def check(self):
+        """Raise if a cell had no homography (the reference would fail inside cv2.warpPerspective)."""
+        bad = int(self.status.item())
+        if bad:
+            raise ValueError(f'{bad} degenerate mesh cell(s): no homography exists '
+                             '(cv2.findHomography would return None)')
+
+
+def cell_table(unstab, stab, W, H, R, C, table=None):
+    """Per-cell homographies of n frames (mfs.py:1039-1048).  unstab/stab: (n, R+1, C+1, 2) or (n, V*2)
+    float64 device tensors.  Also resets the per-frame crop values to their defaults (mfs.py:992-995)."""
+    _need(unstab, torch.float64, 'unstab')
+    _need(stab, torch.float64, 'stab')
+    n = unstab.shape[0]
+    V2 = (R + 1) * (C + 1) * 2
+    if unstab.numel() != n * V2 or stab.numel() != n * V2:
+        raise ValueError('displacement tensors do not match (n, R+1, C+1, 2)')
+    if table is None:
+        table = CellTable(n, W, H, R, C, unstab.device)
+    else:
+        table.status.zero_()
+    _lib.check(_lib_.mf_cell_table_f64(_ptr(unstab), _ptr(stab), n, W, H, R, C, _ptr(table.buf), _ptr(table.crop),
+                                       _ptr(table.status), _stream()))
+    return table
+
+
+def warp(frames, table, border_bgr=(0, 0, 255), out=None):
+    """Mesh warp + crop scan of n frames (mfs.py:1000-1100).  frames: (n, H, W, 3) uint8 device tensor.
+    Returns the stabilized frames; per-frame crop values accumulate in table.crop."""
+    _need(frames, torch.uint8, 'frames')
+    n, H, W, ch = frames.shape
+    if ch != 3 or (n, W, H) != (table.n, table.W, table.H):
+        raise ValueError('frames do not match the cell table (n, H, W, 3)')
+    if out is None:
+        out = torch.empty_like(frames)
+    _need(out, torch.uint8, 'out')
+    border = (ctypes.c_uint8 * 3)(*[int(np.clip(round(float(v)), 0, 255)) for v in border_bgr[:3]])
+    _lib.check(_lib_.mf_warp_u8c3(_ptr(frames), _ptr(out), _ptr(table.buf), n, W, H, table.R, table.C, border,
+                                  _ptr(table.crop), _stream()))
+    return out
+
+
+def crop_reduce(crop, W, H):
+    """Clip-level bounds (mfs.py:1103-1106): int32 tensor {left, top, right, bottom}."""
+    _need(crop, torch.int32, 'crop')
+    bounds = torch.empty(4, dtype=torch.int32, device=crop.device)
+    _lib.check(_lib_.mf_crop_reduce(_ptr(crop), crop.shape[0], W, H, _ptr(bounds), _stream()))
+    return bounds
+
+
+def crop_resize(frames, bounds, out=None):
+    """Crop to inclusive (left, top, right, bottom) and resize back to (W, H) (mfs.py:1111-1157)."""
+    _need(frames, torch.uint8, 'frames')
+    n, H, W, _ = frames.shape
+    left, top, right, bottom = (int(v) for v in bounds)
+    if out is None:
+        out = torch.empty_like(frames)
+    _lib.check(_lib_.mf_crop_resize_u8c3(_ptr(frames), _ptr(out), n, W, H, left, top, right, bottom, _stream()))
+    return out

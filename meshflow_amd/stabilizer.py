@@ -1,0 +1,192 @@
+"""`MeshFlowStabilizer`: the reference's class surface with its two hot methods on an MI355X.
+
+Mirrors /root/reference/meshflowstabilizer.py (`mfs.py`): constructor keywords and defaults
+(mfs.py:43-49), the four enum values and two constants (mfs.py:32-40), `stabilize(input_path,
+output_path, adaptive_weights_definition)` and its `(cropping_ratio, distortion_score,
+stability_score)` return (mfs.py:102-169), and the two private methods that form the drop-in boundary:
+
+    _get_stabilized_vertex_displacements          mfs.py:632-710    Jacobi sweep      -> HIP kernel 1
+    _get_stabilized_frames_and_crop_boundaries    mfs.py:909-1108   mesh warp + crop  -> HIP kernels 2a/2b
+
+Both take and return NumPy arrays exactly like the reference (host buffers in, host buffers out); the
+`*_device` variants keep everything in HBM and are what `stabilize_clip` and bench.py use.  Video
+decode/encode, the FAST/LK/RANSAC front-end and the two feature-based metrics are outside this path
+(they need OpenCV); `stabilize()` needs `cv2` for them and says so when it is missing.
+"""
+import numpy as np
+
+from . import host
+
+try:  # progress bars are optional
+    import tqdm as _tqdm  # noqa: F401
+except Exception:  # pragma: no cover
+    _tqdm = None
+
+
+class MeshFlowStabilizer:
+    ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL = 0
+    ADAPTIVE_WEIGHTS_DEFINITION_FLIPPED = 1
+    ADAPTIVE_WEIGHTS_DEFINITION_CONSTANT_HIGH = 2
+    ADAPTIVE_WEIGHTS_DEFINITION_CONSTANT_LOW = 3
+
+    ADAPTIVE_WEIGHTS_DEFINITION_CONSTANT_HIGH_VALUE = 100
+    ADAPTIVE_WEIGHTS_DEFINITION_CONSTANT_LOW_VALUE = 1
+
+    def __init__(self, mesh_row_count=16, mesh_col_count=16,
+                 mesh_outlier_subframe_row_count=4, mesh_outlier_subframe_col_count=4,
+                 feature_ellipse_row_count=10, feature_ellipse_col_count=10,
+                 homography_min_number_corresponding_features=4,
+                 temporal_smoothing_radius=10, optimization_num_iterations=100,
+                 color_outside_image_area_bgr=(0, 0, 255),
+                 visualize=False, device=None):
+        self.mesh_col_count = mesh_col_count
+        self.mesh_row_count = mesh_row_count
+        self.mesh_outlier_subframe_row_count = mesh_outlier_subframe_row_count
+        self.mesh_outlier_subframe_col_count = mesh_outlier_subframe_col_count
+        self.feature_ellipse_row_count = feature_ellipse_row_count
+        self.feature_ellipse_col_count = feature_ellipse_col_count
+        self.homography_min_number_corresponding_features = homography_min_number_corresponding_features
+        self.temporal_smoothing_radius = temporal_smoothing_radius
+        self.optimization_num_iterations = optimization_num_iterations
+        self.color_outside_image_area_bgr = color_outside_image_area_bgr
+        self.visualize = visualize
+        self.device = device          # extra keyword: torch device string; None = current HIP device
+
+    # ------------------------------------------------------------------------------------------
+    # public API
+    # ------------------------------------------------------------------------------------------
+
+    @staticmethod
+    def _check_definition(adaptive_weights_definition):
+        if adaptive_weights_definition not in host.VALID_DEFINITIONS:          # mfs.py:136-146
+            raise ValueError(
+                'Invalid value for `adaptive_weights_definition`. Expecting value of '
+                '`MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL`, '
+                '`MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_FLIPPED`, '
+                '`MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_CONSTANT_HIGH`, or'
+                '`MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_CONSTANT_LOW`.')
+
+    def stabilize(self, input_path, output_path, adaptive_weights_definition=ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL):
+        """Same contract as mfs.py:102-169.  The stages outside the accelerated path (video I/O,
+        feature tracking, feature-based metrics) are OpenCV calls in the reference and need `cv2`."""
+        self._check_definition(adaptive_weights_definition)
+        try:
+            import cv2  # noqa: F401
+        except ImportError as e:
+            raise ImportError(
+                'MeshFlowStabilizer.stabilize(path, path) needs OpenCV (cv2) for video decode/encode and the '
+                'FAST/LK/RANSAC front-end, which are outside the MI355X path. Use stabilize_clip(frames, '
+                'vertex_unstabilized_displacements, homographies) with in-memory inputs instead.') from e
+        raise NotImplementedError(
+            'video I/O and the feature front-end (mfs.py:172-629, 1160-1212, 1290-1322) are not part of this '
+            'build; feed stabilize_clip() from your own decoder/tracker')
+
+    def stabilize_clip(self, unstabilized_frames, vertex_unstabilized_displacements_by_frame_index, homographies,
+                       adaptive_weights_definition=ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL):
+        """The hot path of `stabilize` (mfs.py:150-158, 162) on in-memory inputs.
+
+        Returns (stabilized_frames list, crop_boundaries, vertex_stabilized_displacements, stability_score)."""
+        self._check_definition(adaptive_weights_definition)
+        num_frames = len(unstabilized_frames)
+        stab = self._get_stabilized_vertex_displacements(
+            num_frames, unstabilized_frames, adaptive_weights_definition,
+            vertex_unstabilized_displacements_by_frame_index, homographies)
+        frames, bounds = self._get_stabilized_frames_and_crop_boundaries(
+            num_frames, unstabilized_frames, vertex_unstabilized_displacements_by_frame_index, stab)
+        return frames, bounds, stab, self._compute_stability_score(num_frames, stab)
+
+    # ------------------------------------------------------------------------------------------
+    # drop-in boundary, host buffers (same signatures as the reference)
+    # ------------------------------------------------------------------------------------------
+
+    def _torch_device(self):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError('no MI355X visible: the meshflow_amd hot path has no CPU fallback')
+        return torch.device(self.device if self.device is not None else f'cuda:{torch.cuda.current_device()}')
+
+    def _get_stabilized_vertex_displacements(self, num_frames, unstabilized_frames, adaptive_weights_definition,
+                                             vertex_unstabilized_displacements_by_frame_index, homographies):
+        """mfs.py:632-710.  float64 (F, R+1, C+1, 2) in, float64 (F, R+1, C+1, 2) out."""
+        import torch
+        disp = np.ascontiguousarray(vertex_unstabilized_displacements_by_frame_index, dtype=np.float64)
+        self._check_mesh_shape(disp, num_frames)
+        frame_height, frame_width = unstabilized_frames[0].shape[:2]                       # mfs.py:679
+        dev = self._torch_device()
+        d_disp = torch.from_numpy(disp).to(dev)
+        d_stab = self._stabilized_vertex_displacements_device(d_disp, frame_width, frame_height,
+                                                              adaptive_weights_definition, homographies)
+        return d_stab.cpu().numpy()
+
+    def _get_stabilized_frames_and_crop_boundaries(self, num_frames, unstabilized_frames,
+                                                   vertex_unstabilized_displacements_by_frame_index,
+                                                   vertex_stabilized_displacements_by_frame_index):
+        """mfs.py:909-1108.  Returns (list of F uint8 (H, W, 3) arrays, (left, top, right, bottom))."""
+        import torch
+        dev = self._torch_device()
+        unstab = np.ascontiguousarray(vertex_unstabilized_displacements_by_frame_index, dtype=np.float64)
+        stab = np.ascontiguousarray(vertex_stabilized_displacements_by_frame_index, dtype=np.float64)
+        self._check_mesh_shape(unstab, num_frames)
+        self._check_mesh_shape(stab, num_frames)
+        if isinstance(unstabilized_frames, np.ndarray):
+            stack = np.ascontiguousarray(unstabilized_frames, dtype=np.uint8)
+        else:
+            stack = np.stack([np.asarray(f, dtype=np.uint8) for f in unstabilized_frames])
+        if stack.ndim != 4 or stack.shape[0] != num_frames or stack.shape[3] != 3:
+            raise ValueError('unstabilized_frames must be num_frames arrays of shape (H, W, 3)')
+        d_frames = torch.from_numpy(stack).to(dev)
+        d_out, d_crop = self._stabilized_frames_device(d_frames, torch.from_numpy(unstab).to(dev),
+                                                       torch.from_numpy(stab).to(dev))
+        out = d_out.cpu().numpy()
+        crop = d_crop.cpu().numpy()
+        left, top = crop[:, 0].max(), crop[:, 1].max()                                      # mfs.py:1103-1106
+        right, bottom = crop[:, 2].min(), crop[:, 3].min()
+        return list(out), (np.int64(left), np.int64(top), np.int64(right), np.int64(bottom))
+
+    def _compute_stability_score(self, num_frames, vertex_stabilized_displacements_by_frame_index):
+        """mfs.py:1216-1259."""
+        return host.stability_score(np.asarray(vertex_stabilized_displacements_by_frame_index))
+
+    def _get_vertex_x_y(self, frame_width, frame_height):
+        """mfs.py:881-906."""
+        return host.vertex_x_y(frame_width, frame_height, self.mesh_row_count, self.mesh_col_count)
+
+    # ------------------------------------------------------------------------------------------
+    # device-resident variants (torch tensors in HBM)
+    # ------------------------------------------------------------------------------------------
+
+    def _check_mesh_shape(self, disp, num_frames):
+        want = (num_frames, self.mesh_row_count + 1, self.mesh_col_count + 1, 2)
+        if tuple(disp.shape) != want:
+            raise ValueError(f'vertex displacements must have shape {want}, got {tuple(disp.shape)}')
+
+    def _jacobi_coefficients_device(self, num_frames, frame_width, frame_height, adaptive_weights_definition,
+                                    homographies, device):
+        import torch
+        taps, lam, inv_on = host.jacobi_band_coefficients(
+            num_frames, frame_width, frame_height, adaptive_weights_definition,
+            np.asarray(homographies, dtype=np.float64), self.temporal_smoothing_radius)
+        packed = torch.from_numpy(np.concatenate([taps, lam, inv_on])).to(device)
+        nt = taps.size
+        return packed[:nt], packed[nt:nt + num_frames], packed[nt + num_frames:]
+
+    def _stabilized_vertex_displacements_device(self, d_disp, frame_width, frame_height,
+                                                adaptive_weights_definition, homographies):
+        """d_disp: (F, R+1, C+1, 2) float64 device tensor -> same shape, stabilized."""
+        from . import ops
+        F = d_disp.shape[0]
+        taps, lam, inv_on = self._jacobi_coefficients_device(F, frame_width, frame_height,
+                                                             adaptive_weights_definition, homographies, d_disp.device)
+        x = ops.jacobi(d_disp.reshape(F, -1), taps, lam, inv_on, self.temporal_smoothing_radius,
+                       self.optimization_num_iterations)
+        return x.view(d_disp.shape)
+
+    def _stabilized_frames_device(self, d_frames, d_unstab, d_stab, out=None, table=None):
+        """d_frames: (n, H, W, 3) uint8; d_unstab/d_stab: (n, R+1, C+1, 2) float64, all in HBM.
+        Returns (stabilized frames (n, H, W, 3) uint8, per-frame crop values (n, 4) int32), in HBM."""
+        from . import ops
+        n, H, W, _ = d_frames.shape
+        table = ops.cell_table(d_unstab, d_stab, W, H, self.mesh_row_count, self.mesh_col_count, table=table)
+        out = ops.warp(d_frames, table, self.color_outside_image_area_bgr, out=out)
+        table.check()
+        return out, table.crop

@@ -54,14 +54,14 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
-def jacobi_banded(b, taps, lam, inv_on, omega, iters):
+def jacobi_banded(b, taps, lam, inv_on, omega, iters, openmp=False):
     b = np.ascontiguousarray(b, dtype=np.float64)
     F, S = b.shape
     x = np.empty_like(b)
     taps = np.ascontiguousarray(taps, dtype=np.float64)
     lam = np.ascontiguousarray(lam, dtype=np.float64)
     inv_on = np.ascontiguousarray(inv_on, dtype=np.float64)
-    load().mfo_jacobi_banded(_p(b, _dp), _p(x, _dp), _p(taps, _dp), _p(lam, _dp), _p(inv_on, _dp), F, S, omega, iters)
+    load(openmp).mfo_jacobi_banded(_p(b, _dp), _p(x, _dp), _p(taps, _dp), _p(lam, _dp), _p(inv_on, _dp), F, S, omega, iters)
     return x
 
 

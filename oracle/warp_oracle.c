@@ -44,6 +44,9 @@ void mfo_jacobi_banded(const double* b, double* x_out, const double* taps, const
     double* nxt = (double*)malloc(n * sizeof(double));
     memcpy(cur, b, n * sizeof(double));                       /* x_start = b, mfs.py:699-703, 871 */
     for (int it = 0; it < iters; ++it) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
         for (int t = 0; t < F; ++t) {
             double two_lam = 2.0 * lam[t];
             for (int s = 0; s < S; ++s) {

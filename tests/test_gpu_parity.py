@@ -1,0 +1,253 @@
+"""Parity of the HIP path against the oracle, through the C ABI.  Needs a real MI355X (-m gpu).
+
+Bars (BASELINE.json north_star): stabilized vertex paths within 1e-4 of the reference; warped uint8
+pixels within 1 LSB.  What is asserted here is tighter: paths within 1e-9 of the reference's own
+outputs and bit-identical to the C oracle; cell tables, pixels and crop values bit-identical to the
+C oracle."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: the -m gpu tests must run on an MI355X')
+    return torch.device('cuda:0')
+
+
+def _coeffs(F, W, H, definition, hom, omega):
+    from oracle import meshflow_oracle as mo
+    taps, lam, on = mo.jacobi_band_coefficients(F, W, H, definition, hom, omega)
+    return taps, lam, np.reciprocal(on)
+
+
+def _hip_jacobi(dev, b, taps, lam, inv_on, omega, iters):
+    from meshflow_amd import ops
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    x = ops.jacobi(t(b), t(taps), t(lam), t(inv_on), omega, iters)
+    torch.cuda.synchronize()
+    return x.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------- Jacobi
+
+@pytest.mark.parametrize('definition', [0, 1, 2, 3])
+def test_jacobi_small_vs_reference_golden(dev, golden_dir, definition):
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    g = np.load(os.path.join(golden_dir, 'jacobi_small.npz'))
+    s = MeshFlowStabilizer(mesh_row_count=int(g['R']), mesh_col_count=int(g['C']),
+                           temporal_smoothing_radius=int(g['omega']), optimization_num_iterations=int(g['iters']))
+    frames = [np.zeros((int(g['height']), int(g['width']), 3), np.uint8)]
+    got = s._get_stabilized_vertex_displacements(int(g['F']), frames, definition, g['disp'], g['hom'])
+    want = g[f'stab_D{definition}']
+    assert got.shape == want.shape and got.dtype == np.float64
+    assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max())      # bar: 1e-4
+
+
+@pytest.mark.parametrize('name', ['jacobi_cfg2_subset', 'jacobi_cfg2_high_subset', 'jacobi_cfg3_subset'])
+def test_jacobi_config_sized_vs_reference_golden(dev, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    F, omega, iters = int(g['F']), int(g['omega']), int(g['iters'])
+    taps, lam, inv_on = _coeffs(F, int(g['width']), int(g['height']), int(g['definition']), g['hom'], omega)
+    b = np.ascontiguousarray(g['inputs'].reshape(F, -1))
+    x = _hip_jacobi(dev, b, taps, lam, inv_on, omega, iters).reshape(g['outputs'].shape)
+    assert np.abs(x - g['outputs']).max() <= 1e-9 * max(1.0, np.abs(g['outputs']).max())   # bar: 1e-4
+
+
+@pytest.mark.parametrize('F,S,omega,iters', [
+    (300, 578, 10, 100),      # cfg2, specialised <10,5>
+    (320, 6, 10, 7), (321, 6, 10, 7), (640, 4, 10, 5), (1200, 4, 10, 20), (2400, 2, 10, 10),
+    (600, 10, 30, 20), (1216, 2, 30, 5), (2432, 2, 30, 3),
+    (1, 3, 10, 4), (2, 3, 10, 4), (11, 5, 10, 30),
+    (50, 7, 5, 13), (17, 3, 1, 9), (3000, 2, 10, 3), (700, 3, 40, 6),   # generic kernel
+])
+def test_jacobi_bit_exact_vs_c_oracle(dev, F, S, omega, iters):
+    from meshflow_amd import synthetic
+    from oracle import clib
+    n = np.arange(F * S, dtype=np.int64).reshape(F, S)
+    b = np.cumsum(3.0 * synthetic.normal(n, seed=F + S), axis=0)
+    d = np.arange(-omega, omega + 1)
+    taps = np.exp(-np.square((3 / omega) * d))
+    lam = 0.2 + 0.75 * synthetic.uniform01(np.arange(F), seed=9)
+    inv_on = 1.0 / (1 + 2 * lam * taps.sum())
+    want = clib.jacobi_banded(b, taps, lam, inv_on, omega, iters)
+    got = _hip_jacobi(dev, b, taps, lam, inv_on, omega, iters)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_jacobi_full_cfg3_properties(dev):
+    """Full config-3 size (F=600, 32x32 mesh, omega=30, 200 sweeps): linearity and constant-path fixed point."""
+    from meshflow_amd import synthetic
+    F, R, C, omega, iters = 600, 32, 32, 30, 200
+    disp, hom = synthetic.motion(F, R, C, seed=0)
+    taps, lam, inv_on = _coeffs(F, 1920, 1080, 0, hom, omega)
+    b = disp.reshape(F, -1)
+    x1 = _hip_jacobi(dev, b, taps, lam, inv_on, omega, iters)
+    x2 = _hip_jacobi(dev, 2.0 * b, taps, lam, inv_on, omega, iters)
+    np.testing.assert_array_equal(x2, 2.0 * x1)                 # scaling by 2 is exact in binary fp
+    assert np.isfinite(x1).all()
+    # smoothing reduces the high-frequency content of every path
+    assert np.abs(np.diff(x1, n=2, axis=0)).mean() < 0.5 * np.abs(np.diff(b, n=2, axis=0)).mean()
+
+
+def test_jacobi_host_wrapper(dev):
+    from meshflow_amd import _lib, synthetic
+    from oracle import clib
+    F, S, omega, iters = 64, 10, 10, 12
+    b = np.ascontiguousarray(synthetic.normal(np.arange(F * S).reshape(F, S), 4))
+    taps = np.exp(-np.square((3 / omega) * np.arange(-omega, omega + 1)))
+    lam = np.full(F, 0.5)
+    inv_on = np.full(F, 0.1)
+    x = np.empty_like(b)
+    ms = ctypes.c_float(0)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _lib.check(_lib.lib.mf_jacobi_f64_host(p(b), p(x), p(taps), p(lam), p(inv_on), F, S, omega, iters, ctypes.byref(ms)))
+    np.testing.assert_array_equal(x, clib.jacobi_banded(b, taps, lam, inv_on, omega, iters))
+    assert ms.value > 0
+
+
+# ---------------------------------------------------------------------------------------------- warp
+
+def _clip(F, H, W, R, C, seed, kind='noise', omega=3, iters=10, **kw):
+    from meshflow_amd import synthetic
+    from oracle import meshflow_oracle as mo
+    frames, disp, hom = synthetic.clip(F, H, W, R, C, seed=seed, kind=kind, **kw)
+    stab = mo.stabilized_vertex_displacements(W, H, 0, disp, hom, omega, iters)
+    return frames, disp, stab
+
+
+def _hip_warp(dev, frames, R, C, unstab, stab, border=(0, 0, 255)):
+    from meshflow_amd import ops
+    n, H, W = frames.shape[:3]
+    d_fr = torch.from_numpy(frames).to(dev)
+    table = ops.cell_table(torch.from_numpy(np.ascontiguousarray(unstab)).to(dev),
+                           torch.from_numpy(np.ascontiguousarray(stab)).to(dev), W, H, R, C)
+    out = ops.warp(d_fr, table, border)
+    torch.cuda.synchronize()
+    table.check()
+    return out.cpu().numpy(), table.crop.cpu().numpy(), table.records().cpu().numpy()
+
+
+@pytest.mark.parametrize('H,W,R,C,kw', [
+    (64, 96, 4, 4, dict(jitter_sigma=1.0)),
+    (150, 200, 3, 5, dict(jitter_sigma=0.5)),                       # R != C, H not a multiple of 16
+    (75, 101, 3, 5, dict(jitter_sigma=0.5)),                        # W % 4 != 0: byte-store path
+    (130, 260, 16, 16, dict(jitter_sigma=0.3)),                     # small cells, 256 of them
+    (96, 160, 32, 32, dict(translation_sigma=1.0, field_sigma=0.3)),  # 1024 cells
+    (360, 640, 16, 16, dict(translation_sigma=8.0, jitter_sigma=2.0)),   # demo-video size, strong motion
+])
+def test_warp_bit_exact_vs_c_oracle(dev, H, W, R, C, kw):
+    from oracle import clib
+    frames, disp, stab = _clip(5, H, W, R, C, seed=H + W, **kw)
+    out, crop, rec = _hip_warp(dev, frames, R, C, disp, stab)
+    for f in range(frames.shape[0]):
+        table, bad = clib.cell_table(W, H, R, C, disp[f], stab[f])
+        assert bad == 0
+        np.testing.assert_array_equal(rec[f], table)                      # homographies, rects, boxes
+        want, want_crop = clib.warp_frame(frames[f], R, C, table)          # brute-force owner search
+        np.testing.assert_array_equal(out[f], want)
+        np.testing.assert_array_equal(crop[f], want_crop)
+
+
+def test_warp_matches_numpy_oracle_painter_loop(dev):
+    """Against the reference-shaped per-cell painter loop (oracle/meshflow_oracle.py), small frame."""
+    from oracle import meshflow_oracle as mo
+    H, W, R, C = 48, 80, 4, 4
+    frames, disp, stab = _clip(3, H, W, R, C, seed=11, jitter_sigma=1.5)
+    out, crop, _ = _hip_warp(dev, frames, R, C, disp, stab, border=(10, 200, 30))
+    want, bounds, per_frame = mo.stabilized_frames_and_crop_boundaries(list(frames), R, C, disp, stab, (10, 200, 30))
+    np.testing.assert_array_equal(out, np.stack(want))
+    np.testing.assert_array_equal(crop, per_frame)
+
+
+def test_warp_known_answers(dev):
+    from meshflow_amd import synthetic
+    H, W, R, C = 64, 96, 4, 4
+    frames = synthetic.frames_numpy(2, H, W, seed=1, kind='noise')
+    z = np.zeros((2, R + 1, C + 1, 2))
+    out, crop, _ = _hip_warp(dev, frames, R, C, z, z)
+    np.testing.assert_array_equal(out, frames)                             # identity motion
+    np.testing.assert_array_equal(crop, [[0, 0, W - 1, H - 1]] * 2)
+    s = z.copy(); s[..., 0] = 5; s[..., 1] = -3                            # integer translation
+    out, crop, _ = _hip_warp(dev, frames, R, C, z, s)
+    want = np.empty_like(frames); want[...] = (0, 0, 255)
+    want[:, 0:H - 3, 5:W] = frames[:, 3:H, 0:W - 5]
+    np.testing.assert_array_equal(out, want)
+    np.testing.assert_array_equal(crop, [[5, 0, W - 1, H - 4]] * 2)
+    s = z.copy(); s[..., 0] = 0.5                                          # half-pixel translation
+    out, _, _ = _hip_warp(dev, frames, R, C, z, s)
+    a = frames[:, :, 0:W - 1].astype(np.int64); b = frames[:, :, 1:W].astype(np.int64)
+    np.testing.assert_array_equal(out[:, :, 1:W], ((16 * 32 * a + 16 * 32 * b + 512) >> 10).astype(np.uint8))
+
+
+def test_warp_1080p_vs_c_oracle_and_identity(dev):
+    """Config-2 geometry (1920x1080, 16x16 mesh): 3 frames against the C oracle, plus identity round trip."""
+    from oracle import clib
+    H, W, R, C = 1080, 1920, 16, 16
+    frames, disp, stab = _clip(12, H, W, R, C, seed=0, kind='noise', omega=10, iters=100)
+    sel = [3, 7, 11]
+    out, crop, rec = _hip_warp(dev, frames[sel], R, C, disp[sel], stab[sel])
+    want, want_crop, bad = clib.warp_clip(frames[sel], R, C, disp[sel], stab[sel], use_bbox=True, openmp=True)
+    assert bad == 0
+    np.testing.assert_array_equal(crop, want_crop)
+    assert np.array_equal(out, want), f'{(out != want).sum()} bytes differ'
+    z = np.zeros_like(disp[:2])
+    out, crop, _ = _hip_warp(dev, frames[:2], R, C, z, z)
+    assert np.array_equal(out, frames[:2])
+    np.testing.assert_array_equal(crop, [[0, 0, W - 1, H - 1]] * 2)
+
+
+def test_degenerate_mesh_is_reported(dev):
+    from meshflow_amd import synthetic
+    H, W, R, C = 64, 96, 4, 4
+    frames = synthetic.frames_numpy(1, H, W, seed=1)
+    z = np.zeros((1, R + 1, C + 1, 2))
+    s = z.copy()
+    grid_x = np.array([np.ceil((W - 1) * c / C) for c in range(C + 1)])
+    s[0, :, :, 0] = -grid_x[None, :]                   # collapse every vertex onto x = 0
+    with pytest.raises(ValueError, match='degenerate'):
+        _hip_warp(dev, frames, R, C, z, s)
+
+
+def test_stabilizer_class_end_to_end(dev):
+    """The drop-in boundary with the reference's own signatures (host buffers in and out)."""
+    from meshflow_amd import synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    from oracle import clib, meshflow_oracle as mo
+    F, H, W, R, C = 24, 96, 128, 4, 4
+    frames, disp, hom = synthetic.clip(F, H, W, R, C, seed=2, kind='pattern', jitter_sigma=0.5)
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=5,
+                           optimization_num_iterations=20)
+    out_frames, bounds, stab, score = s.stabilize_clip(list(frames), disp, hom)
+    want_stab = mo.stabilized_vertex_displacements(W, H, 0, disp, hom, 5, 20)
+    assert np.abs(stab - want_stab).max() < 1e-9
+    assert score == mo.stability_score(stab)
+    want, want_crop, _ = clib.warp_clip(frames, R, C, disp, stab)
+    assert isinstance(out_frames, list) and len(out_frames) == F and out_frames[0].shape == (H, W, 3)
+    np.testing.assert_array_equal(np.stack(out_frames), want)
+    assert tuple(int(v) for v in bounds) == (want_crop[:, 0].max(), want_crop[:, 1].max(),
+                                             want_crop[:, 2].min(), want_crop[:, 3].min())
+
+
+def test_warp_host_wrapper(dev):
+    from meshflow_amd import _lib
+    from oracle import clib
+    H, W, R, C = 64, 96, 4, 4
+    frames, disp, stab = _clip(3, H, W, R, C, seed=5, jitter_sigma=1.0)
+    out = np.empty_like(frames)
+    crop = np.zeros((3, 4), np.int32)
+    border = (ctypes.c_uint8 * 3)(0, 0, 255)
+    ms = ctypes.c_float(0)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _lib.check(_lib.lib.mf_warp_u8c3_host(p(frames), p(out), p(np.ascontiguousarray(disp)), p(np.ascontiguousarray(stab)),
+                                          3, W, H, R, C, border, p(crop), ctypes.byref(ms)))
+    want, want_crop, _ = clib.warp_clip(frames, R, C, disp, stab)
+    np.testing.assert_array_equal(out, want)
+    np.testing.assert_array_equal(crop, want_crop)

@@ -1,0 +1,121 @@
+"""Host-side logic of the product (no GPU): coefficients, vertex grid, stability score, sharding, API."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from meshflow_amd import host, synthetic
+from meshflow_amd.stabilizer import MeshFlowStabilizer
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize('F,omega', [(12, 3), (48, 10), (300, 10), (300, 30)])
+@pytest.mark.parametrize('definition', [0, 1, 2, 3])
+def test_band_coefficients_match_reference(golden_dir, F, omega, definition):
+    g = _load(golden_dir, 'coeffs.npz')
+    key = f'F{F}_O{omega}_D{definition}'
+    taps, lam, inv_on = host.jacobi_band_coefficients(F, 1920, 1080, definition, g[key + '_hom'], omega)
+    np.testing.assert_allclose(lam, g[key + '_lam'].astype(np.float64), rtol=1e-15, atol=0)
+    np.testing.assert_allclose(1.0 / inv_on, g[key + '_on'], rtol=1e-13)
+    band = g[key + '_band']
+    mine = -2 * (lam[:, None] * taps[None, :])
+    valid = band != 0
+    np.testing.assert_allclose(mine[valid], band[valid], rtol=1e-15)
+
+
+def test_vertex_grid_matches_reference(golden_dir):
+    g = _load(golden_dir, 'vertex_xy.npz')
+    for key in g.files:
+        W, H, R, C = (int(p[1:]) for p in key.split('_'))
+        got = host.vertex_x_y(W, H, R, C)
+        assert got.dtype == np.float32
+        np.testing.assert_array_equal(got, g[key])
+        s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C)
+        np.testing.assert_array_equal(s._get_vertex_x_y(W, H), g[key])
+
+
+def test_stability_score_matches_reference(golden_dir):
+    g = _load(golden_dir, 'stability.npz')
+    s = MeshFlowStabilizer()
+    for i in range(3):
+        assert s._compute_stability_score(g[f'disp{i}'].shape[0], g[f'disp{i}']) == float(g[f'score{i}'])
+
+
+def test_constructor_and_enums_mirror_reference():
+    s = MeshFlowStabilizer()
+    assert (s.mesh_row_count, s.mesh_col_count) == (16, 16)
+    assert (s.mesh_outlier_subframe_row_count, s.mesh_outlier_subframe_col_count) == (4, 4)
+    assert (s.feature_ellipse_row_count, s.feature_ellipse_col_count) == (10, 10)
+    assert s.homography_min_number_corresponding_features == 4
+    assert (s.temporal_smoothing_radius, s.optimization_num_iterations) == (10, 100)
+    assert s.color_outside_image_area_bgr == (0, 0, 255) and s.visualize is False
+    assert [MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL, MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_FLIPPED,
+            MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_CONSTANT_HIGH,
+            MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_CONSTANT_LOW] == [0, 1, 2, 3]
+    assert MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_CONSTANT_HIGH_VALUE == 100
+    assert MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_CONSTANT_LOW_VALUE == 1
+
+
+def test_bad_definition_raises_value_error_like_reference():
+    s = MeshFlowStabilizer()
+    with pytest.raises(ValueError, match='Invalid value for `adaptive_weights_definition`'):
+        s.stabilize('in.m4v', 'out.m4v', adaptive_weights_definition=7)
+    with pytest.raises(ValueError):
+        s.stabilize_clip([np.zeros((8, 8, 3), np.uint8)], np.zeros((1, 17, 17, 2)), np.eye(3)[None], 4)
+
+
+def test_shard_ranges_cover_all_frames():
+    for F in (1, 7, 300, 1200):
+        for G in (1, 2, 3, 8):
+            spans = [host.shard_range(F, G, r) for r in range(G)]
+            assert spans[0][0] == 0 and spans[-1][1] == F
+            for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+                assert a1 == b0 and a0 <= a1 and b0 <= b1
+    assert host.shard_range(300, 8, 7) == (266, 300)
+
+
+def test_synthetic_generators_are_deterministic_and_torch_matches_numpy():
+    import torch
+    a = synthetic.frames_numpy(3, 20, 28, seed=5, kind='pattern', first_frame=2)
+    b = synthetic.frames_torch(3, 20, 28, torch.device('cpu'), seed=5, kind='pattern', first_frame=2).numpy()
+    np.testing.assert_array_equal(a, b)
+    a = synthetic.frames_numpy(2, 9, 13, seed=1, kind='noise')
+    b = synthetic.frames_torch(2, 9, 13, torch.device('cpu'), seed=1, kind='noise').numpy()
+    np.testing.assert_array_equal(a, b)
+    assert a.std() > 60          # noise frames really are noise
+    d1, h1 = synthetic.motion(20, 4, 4, seed=3)
+    d2, h2 = synthetic.motion(20, 4, 4, seed=3)
+    np.testing.assert_array_equal(d1, d2)
+    np.testing.assert_array_equal(h1[-1], np.identity(3))
+    assert not d1[0].any()
+    np.testing.assert_array_equal(np.diff(d1, axis=0), np.diff(d1, axis=0).astype(np.float32))  # float32 velocities
+
+
+def test_library_exports_every_symbol_in_the_header():
+    """The C-ABI library loads on a machine without a GPU and exports everything include/*.h declares."""
+    from meshflow_amd import _lib
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(here, 'include', 'meshflow_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    declared = set(re.findall(r'\b(mf_[a-z0-9_]+)\s*\(', text))
+    assert declared, 'no declarations found'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(_lib.lib, name), name
+    assert _lib.lib.mf_abi_version() == 1
+    assert _lib.lib.mf_cell_table_bytes(2, 4, 4) == 2 * 16 * (32 * 8 + 8)
+
+
+def test_product_never_imports_the_oracle():
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(here, 'meshflow_amd')
+    for root, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(root, fn)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), fn
+                assert 'liboracle' not in src, fn
