@@ -103,6 +103,10 @@ int mf_crop_reduce(const int32_t* d_crop, int n, int W, int H, int32_t* d_bounds
 int mf_crop_resize_u8c3(const uint8_t* d_frames, uint8_t* d_out, int n, int W, int H,
                         int left, int top, int right, int bottom, void* stream);
 
+/* Device self-test: the warp kernel's trimmed reciprocal (exact for 0.5 <= |w| <= 2) against IEEE 1.0/w on
+ * n hashed inputs; *mismatches receives the number of differing bit patterns (must be 0). Synchronous. */
+int mf_selftest_recip(uint64_t n, uint64_t seed, uint64_t* mismatches);
+
 /* ---- host-buffer convenience wrappers (synchronous; H2D, kernels, D2H on an internal stream) ----
  * These are what a ctypes stub inside the reference's two methods would call.
  * kernel_ms (optional) receives the device time of the kernels alone, measured with HIP events. */

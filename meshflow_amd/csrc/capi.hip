@@ -82,16 +82,17 @@ int mf_jacobi_f64(const double* d_b, double* d_x, const double* d_taps, const do
 size_t mf_cell_table_bytes(int n, int R, int C)
 {
     if (n <= 0 || R <= 0 || C <= 0) return 0;
-    return table_records(n, R, C) * (MF_CELL_DOUBLES * sizeof(double) + sizeof(CellBox));
+    return table_bytes(n, R, C);
 }
 
 int mf_cell_table_f64(const double* d_unstab, const double* d_stab, int n, int W, int H, int R, int C,
                       void* d_table, int32_t* d_crop, int32_t* d_status, void* stream)
 {
     if (!d_unstab || !d_stab || !d_table || !d_crop || !d_status) { set_error("mf_cell_table_f64: null pointer"); return MF_ERR_INVALID_ARG; }
-    double* records = (double*)d_table;
-    CellBox* boxes = (CellBox*)(records + table_records(n, R, C) * MF_CELL_DOUBLES);
-    return launch_cell_table(d_unstab, d_stab, n, W, H, R, C, records, boxes, d_crop, d_status, (hipStream_t)stream);
+    if (n <= 0 || R <= 0 || C <= 0) { set_error("mf_cell_table_f64: bad sizes"); return MF_ERR_INVALID_ARG; }
+    const TableView tv = table_view(d_table, n, R, C);
+    return launch_cell_table(d_unstab, d_stab, n, W, H, R, C, tv.records, tv.boxes, tv.edges, tv.reach, tv.grid, d_crop,
+                             d_status, (hipStream_t)stream);
 }
 
 int mf_warp_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, int n, int W, int H,
@@ -99,9 +100,9 @@ int mf_warp_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, i
 {
     if (!d_frames || !d_out || !d_table || !border_bgr || !d_crop) { set_error("mf_warp_u8c3: null pointer"); return MF_ERR_INVALID_ARG; }
     if (d_frames == d_out) { set_error("mf_warp_u8c3: d_frames and d_out alias"); return MF_ERR_INVALID_ARG; }
-    const double* records = (const double*)d_table;
-    const CellBox* boxes = (const CellBox*)(records + table_records(n, R, C) * MF_CELL_DOUBLES);
-    return launch_warp(d_frames, d_out, records, boxes, n, W, H, R, C, pack_border(border_bgr), d_crop, (hipStream_t)stream);
+    if (n <= 0 || R <= 0 || C <= 0) { set_error("mf_warp_u8c3: bad sizes"); return MF_ERR_INVALID_ARG; }
+    const TableView tv = table_view(const_cast<void*>(d_table), n, R, C);
+    return launch_warp(d_frames, d_out, tv, n, W, H, R, C, pack_border(border_bgr), d_crop, (hipStream_t)stream);
 }
 
 int mf_crop_reduce(const int32_t* d_crop, int n, int W, int H, int32_t* d_bounds, void* stream)
@@ -115,6 +116,18 @@ int mf_crop_resize_u8c3(const uint8_t* d_frames, uint8_t* d_out, int n, int W, i
 {
     if (!d_frames || !d_out) { set_error("mf_crop_resize_u8c3: null pointer"); return MF_ERR_INVALID_ARG; }
     return launch_crop_resize(d_frames, d_out, n, W, H, left, top, right, bottom, (hipStream_t)stream);
+}
+
+int mf_selftest_recip(uint64_t n, uint64_t seed, uint64_t* mismatches)
+{
+    if (!mismatches) { set_error("mf_selftest_recip: null"); return MF_ERR_INVALID_ARG; }
+    void* d = nullptr;
+    MF_HIP_TRY(hipMalloc(&d, sizeof(uint64_t)));
+    hipError_t e = hipMemset(d, 0, sizeof(uint64_t));
+    int rc = e == hipSuccess ? launch_selftest_recip(n, seed, (unsigned long long*)d, nullptr) : hip_fail(e, "hipMemset");
+    if (rc == MF_OK) rc = hip_fail(hipMemcpy(mismatches, d, sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy");
+    (void)hipFree(d);
+    return rc;
 }
 
 // ---- host-buffer wrappers ------------------------------------------------------------------------

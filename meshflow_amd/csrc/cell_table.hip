@@ -151,14 +151,17 @@ __device__ static void cell_bbox(const double Hf[9], const double M[9], double L
 __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict__ unstab,
                                                         const double* __restrict__ stab, int n, int W, int H, int R,
                                                         int C, double* __restrict__ records,
-                                                        CellBox* __restrict__ boxes, int32_t* __restrict__ crop,
-                                                        int32_t* __restrict__ status)
+                                                        CellBox* __restrict__ boxes, float* __restrict__ edges,
+                                                        int32_t* __restrict__ reach, int32_t* __restrict__ grid,
+                                                        int32_t* __restrict__ crop, int32_t* __restrict__ status)
 {
     const int ncell = R * C;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < n) {                         // per-frame crop defaults, meshflowstabilizer.py:992-995
         crop[4 * gid + 0] = 0; crop[4 * gid + 1] = 0; crop[4 * gid + 2] = W - 1; crop[4 * gid + 3] = H - 1;
     }
+    if (gid <= C) grid[gid] = (int32_t)ceil((double)(W - 1) * ((double)gid / (double)C));             // vertex x
+    if (gid <= R) grid[C + 1 + gid] = (int32_t)ceil((double)(H - 1) * ((double)gid / (double)R));     // vertex y
     if (gid >= (long long)n * ncell) return;
     const int f = (int)(gid / ncell);
     const int k = (int)(gid % ncell);
@@ -186,7 +189,9 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
     rec[MF_CELL_OFF_RECT + 0] = L; rec[MF_CELL_OFF_RECT + 1] = T;
     rec[MF_CELL_OFF_RECT + 2] = Rt; rec[MF_CELL_OFF_RECT + 3] = B;
     CellBox box;
+    float* ed = edges + (size_t)gid * MF_EDGE_FLOATS;
     if (!ok) {
+        for (int e = 0; e < 4; ++e) { ed[3 * e] = 0.0f; ed[3 * e + 1] = 0.0f; ed[3 * e + 2] = -1e30f; }   // never a candidate
         rec[MF_CELL_OFF_STATUS] = 1.0;
         rec[MF_CELL_OFF_BBOX + 0] = 1; rec[MF_CELL_OFF_BBOX + 1] = 1; rec[MF_CELL_OFF_BBOX + 2] = 0; rec[MF_CELL_OFF_BBOX + 3] = 0;
         box.x0 = 1; box.y0 = 1; box.x1 = 0; box.y1 = 0;
@@ -198,22 +203,52 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
         for (int i = 0; i < 9; ++i) { rec[MF_CELL_OFF_M + i] = M[i]; rec[MF_CELL_OFF_HI + i] = Hi[i]; }
         for (int i = 0; i < 4; ++i) rec[MF_CELL_OFF_BBOX + i] = bb[i];
         box.x0 = (int16_t)bb[0]; box.y0 = (int16_t)bb[1]; box.x1 = (int16_t)bb[2]; box.y1 = (int16_t)bb[3];
+        // Edge functions for the wave-level classification in the warp kernel: with X = 32*Xn/Wd
+        // (Xn = M0 x + M1 y + M2, Wd = M6 x + M7 y + M8 > 0 on the frame) the mask test
+        // 32(L-1) < rint(X) < 32(Rt+1) is, up to rounding, gL > 0 and gR > 0 with
+        //   gL = 32 Xn - (32(L-1) + 1/2) Wd,   gR = (32(Rt+1) - 1/2) Wd - 32 Xn      (same for y),
+        // each affine in (x, y), so its extrema over a pixel rectangle sit on the corners.  Stored as
+        // float32 {a, b, c}; the consumer keeps a margin of one unit (1/32 px), far above their error.
+        // A cell whose Wd is not positive on the whole frame gets NaNs: neither "all inside" nor
+        // "all outside" can then be concluded and every pixel is tested.
+        const double fw = (double)(W - 1), fh = (double)(H - 1);
+        const bool regular = (M[6] * 0.0 + M[7] * 0.0) + M[8] > 1e-3 && (M[6] * fw + M[7] * 0.0) + M[8] > 1e-3 &&
+                             (M[6] * 0.0 + M[7] * fh) + M[8] > 1e-3 && (M[6] * fw + M[7] * fh) + M[8] > 1e-3;
+        const double lox = 32.0 * (L - 1) + 0.5, hix = 32.0 * (Rt + 1) - 0.5;
+        const double loy = 32.0 * (T - 1) + 0.5, hiy = 32.0 * (B + 1) - 0.5;
+        const double co[12] = {
+            32.0 * M[0] - lox * M[6], 32.0 * M[1] - lox * M[7], 32.0 * M[2] - lox * M[8],
+            hix * M[6] - 32.0 * M[0], hix * M[7] - 32.0 * M[1], hix * M[8] - 32.0 * M[2],
+            32.0 * M[3] - loy * M[6], 32.0 * M[4] - loy * M[7], 32.0 * M[5] - loy * M[8],
+            hiy * M[6] - 32.0 * M[3], hiy * M[7] - 32.0 * M[4], hiy * M[8] - 32.0 * M[5] };
+        for (int i = 0; i < 12; ++i) ed[i] = regular ? (float)co[i] : __builtin_nanf("");
+        // how far this cell's box reaches beyond its grid rect (per-frame maxima bound the search range)
+        if (box.x0 <= box.x1) {
+            atomicMax(&reach[4 * f + 0], (int)L - box.x0);
+            atomicMax(&reach[4 * f + 1], (int)T - box.y0);
+            atomicMax(&reach[4 * f + 2], box.x1 - (int)Rt);
+            atomicMax(&reach[4 * f + 3], box.y1 - (int)B);
+        }
     }
     boxes[gid] = box;
 }
 
 int launch_cell_table(const double* unstab, const double* stab, int n, int W, int H, int R, int C,
-                      double* records, CellBox* boxes, int32_t* crop, int32_t* status, hipStream_t st)
+                      double* records, CellBox* boxes, float* edges, int32_t* reach, int32_t* grid, int32_t* crop,
+                      int32_t* status, hipStream_t st)
 {
-    if (n <= 0 || R <= 0 || C <= 0 || W < 2 || H < 2 || W > 32767 || H > 32767 || R * C > 4096) {
+    if (n <= 0 || R <= 0 || C <= 0 || W < 2 || H < 2 || W > 32767 || H > 32767 || R > 64 || C > 64) {
         set_error("mf_cell_table_f64: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
         return MF_ERR_INVALID_ARG;
     }
+    hipError_t e = hipMemsetAsync(reach, 0, (size_t)n * 4 * sizeof(int32_t), st);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(reach)");
     const long long total = (long long)n * R * C;
-    const long long threads = total > n ? total : n;
+    long long threads = total > n ? total : n;
+    if (threads < 65) threads = 65;
     const unsigned blocks = (unsigned)((threads + 63) / 64);
     hipLaunchKernelGGL(cell_table_kernel, dim3(blocks), dim3(64), 0, st, unstab, stab, n, W, H, R, C, records, boxes,
-                       crop, status);
+                       edges, reach, grid, crop, status);
     return hip_fail(hipGetLastError(), "cell_table_kernel launch");
 }
 

@@ -22,13 +22,43 @@ struct alignas(8) CellBox { int16_t x0, y0, x1, y1; };
 
 inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 
+// Layout of the cell table blob (mf_cell_table_bytes): records | boxes | edges | reach | grid.
+//   records: n*R*C x MF_CELL_DOUBLES float64      (ABI, include/meshflow_hip.h)
+//   boxes:   n*R*C x CellBox                      compact copy of the record's bbox
+//   edges:   n*R*C x MF_EDGE_FLOATS float32       4 affine edge functions {a, b, c} (cell_table.hip)
+//   reach:   n x 4 int32                          per-frame max extent of a box beyond its grid rect
+//   grid:    (C+1) + (R+1) int32                  vertex x / y pixel coordinates
+#define MF_EDGE_FLOATS 12
+struct TableView {
+    double* records; CellBox* boxes; float* edges; int32_t* reach; int32_t* grid;
+};
+inline size_t table_bytes(int n, int R, int C)
+{
+    const size_t nrec = table_records(n, R, C);
+    return nrec * (MF_CELL_DOUBLES * sizeof(double) + sizeof(CellBox) + MF_EDGE_FLOATS * sizeof(float)) +
+           (size_t)n * 4 * sizeof(int32_t) + (size_t)(R + C + 2) * sizeof(int32_t);
+}
+inline TableView table_view(void* blob, int n, int R, int C)
+{
+    const size_t nrec = table_records(n, R, C);
+    TableView v;
+    v.records = (double*)blob;
+    v.boxes = (CellBox*)(v.records + nrec * MF_CELL_DOUBLES);
+    v.edges = (float*)(v.boxes + nrec);
+    v.reach = (int32_t*)(v.edges + nrec * MF_EDGE_FLOATS);
+    v.grid = v.reach + (size_t)n * 4;
+    return v;
+}
+
 // Launchers (defined next to their kernels).
 int launch_jacobi(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
                   int F, int S, int omega, int iters, hipStream_t st);
 int launch_cell_table(const double* unstab, const double* stab, int n, int W, int H, int R, int C,
-                      double* records, CellBox* boxes, int32_t* crop, int32_t* status, hipStream_t st);
-int launch_warp(const uint8_t* frames, uint8_t* out, const double* records, const CellBox* boxes, int n,
-                int W, int H, int R, int C, uint32_t border, int32_t* crop, hipStream_t st);
+                      double* records, CellBox* boxes, float* edges, int32_t* reach, int32_t* grid, int32_t* crop,
+                      int32_t* status, hipStream_t st);
+int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n, int W, int H, int R, int C,
+                uint32_t border, int32_t* crop, hipStream_t st);
+int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t st);
 int launch_crop_reduce(const int32_t* crop, int n, int W, int H, int32_t* bounds, hipStream_t st);
 int launch_crop_resize(const uint8_t* frames, uint8_t* out, int n, int W, int H, int left, int top, int right,
                        int bottom, hipStream_t st);

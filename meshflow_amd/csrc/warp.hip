@@ -15,29 +15,39 @@
 // float32, then 1/32-pixel fixed point; interpolation is integer.  The result is bit-identical to the CPU
 // oracle (oracle/warp_oracle.c).
 //
-// Mapping (gfx950): a 256-thread workgroup owns a 128 x 16 pixel tile of one frame (tile rows start on a
-// 128-byte boundary of the 3-byte-per-pixel output when W % 128 == 0, as for 1080p and 4K).  Each
-// wavefront owns a 32-pixel-wide column of the tile and walks it in two 32 x 8 footprints; a lane owns 4
-// consecutive pixels of one row (12 contiguous output bytes -> one global_store_dwordx3).  Per wavefront:
-//   1. candidate cells = those whose conservative box (compact int16 array, coalesced 8-byte loads)
-//      touches the wave's 32 x 16 region, collected with __ballot into wave-uniform 64-bit masks;
-//   2. candidates are visited in DESCENDING cell order; the cell index is wave-uniform, so its record
-//      (M, rect, Hi) is fetched with scalar loads into SGPRs -- nothing per-cell is held per lane or in
-//      LDS; the first cell whose mask test passes owns the pixel; the loop ends when every pixel is owned;
-//   3. source taps are fetched with unaligned 4-byte loads (3 bytes used), served by L1/L2: neighbouring
-//      lanes touch neighbouring bytes because the motion is a few pixels.
+// Mapping (gfx950).  A 256-thread workgroup owns a 128 x 16 pixel tile of one frame (tile rows start on a
+// 128-byte boundary of the 3-byte-per-pixel output when W % 128 == 0: 1080p, 4K).  Each wavefront owns a
+// 32-pixel-wide column of the tile and walks it in 32 x 8 "footprints"; a lane owns 4 consecutive pixels
+// of one row (12 contiguous output bytes -> one global_store_dwordx3).  Per footprint:
+//   1. Candidate cells: the cells whose grid rect, widened by the frame's "reach" (how far any cell's
+//      conservative box extends beyond its grid rect, from the cell-table kernel), meets the footprint --
+//      a small r x c index range found with two __ballot's over the vertex coordinates held in LDS.
+//   2. Classification, 4 candidates per pass: lane = (candidate, edge, corner) evaluates one float32 edge
+//      function of the cell's mask quad at one footprint corner; two __ballot's tell, per candidate,
+//      OUT (some edge excludes all four corners: skip), IN (every edge admits all four corners: every
+//      pixel passes, no per-pixel test) or MIXED.  The functions are affine, so corners bound the
+//      footprint; a one-unit (1/32 px) margin dwarfs their float32 error.
+//   3. Candidates are visited in DESCENDING cell order (last painter wins).  The cell index is
+//      wave-uniform, so its record (M, rect, Hi) comes in through scalar loads into SGPRs -- nothing
+//      per-cell is held per lane or in LDS.  MIXED cells run the mask test per pixel: a division-free
+//      float64 comparison that decides whenever the pixel is not within 1e-6 of the mask edge, else
+//      OpenCV's exact arithmetic (division, rint).  Owned pixels get their coordinates at once; the loop
+//      ends when every pixel of the footprint is owned.
+//   4. Source taps: two unaligned 8-byte loads per pixel (two horizontally adjacent BGR pixels per row),
+//      served by L1/L2 -- neighbouring lanes touch neighbouring bytes because the motion is a few
+//      pixels; border / frame-edge pixels take a per-tap path.
 // Algorithmic HBM traffic: 2*H*W*3 bytes per frame (each source byte read once, each output byte written
-// once); the cell table adds R*C*264 bytes per frame (< 1.5 %).  No dense contraction: no MFMA.
+// once); the cell table adds R*C*312 bytes per frame (< 1.5 %).  No dense contraction: no MFMA.
 #include "mf_common.h"
 
 namespace mf {
 
 constexpr int TILE_W = 128;
-constexpr int TILE_H = 16;
-constexpr int WAVE_W = 32;      // pixels per wavefront footprint row (8 lanes x 4 pixels)
-constexpr int FOOT_H = 8;       // rows per footprint (64 lanes / 8)
-constexpr int QUADS = TILE_H / FOOT_H;   // footprints per wavefront
-constexpr int NPIX = 4 * QUADS;          // pixels per lane
+constexpr int FOOT_W = 32;      // 8 lanes x 4 pixels
+constexpr int FOOT_H = 8;       // 64 lanes / 8
+constexpr int FOOTS = 2;        // footprints per wavefront, stacked vertically
+constexpr int TILE_H = FOOT_H * FOOTS;
+constexpr int MAX_MESH = 64;    // R, C <= 64
 
 __device__ __forceinline__ int cv_round_f32(float v)
 {
@@ -52,9 +62,9 @@ __device__ __forceinline__ uint32_t fetch_bgr(const uint8_t* __restrict__ frame,
                                               uint32_t border, size_t limit)
 {
     if ((unsigned)tx < (unsigned)W && (unsigned)ty < (unsigned)H) {
-        const size_t o = ((size_t)ty * W + tx) * 3;
+        const uint32_t o = ((uint32_t)ty * (uint32_t)W + (uint32_t)tx) * 3u;
         uint32_t v;
-        if (o + 4 <= limit) {
+        if ((size_t)o + 4 <= limit) {
             __builtin_memcpy(&v, frame + o, 4);
         } else {
             __builtin_memcpy(&v, frame + o - 1, 4);
@@ -65,163 +75,312 @@ __device__ __forceinline__ uint32_t fetch_bgr(const uint8_t* __restrict__ frame,
     return border;
 }
 
+// OpenCV's mask test, exactly (imgwarp.cpp WarpPerspectiveInvoker: 64-wide destination blocks).
+__device__ __forceinline__ bool mask_test_exact(const double* __restrict__ M, int lo_x, int hi_x, int lo_y, int hi_y,
+                                             int x, int y)
+{
+    const double xb = (double)(x & ~63), x1 = (double)(x & 63), yy = (double)y;
+    const double X0 = (M[0] * xb + M[1] * yy) + M[2];
+    const double Y0 = (M[3] * xb + M[4] * yy) + M[5];
+    const double W0 = (M[6] * xb + M[7] * yy) + M[8];
+    const double Wd = W0 + M[6] * x1;
+    const double Ws = Wd != 0.0 ? 32.0 / Wd : 0.0;
+    const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + M[0] * x1) * Ws));
+    const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + M[3] * x1) * Ws));
+    const int X = (int)rint(fX);
+    const int Y = (int)rint(fY);
+    // non-zero bilinear sample of the 255-filled rect <=> a tap with non-zero weight lies on it
+    return X > lo_x && X < hi_x && Y > lo_y && Y < hi_y;
+}
+
+// 1/w with the exact bits of IEEE division for 0.5 <= |w| <= 2: the compiler's own f64 division sequence
+// (v_div_scale / v_rcp / 2 Newton steps / residual / v_div_fmas / v_div_fixup) without the scaling and
+// special-case steps, which are the identity in that range.  tests/test_gpu_parity.py checks it against
+// 1.0 / w on random inputs (mf_selftest_recip).
+__device__ __forceinline__ double recip_unit_range(double w)
+{
+    double r = __builtin_amdgcn_rcp(w);
+    double e = __builtin_fma(-w, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-w, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-w, r, 1.0);
+    return __builtin_fma(e, r, r);
+}
+
 __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out,
                                                    const double* __restrict__ records,
-                                                   const CellBox* __restrict__ boxes, int n, int W, int H,
-                                                   int ncell, uint32_t border, int32_t* __restrict__ crop)
+                                                   const float* __restrict__ edges,
+                                                   const int32_t* __restrict__ reach,
+                                                   const int32_t* __restrict__ grid, int n, int W, int H, int R, int C,
+                                                   uint32_t border, int32_t* __restrict__ crop)
 {
+    __shared__ int s_gx[MAX_MESH + 2];
+    __shared__ int s_gy[MAX_MESH + 2];
+    if ((int)threadIdx.x <= C) s_gx[threadIdx.x] = grid[threadIdx.x];
+    if ((int)threadIdx.x <= R) s_gy[threadIdx.x] = grid[C + 1 + threadIdx.x];
+    __syncthreads();
+
     const int f = blockIdx.z;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const int x0 = blockIdx.x * TILE_W + wave * WAVE_W + (lane & 7) * 4;   // first of this lane's 4 pixels
-    const int ybase = blockIdx.y * TILE_H + (lane >> 3);                  // row of quad 0; quad q adds 8*q
-    const int rx0 = blockIdx.x * TILE_W + wave * WAVE_W;                  // wave region (inclusive)
-    if (rx0 >= W) return;                                                 // whole wave outside the frame
-    const int rx1 = min(rx0 + WAVE_W - 1, W - 1);
-    const int ry0 = blockIdx.y * TILE_H;
-    const int ry1 = min(ry0 + TILE_H - 1, H - 1);
+    const int xa = blockIdx.x * TILE_W + wave * FOOT_W;                  // footprint x range (inclusive)
+    if (xa >= W) return;                                                 // whole wave outside the frame
+    const int xb = min(xa + FOOT_W - 1, W - 1);
+    const int x0 = xa + (lane & 7) * 4;                                  // first of this lane's 4 pixels
+    const int ncell = R * C;
 
     const size_t frame_bytes = (size_t)W * H * 3;
     const uint8_t* __restrict__ src = frames + (size_t)f * frame_bytes;
     uint8_t* __restrict__ dst = out + (size_t)f * frame_bytes;
     const size_t limit = (size_t)(n - f) * frame_bytes;
     const double* __restrict__ frec = records + (size_t)f * ncell * MF_CELL_DOUBLES;
-    const CellBox* __restrict__ fbox = boxes + (size_t)f * ncell;
+    const float* __restrict__ fedge = edges + (size_t)f * ncell * MF_EDGE_FLOATS;
+    const int reach_xlo = reach[4 * f + 0], reach_ylo = reach[4 * f + 1];
+    const int reach_xhi = reach[4 * f + 2], reach_yhi = reach[4 * f + 3];
 
-    // Per-pixel state.  A pixel outside the frame counts as owned from the start.
-    int sx[NPIX], sy[NPIX];
-    uint32_t unowned = 0;
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q)
+    // column range of candidate cells: grid rect [gx[c], gx[c+1]] widened by the reach meets [xa, xb]
+    const bool col_in = lane < C && s_gx[lane] <= xb + reach_xlo && s_gx[lane + 1] >= xa - reach_xhi;
+    const unsigned long long colmask = __ballot(col_in);
+    const int c_lo = __ffsll((long long)colmask) - 1;
+    const int c_hi = 63 - __clzll((long long)colmask);
+    const int nc = c_hi - c_lo + 1;
+
+    int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
+    const float fWm1 = (float)(W - 1), fHm1 = (float)(H - 1);
+    const bool fast_store = (W & 3) == 0;
+    const double xs0 = (double)x0, xs1 = (double)(x0 + 1), xs2 = (double)(x0 + 2), xs3 = (double)(x0 + 3);
+
+#pragma unroll 1
+    for (int q = 0; q < FOOTS; ++q) {
+        const int ya = blockIdx.y * TILE_H + q * FOOT_H;
+        if (ya >= H) break;
+        const int yb = min(ya + FOOT_H - 1, H - 1);
+        const int y = ya + (lane >> 3);
+        const double yy = (double)y;
+
+        const bool row_in = lane < R && s_gy[lane] <= yb + reach_ylo && s_gy[lane + 1] >= ya - reach_yhi;
+        const unsigned long long rowmask = __ballot(row_in);
+        const int r_lo = __ffsll((long long)rowmask) - 1;
+        const int r_hi = 63 - __clzll((long long)rowmask);
+
+        // Source coordinates of the lane's 4 pixels; (W+1, H+1) = "no cell covers it" (mfs.py:983-984).
+        float u[4], v[4];
+        uint32_t unowned = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int p = q * 4 + j;
-            sx[p] = (W + 1) * 32;          // cvRound(float(W+1)*32): the "uncovered" default, mfs.py:983-984
-            sy[p] = (H + 1) * 32;
-            if (x0 + j < W && ybase + q * FOOT_H < H) unowned |= 1u << p;
+            u[j] = (float)(W + 1);
+            v[j] = (float)(H + 1);
+            if (x0 + j < W && y < H) unowned |= 1u << j;
         }
-    int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
+        bool done = __ballot(unowned != 0) == 0;
 
-    const int nchunk = (ncell + 63) >> 6;
-    bool done = __ballot(unowned != 0) == 0;
-    for (int ch = nchunk - 1; ch >= 0 && !done; --ch) {
-        const int kc = ch * 64 + lane;
-        bool hit = false;
-        if (kc < ncell) {
-            const CellBox b = fbox[kc];
-            hit = b.x0 <= b.x1 && b.x1 >= rx0 && b.x0 <= rx1 && b.y1 >= ry0 && b.y0 <= ry1;
-        }
-        unsigned long long cand = __ballot(hit);
-        while (cand != 0 && !done) {
-            const int bit = 63 - __clzll(cand);
-            cand &= ~(1ull << bit);
-            const int k = ch * 64 + bit;                                   // wave-uniform
-            const double* __restrict__ rec = frec + (size_t)k * MF_CELL_DOUBLES;
-            double M[9], Hi[9];
+        // Candidates (r, c) in [r_lo, r_hi] x [c_lo, c_hi], visited from the last cell to the first,
+        // four per classification pass.
+        int cr = r_hi, cc = c_hi;                                         // wave-uniform cursor
+        while (cr >= r_lo && !done) {
+            // this lane's candidate = cursor stepped back (lane >> 4) times
+            int lr = cr, lc = cc - (lane >> 4);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) { M[i] = rec[MF_CELL_OFF_M + i]; Hi[i] = rec[MF_CELL_OFF_HI + i]; }
-            const int lo_x = 32 * ((int)rec[MF_CELL_OFF_RECT + 0] - 1);
-            const int lo_y = 32 * ((int)rec[MF_CELL_OFF_RECT + 1] - 1);
-            const int hi_x = 32 * ((int)rec[MF_CELL_OFF_RECT + 2] + 1);
-            const int hi_y = 32 * ((int)rec[MF_CELL_OFF_RECT + 3] + 1);
+            for (int s = 0; s < 3; ++s)
+                if (lc < c_lo) { lc += nc; lr -= 1; }
+            const bool lvalid = lr >= r_lo;
+            float g = 0.0f;
+            if (lvalid) {
+                const float* __restrict__ ed = fedge + (uint32_t)(lr * C + lc) * MF_EDGE_FLOATS + ((lane >> 2) & 3) * 3;
+                const float cx = (float)((lane & 1) ? xb : xa);
+                const float cy = (float)((lane & 2) ? yb : ya);
+                g = ed[0] * cx + ed[1] * cy + ed[2];
+            }
+            const unsigned long long inm = __ballot(lvalid && g > 1.0f);
+            const unsigned long long outm = __ballot(lvalid && g < -1.0f);
+#pragma unroll 1
+            for (int ci = 0; ci < 4 && cr >= r_lo && !done; ++ci) {
+                const int k = cr * C + cc;                                 // wave-uniform cell index
+                if (--cc < c_lo) { cc = c_hi; --cr; }
+                const uint32_t bin = (uint32_t)(inm >> (16 * ci)) & 0xFFFFu;
+                const uint32_t bout = (uint32_t)(outm >> (16 * ci)) & 0xFFFFu;
+                if ((bout & (bout >> 1) & (bout >> 2) & (bout >> 3) & 0x1111u) != 0) continue;     // OUT
+                const double* __restrict__ rec = frec + (uint32_t)k * MF_CELL_DOUBLES;
+                uint32_t pass = unowned;                                   // IN: every unowned pixel passes
+                if (bin != 0xFFFFu) {
+                    // MIXED: per-pixel mask test.  Division-free decision: with Xn = M0 x + M1 y + M2 and
+                    // Wd = M6 x + M7 y + M8 > 0, OpenCV's fX = fl(Xn * fl(32/Wd)) differs from 32 Xn / Wd by
+                    // < 1e-9 relative, and rint(fX) > lo  <=>  fX > lo + 1/2 (lo is even).  So the sign of
+                    //   q = 32 Xn - (lo + 1/2) Wd   (and its three siblings)
+                    // decides the test unless |q| <= 1e-6 Wd; only then is the exact arithmetic needed.
+                    double M[9];
 #pragma unroll
-            for (int q = 0; q < QUADS; ++q) {
-                if (((unowned >> (4 * q)) & 15u) == 0) continue;
-                const int y = ybase + q * FOOT_H;
-                const double yy = (double)y;
-                // cv2.warpPerspective evaluates destination pixels in 64-wide blocks (imgwarp.cpp):
-                //   X0 = M0*xb + M1*y + M2 at the block start xb, then X0 + M0*x1 inside the block.
-                const double xb = (double)(x0 & ~63);
-                const double X0 = (M[0] * xb + M[1] * yy) + M[2];
-                const double Y0 = (M[3] * xb + M[4] * yy) + M[5];
-                const double W0 = (M[6] * xb + M[7] * yy) + M[8];
+                    for (int i = 0; i < 9; ++i) M[i] = rec[MF_CELL_OFF_M + i];
+                    const double rL = rec[MF_CELL_OFF_RECT + 0], rT = rec[MF_CELL_OFF_RECT + 1];
+                    const double rR = rec[MF_CELL_OFF_RECT + 2], rB = rec[MF_CELL_OFF_RECT + 3];
+                    const double loxh = 32.0 * (rL - 1.0) + 0.5, hixh = 32.0 * (rR + 1.0) - 0.5;
+                    const double loyh = 32.0 * (rT - 1.0) + 0.5, hiyh = 32.0 * (rB + 1.0) - 0.5;
+                    const double RX = __builtin_fma(M[1], yy, M[2]);
+                    const double RY = __builtin_fma(M[4], yy, M[5]);
+                    const double RW = __builtin_fma(M[7], yy, M[8]);
+                    uint32_t ok = 0, amb = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double xs = j == 0 ? xs0 : j == 1 ? xs1 : j == 2 ? xs2 : xs3;
+                        const double Wd = __builtin_fma(M[6], xs, RW);
+                        const double X32 = 32.0 * __builtin_fma(M[0], xs, RX);
+                        const double Y32 = 32.0 * __builtin_fma(M[3], xs, RY);
+                        const double qmin = fmin(fmin(__builtin_fma(-loxh, Wd, X32), __builtin_fma(hixh, Wd, -X32)),
+                                                 fmin(__builtin_fma(-loyh, Wd, Y32), __builtin_fma(hiyh, Wd, -Y32)));
+                        const double t = 1e-6 * Wd;
+                        const bool sane = Wd > 0.25 && Wd < 4.0;
+                        if (sane && qmin > t) ok |= 1u << j;
+                        else if (!(sane && qmin < -t)) amb |= 1u << j;
+                    }
+                    amb &= unowned;
+                    if (__ballot(amb != 0) != 0) {                         // rare: a pixel within 1e-6 of a mask edge
+                        const int lo_x = 32 * ((int)rL - 1), hi_x = 32 * ((int)rR + 1);
+                        const int lo_y = 32 * ((int)rT - 1), hi_y = 32 * ((int)rB + 1);
+#pragma unroll 1
+                        for (int j = 0; j < 4; ++j)
+                            if (((amb >> j) & 1u) && mask_test_exact(M, lo_x, hi_x, lo_y, hi_y, x0 + j, y)) ok |= 1u << j;
+                    }
+                    pass = ok & unowned;
+                    if (__ballot(pass != 0) == 0) continue;
+                }
+                unowned &= ~pass;
+                // cv2.perspectiveTransform (matmul.simd.hpp): float32 point, float64 matrix, for the lane's
+                // four pixels in straight-line code; results are merged under the pass mask.
+                double Hi[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Hi[i] = rec[MF_CELL_OFF_HI + i];
+                const double t6 = yy * Hi[7], t0 = yy * Hi[1], t3 = yy * Hi[4];
+                double w4[4];
+                uint32_t eor = 0;                                          // |w| in [0.5, 2) <=> frexp exponent in {0, 1}
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int p = q * 4 + j;
-                    if (!((unowned >> p) & 1u)) continue;
-                    const int x = x0 + j;
-                    const double x1 = (double)(x & 63);
-                    const double Wd = W0 + M[6] * x1;
-                    const double Ws = Wd != 0.0 ? 32.0 / Wd : 0.0;
-                    const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + M[0] * x1) * Ws));
-                    const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + M[3] * x1) * Ws));
-                    const int X = (int)rint(fX);
-                    const int Y = (int)rint(fY);
-                    // non-zero bilinear sample of the 255-filled rect <=> a tap with non-zero weight on it
-                    if (!(X > lo_x && X < hi_x && Y > lo_y && Y < hi_y)) continue;
-                    unowned &= ~(1u << p);
-                    // cv2.perspectiveTransform (matmul.simd.hpp): float32 point, float64 matrix
-                    const double xs = (double)x;
-                    double w = (xs * Hi[6] + yy * Hi[7]) + Hi[8];
-                    float u = 0.0f, v = 0.0f;
-                    if (fabs(w) > 1.1920928955078125e-07) {
-                        w = 1.0 / w;
-                        u = (float)(((xs * Hi[0] + yy * Hi[1]) + Hi[2]) * w);
-                        v = (float)(((xs * Hi[3] + yy * Hi[4]) + Hi[5]) * w);
-                    }
-                    // crop-boundary scan, mfs.py:1075-1098 (|u - e| < 1 on exact values)
-                    if (u > -1.0f && u < 1.0f) c_left = max(c_left, x);
-                    if (u > (float)(W - 2) && u < (float)W) c_right = min(c_right, x);
-                    if (v > -1.0f && v < 1.0f) c_top = max(c_top, y);
-                    if (v > (float)(H - 2) && v < (float)H) c_bottom = min(c_bottom, y);
-                    // cv2.remap: 1/32-pixel fixed point, round half to even
-                    sx[p] = cv_round_f32(u * 32.0f);
-                    sy[p] = cv_round_f32(v * 32.0f);
+                    const double xs = j == 0 ? xs0 : j == 1 ? xs1 : j == 2 ? xs2 : xs3;
+                    w4[j] = (xs * Hi[6] + t6) + Hi[8];
+                    eor |= (uint32_t)__builtin_amdgcn_frexp_exp(w4[j]);
                 }
-            }
-            done = __ballot(unowned != 0) == 0;
-        }
-    }
-
-    // Crop bounds: wave reduction, then at most one atomic per bound per wave (most waves have none).
-    {
-        const bool any = c_left != 0 || c_top != 0 || c_right != W - 1 || c_bottom != H - 1;
-        if (__ballot(any) != 0) {
+                const bool unit = eor <= 1u;
+                if (__ballot(!unit) == 0) {
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                c_left = max(c_left, __shfl_xor(c_left, off));
-                c_top = max(c_top, __shfl_xor(c_top, off));
-                c_right = min(c_right, __shfl_xor(c_right, off));
-                c_bottom = min(c_bottom, __shfl_xor(c_bottom, off));
-            }
-            if (lane == 0) {
-                if (c_left != 0) atomicMax(&crop[4 * f + 0], c_left);
-                if (c_top != 0) atomicMax(&crop[4 * f + 1], c_top);
-                if (c_right != W - 1) atomicMin(&crop[4 * f + 2], c_right);
-                if (c_bottom != H - 1) atomicMin(&crop[4 * f + 3], c_bottom);
+                    for (int j = 0; j < 4; ++j) {
+                        const double xs = j == 0 ? xs0 : j == 1 ? xs1 : j == 2 ? xs2 : xs3;
+                        const double iw = recip_unit_range(w4[j]);
+                        const float un = (float)(((xs * Hi[0] + t0) + Hi[2]) * iw);
+                        const float vn = (float)(((xs * Hi[3] + t3) + Hi[5]) * iw);
+                        const bool p = (pass >> j) & 1u;
+                        u[j] = p ? un : u[j];
+                        v[j] = p ? vn : v[j];
+                    }
+                } else {                                                   // far-from-affine cell: generic division
+#pragma unroll 1
+                    for (int j = 0; j < 4; ++j) {
+                        if (!((pass >> j) & 1u)) continue;
+                        const double xs = (double)(x0 + j);
+                        double w = (xs * Hi[6] + t6) + Hi[8];
+                        float un = 0.0f, vn = 0.0f;
+                        if (fabs(w) > 1.1920928955078125e-07) {
+                            w = 1.0 / w;
+                            un = (float)(((xs * Hi[0] + t0) + Hi[2]) * w);
+                            vn = (float)(((xs * Hi[3] + t3) + Hi[5]) * w);
+                        }
+                        if (j == 0) { u[0] = un; v[0] = vn; }
+                        else if (j == 1) { u[1] = un; v[1] = vn; }
+                        else if (j == 2) { u[2] = un; v[2] = vn; }
+                        else { u[3] = un; v[3] = vn; }
+                    }
+                }
+                done = __ballot(unowned != 0) == 0;
             }
         }
-    }
 
-    // Bilinear gather + store.
-    const bool fast_store = (W & 3) == 0;
-#pragma unroll
-    for (int q = 0; q < QUADS; ++q) {
-        const int y = ybase + q * FOOT_H;
-        if (y >= H || x0 >= W) continue;
-        uint32_t px[4];
+        // cv2.remap: 1/32-pixel fixed point (round half to even), bilinear gather, store.
+        const bool active = y < H && x0 < W;
+        // sx = rint(32 u) by the 1.5*2^23 trick: fma rounds 32u + magic once, to nearest even, and the
+        // integer sits in the low mantissa bits (valid for |32u| < 2^22; anything else lands far outside
+        // the "deep interior" window below and is redone exactly by the generic path).
+        int sx[4], sy[4];
+        uint32_t dxm = 0, dym = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int p = q * 4 + j;
-            const int ix = max(-32768, min(32767, sx[p] >> 5));
-            const int iy = max(-32768, min(32767, sy[p] >> 5));
-            const int fx = sx[p] & 31, fy = sy[p] & 31;
-            if (ix >= W || ix + 1 < 0 || iy >= H || iy + 1 < 0) { px[j] = border; continue; }
-            const uint32_t p00 = fetch_bgr(src, W, H, ix, iy, border, limit);
-            const uint32_t p01 = fetch_bgr(src, W, H, ix + 1, iy, border, limit);
-            const uint32_t p10 = fetch_bgr(src, W, H, ix, iy + 1, border, limit);
-            const uint32_t p11 = fetch_bgr(src, W, H, ix + 1, iy + 1, border, limit);
-            const uint32_t w00 = (32 - fx) * (32 - fy), w01 = fx * (32 - fy), w10 = (32 - fx) * fy, w11 = fx * fy;
-            uint32_t r = 0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const uint32_t a = w00 * ((p00 >> (8 * c)) & 255u) + w01 * ((p01 >> (8 * c)) & 255u) +
-                                   w10 * ((p10 >> (8 * c)) & 255u) + w11 * ((p11 >> (8 * c)) & 255u);
-                r |= ((a + 512u) >> 10) << (8 * c);      // == (a*32 + 2^14) >> 15
-            }
-            px[j] = r;
+            sx[j] = __float_as_int(__builtin_fmaf(u[j], 32.0f, 12582912.0f)) - 0x4B400000;
+            sy[j] = __float_as_int(__builtin_fmaf(v[j], 32.0f, 12582912.0f)) - 0x4B400000;
+            dxm = max(dxm, (uint32_t)(sx[j] - 64));
+            dym = max(dym, (uint32_t)(sy[j] - 64));
         }
-        const size_t o = ((size_t)y * W + x0) * 3;
+        // "deep interior": 2 <= ix <= W-3 and 2 <= iy <= H-3 for all four pixels.  Then both taps in x and
+        // y are inside the frame, the 8-byte loads stay inside the row, and no crop flag can be set
+        // (u >= 2 - 1/64 and u < W - 2, same for v).
+        const bool deep = dxm <= (uint32_t)(32 * (W - 3) + 31 - 64) && dym <= (uint32_t)(32 * (H - 3) + 31 - 64);
+        uint32_t px[4];
+        if (__ballot(active && !deep) == 0) {
+            // fast path (wave-uniform): every pixel of the footprint samples the deep interior
+            if (!active) continue;
+            uint2 a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t t = __umul24((uint32_t)(sy[j] >> 5), (uint32_t)W) + (uint32_t)(sx[j] >> 5);
+                const uint32_t o = t + (t << 1);
+                __builtin_memcpy(&a[j], src + o, 8);
+                __builtin_memcpy(&b[j], src + (o + 3u * (uint32_t)W), 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // a[j].x = B0 G0 R0 B1, a[j].y = G1 R1 . .   (pixel ix, pixel ix+1 of row iy; b: row iy+1)
+                const uint32_t fx = sx[j] & 31, fy = sy[j] & 31;
+                const uint32_t w0 = 32u - fx;
+                const uint32_t wb = w0 | (fx << 24);          // weights on bytes 0 and 3 of .x  (B0, B1)
+                const uint32_t wg = w0 | (fx << 8);           // weights on bytes 0, 1 of the permuted dword (G0, G1)
+                const uint32_t wr = wg << 16;                 // weights on bytes 2, 3 (R0, R1)
+                const uint32_t pa = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x05020401u);   // G0 G1 R0 R1
+                const uint32_t pb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x05020401u);
+                // horizontal lerps (<= 255*32), v_dot4_u32_u8
+                const uint32_t hBa = __builtin_amdgcn_udot4(a[j].x, wb, 0u, false), hBb = __builtin_amdgcn_udot4(b[j].x, wb, 0u, false);
+                const uint32_t hGa = __builtin_amdgcn_udot4(pa, wg, 0u, false), hGb = __builtin_amdgcn_udot4(pb, wg, 0u, false);
+                const uint32_t hRa = __builtin_amdgcn_udot4(pa, wr, 0u, false), hRb = __builtin_amdgcn_udot4(pb, wr, 0u, false);
+                // vertical lerp scaled by 64 so that ((sum + 512) >> 10) lands in byte 2:  (sum + 512) * 64 < 2^24
+                const uint32_t fy6 = fy << 6, wy6 = 2048u - fy6;
+                const uint32_t oB = __umul24(wy6, hBa) + (__umul24(fy6, hBb) + 32768u);
+                const uint32_t oG = __umul24(wy6, hGa) + (__umul24(fy6, hGb) + 32768u);
+                const uint32_t oR = __umul24(wy6, hRa) + (__umul24(fy6, hRb) + 32768u);
+                const uint32_t bg = __builtin_amdgcn_perm(oG, oB, 0x0C0C0602u);           // B | G << 8
+                px[j] = __builtin_amdgcn_perm(oR, bg, 0x0C060100u);                       // | R << 16
+            }
+        } else {
+            // generic path: frame borders, uncovered pixels, crop flags, out-of-range coordinates
+            if (!active) continue;
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const float uu = j == 0 ? u[0] : j == 1 ? u[1] : j == 2 ? u[2] : u[3];
+                const float vv = j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : v[3];
+                const int x = x0 + j;
+                // crop-boundary scan, mfs.py:1075-1098: |u - e| < 1.  The float32 differences are exact
+                // whenever they are smaller than 1 in magnitude (Sterbenz), so the tests are exact.
+                if (fabsf(uu) < 1.0f) c_left = max(c_left, x);
+                if (fabsf(uu - fWm1) < 1.0f) c_right = min(c_right, x);
+                if (fabsf(vv) < 1.0f) c_top = max(c_top, y);
+                if (fabsf(vv - fHm1) < 1.0f) c_bottom = min(c_bottom, y);
+                const int sxx = cv_round_f32(uu * 32.0f), syy = cv_round_f32(vv * 32.0f);
+                const int ix = sxx >> 5, iy = syy >> 5;      // (saturation to int16 cannot change any decision below)
+                const uint32_t fx = sxx & 31, fy = syy & 31;
+                uint32_t r = border;                         // whole 2x2 footprint outside -> border colour
+                if (!(ix >= W || ix + 1 < 0 || iy >= H || iy + 1 < 0)) {
+                    const uint32_t p00 = fetch_bgr(src, W, H, ix, iy, border, limit);
+                    const uint32_t p01 = fetch_bgr(src, W, H, ix + 1, iy, border, limit);
+                    const uint32_t p10 = fetch_bgr(src, W, H, ix, iy + 1, border, limit);
+                    const uint32_t p11 = fetch_bgr(src, W, H, ix + 1, iy + 1, border, limit);
+                    const uint32_t w00 = (32u - fx) * (32u - fy), w01 = fx * (32u - fy), w10 = (32u - fx) * fy, w11 = fx * fy;
+                    r = 0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const uint32_t acc = w00 * ((p00 >> (8 * c)) & 255u) + w01 * ((p01 >> (8 * c)) & 255u) +
+                                             w10 * ((p10 >> (8 * c)) & 255u) + w11 * ((p11 >> (8 * c)) & 255u);
+                        r |= ((acc + 512u) >> 10) << (8 * c);
+                    }
+                }
+                if (j == 0) px[0] = r; else if (j == 1) px[1] = r; else if (j == 2) px[2] = r; else px[3] = r;
+            }
+        }
+        const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
         if (fast_store && x0 + 3 < W) {
             uint3 d;
             d.x = px[0] | (px[1] << 24);
@@ -238,17 +397,65 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 }
         }
     }
+
+    // Crop bounds: wave reduction, then at most one atomic per bound per wave (most waves have none).
+    const bool any = c_left != 0 || c_top != 0 || c_right != W - 1 || c_bottom != H - 1;
+    if (__ballot(any) != 0) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            c_left = max(c_left, __shfl_xor(c_left, off));
+            c_top = max(c_top, __shfl_xor(c_top, off));
+            c_right = min(c_right, __shfl_xor(c_right, off));
+            c_bottom = min(c_bottom, __shfl_xor(c_bottom, off));
+        }
+        if (lane == 0) {
+            if (c_left != 0) atomicMax(&crop[4 * f + 0], c_left);
+            if (c_top != 0) atomicMax(&crop[4 * f + 1], c_top);
+            if (c_right != W - 1) atomicMin(&crop[4 * f + 2], c_right);
+            if (c_bottom != H - 1) atomicMin(&crop[4 * f + 3], c_bottom);
+        }
+    }
 }
 
-int launch_warp(const uint8_t* frames, uint8_t* out, const double* records, const CellBox* boxes, int n, int W,
-                int H, int R, int C, uint32_t border, int32_t* crop, hipStream_t st)
+// Self-test of recip_unit_range against IEEE division: counts mismatching bit patterns.
+__global__ void selftest_recip_kernel(unsigned long long n, unsigned long long seed, unsigned long long* mismatches)
 {
-    if (n <= 0 || n > 65535 || W < 2 || H < 2 || W > 32767 || H > 32767 || R <= 0 || C <= 0 || R * C > 4096) {
+    unsigned long long bad = 0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long z = (i + seed) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        // mantissa from the hash, exponent -1 or 0 (|w| in [0.5, 2)), random sign; a few exact end points
+        unsigned long long bits = (z & 0x800FFFFFFFFFFFFFull) | ((0x3FEull + ((z >> 52) & 1ull)) << 52);
+        if ((i & 0xFFFFF) == 0) bits = 0x4000000000000000ull;             // 2.0
+        if ((i & 0xFFFFF) == 1) bits = 0x3FE0000000000000ull;             // 0.5
+        const double w = __longlong_as_double((long long)bits);
+        const double a = recip_unit_range(w);
+        const double b = 1.0 / w;
+        if (__double_as_longlong(a) != __double_as_longlong(b)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t st)
+{
+    hipLaunchKernelGGL(selftest_recip_kernel, dim3(2048), dim3(256), 0, st, n, seed, d_mismatches);
+    return hip_fail(hipGetLastError(), "selftest_recip_kernel launch");
+}
+
+int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n, int W, int H, int R, int C,
+                uint32_t border, int32_t* crop, hipStream_t st)
+{
+    if (n <= 0 || n > 65535 || W < 2 || H < 2 || W > 32767 || H > 32767 || R <= 0 || C <= 0 || R > MAX_MESH ||
+        C > MAX_MESH) {
         set_error("mf_warp_u8c3: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
         return MF_ERR_INVALID_ARG;
     }
     const dim3 grid((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H, n);
-    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, records, boxes, n, W, H, R * C, border, crop);
+    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, tv.records, tv.edges, tv.reach, tv.grid, n, W, H,
+                       R, C, border, crop);
     return hip_fail(hipGetLastError(), "warp_kernel launch");
 }
 

@@ -204,6 +204,13 @@ def test_warp_1080p_vs_c_oracle_and_identity(dev):
     np.testing.assert_array_equal(crop, [[0, 0, W - 1, H - 1]] * 2)
 
 
+def test_trimmed_reciprocal_matches_ieee_division(dev):
+    from meshflow_amd import _lib
+    bad = ctypes.c_uint64(123)
+    _lib.check(_lib.lib.mf_selftest_recip(1 << 32, 12345, ctypes.byref(bad)))
+    assert bad.value == 0
+
+
 def test_degenerate_mesh_is_reported(dev):
     from meshflow_amd import synthetic
     H, W, R, C = 64, 96, 4, 4
