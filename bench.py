@@ -43,7 +43,8 @@ def cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, budget_frames):
     linearly to F frames).  The oracle is only the thing timed here, never part of the product path."""
     from meshflow_amd import synthetic
     from oracle import clib, meshflow_oracle as mo
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, max(budget_frames, 1))
+    os.environ['OMP_NUM_THREADS'] = str(threads)
     taps, lam, on = mo.jacobi_band_coefficients(F, W, H, 0, hom, omega)
     b = np.ascontiguousarray(disp.reshape(F, -1))
     t0 = time.perf_counter()
@@ -71,7 +72,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
     ap.add_argument('--frames-kind', default='pattern', choices=['pattern', 'noise'])
-    ap.add_argument('--cpu-frames', type=int, default=8, help='frames warped by the CPU baseline (0 = skip)')
+    ap.add_argument('--cpu-frames', type=int, default=64, help='frames warped by the CPU baseline (0 = skip)')
     ap.add_argument('--gather', action='store_true', help='also time one RCCL gather of all frames to rank 0')
     args = ap.parse_args()
 
@@ -144,6 +145,12 @@ def main():
     if rank == 0:
         algo_bytes = 2.0 * H * W * 3 * (hi - lo)
         achieved = algo_bytes / (warp_ms * 1e-3)
+        traffic = None            # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
+        try:
+            with open(os.path.join(REPO, 'profiles', 'traffic.json')) as fh:
+                traffic = json.load(fh).get(args.workload, {}).get('traffic_bytes')
+        except (OSError, ValueError):
+            pass
         result = {
             'metric': 'frames/sec stabilize() hot path (Jacobi + mesh warp + crop scan), inputs resident in HBM',
             'value': F * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
@@ -155,7 +162,10 @@ def main():
                        'parallelism': f'frame-range shards x{world}, Jacobi replicated, 16-byte crop all-reduce'},
             'roofline': {'kernel': 'warp_kernel', 'bound': 'hbm', 'achieved': achieved / 1e9,
                          'peak': HBM_PEAK_BYTES_PER_S / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_BYTES_PER_S,
-                         'traffic': None, 'algorithmic_bytes_per_launch': algo_bytes, 'avg_launch_ms': warp_ms},
+                         'traffic': traffic, 'traffic_source': 'profiles/traffic.json (PMC FETCH_SIZE/WRITE_SIZE, calibrated)'
+                         if traffic else None,
+                         'algorithmic_bytes_per_launch': algo_bytes, 'avg_launch_ms': warp_ms,
+                         'note': 'VALU-issue bound (float64 coordinate arithmetic), not HBM bound: see DESIGN.md'},
             'jacobi': {'avg_ms_incl_host_setup': jac_ms, 'series': int(d_disp[0].numel()), 'frames': F},
             'crop_bounds': [int(v) for v in bounds.tolist()],
         }

@@ -6,10 +6,6 @@
  *   _get_stabilized_vertex_displacements        mfs.py:632-710   -> mf_jacobi_f64
  *   _get_stabilized_frames_and_crop_boundaries  mfs.py:909-1108  -> mf_cell_table_f64 + mf_warp_u8c3
  *
- * and, next on the path:
- *
- *   _crop_frames                                mfs.py:1111-1157 -> mf_crop_resize_u8c3
- *
  * Every entry point takes plain pointers and sizes.  Pointers named d_* are DEVICE pointers
  * (hipMalloc / torch tensors' data_ptr()); `stream` is a hipStream_t passed as void* (NULL = the
  * default stream).  Kernel entry points are asynchronous on `stream`.  Return value: 0 on success,
@@ -45,7 +41,8 @@ extern "C" {
  *                   is certainly zero (x0 > x1: empty)
  *   [26]     status: 0 ok, 1 degenerate
  *   [27..31] reserved
- * The table of n frames is n*R*C records followed by n*R*C compact boxes (4 x int16 each). */
+ * The table blob of n frames (mf_cell_table_bytes) holds n*R*C records followed by private acceleration
+ * data of the warp kernel (compact boxes, edge functions, per-frame reach, vertex grid). */
 #define MF_CELL_DOUBLES 32
 #define MF_CELL_OFF_M 0
 #define MF_CELL_OFF_HI 9
@@ -97,11 +94,6 @@ int mf_warp_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, i
 /* Clip-level crop bounds (mfs.py:1103-1106): {max left, max top, min right, min bottom} over n frames.
  * d_bounds: [4] int32. */
 int mf_crop_reduce(const int32_t* d_crop, int n, int W, int H, int32_t* d_bounds, void* stream);
-
-/* ---- next row: crop + bilinear resize (mfs.py:1111-1157, cv2.resize INTER_LINEAR to (W, H)) ----
- * Crops every frame to the inclusive bounds {left, top, right, bottom} and scales back to W x H. */
-int mf_crop_resize_u8c3(const uint8_t* d_frames, uint8_t* d_out, int n, int W, int H,
-                        int left, int top, int right, int bottom, void* stream);
 
 /* Device self-test: the warp kernel's trimmed reciprocal (exact for 0.5 <= |w| <= 2) against IEEE 1.0/w on
  * n hashed inputs; *mismatches receives the number of differing bit patterns (must be 0). Synchronous. */

@@ -60,7 +60,5 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
                 uint32_t border, int32_t* crop, hipStream_t st);
 int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t st);
 int launch_crop_reduce(const int32_t* crop, int n, int W, int H, int32_t* bounds, hipStream_t st);
-int launch_crop_resize(const uint8_t* frames, uint8_t* out, int n, int W, int H, int left, int top, int right,
-                       int bottom, hipStream_t st);
 
 }  // namespace mf

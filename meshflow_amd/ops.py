@@ -109,14 +109,3 @@ def crop_reduce(crop, W, H):
     bounds = torch.empty(4, dtype=torch.int32, device=crop.device)
     _lib.check(_lib_.mf_crop_reduce(_ptr(crop), crop.shape[0], W, H, _ptr(bounds), _stream()))
     return bounds
-
-
-def crop_resize(frames, bounds, out=None):
-    """Crop to inclusive (left, top, right, bottom) and resize back to (W, H) (mfs.py:1111-1157)."""
-    _need(frames, torch.uint8, 'frames')
-    n, H, W, _ = frames.shape
-    left, top, right, bottom = (int(v) for v in bounds)
-    if out is None:
-        out = torch.empty_like(frames)
-    _lib.check(_lib_.mf_crop_resize_u8c3(_ptr(frames), _ptr(out), n, W, H, left, top, right, bottom, _stream()))
-    return out
