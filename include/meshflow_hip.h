@@ -42,7 +42,7 @@ extern "C" {
  *   [26]     status: 0 ok, 1 degenerate
  *   [27..31] reserved
  * The table blob of n frames (mf_cell_table_bytes) holds n*R*C records followed by private acceleration
- * data of the warp kernel (compact boxes, edge functions, per-frame reach, vertex grid). */
+ * data of the warp kernel (compact boxes, edge functions, per-footprint candidate plan, per-frame reach, vertex grid). */
 #define MF_CELL_DOUBLES 32
 #define MF_CELL_OFF_M 0
 #define MF_CELL_OFF_HI 9
@@ -75,10 +75,10 @@ int mf_jacobi_f64(const double* d_b, double* d_x, const double* d_taps, const do
 
 /* ---- kernel 2a: per-cell homography table (mfs.py:881-906, 964-967, 1025-1027, 1039-1048) ----
  * d_unstab, d_stab: [n][(R+1)*(C+1)][2] float64 vertex displacements of the n frames to warp.
- * d_table: mf_cell_table_bytes(n, R, C) bytes.  d_crop: [n][4] int32, initialised here to the
+ * d_table: mf_cell_table_bytes(n, W, H, R, C) bytes, 16-byte aligned.  d_crop: [n][4] int32, initialised here to the
  * per-frame defaults {0, 0, W-1, H-1} = {left, top, right, bottom} (mfs.py:992-995).
  * d_status: one int32, incremented once per degenerate cell (zero it before the call). */
-size_t mf_cell_table_bytes(int n, int R, int C);
+size_t mf_cell_table_bytes(int n, int W, int H, int R, int C);
 int mf_cell_table_f64(const double* d_unstab, const double* d_stab, int n, int W, int H, int R, int C,
                       void* d_table, int32_t* d_crop, int32_t* d_status, void* stream);
 

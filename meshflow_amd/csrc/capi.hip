@@ -79,10 +79,10 @@ int mf_jacobi_f64(const double* d_b, double* d_x, const double* d_taps, const do
     return launch_jacobi(d_b, d_x, d_taps, d_lam, d_inv_on, F, S, omega, iters, (hipStream_t)stream);
 }
 
-size_t mf_cell_table_bytes(int n, int R, int C)
+size_t mf_cell_table_bytes(int n, int W, int H, int R, int C)
 {
-    if (n <= 0 || R <= 0 || C <= 0) return 0;
-    return table_bytes(n, R, C);
+    if (n <= 0 || R <= 0 || C <= 0 || W <= 0 || H <= 0) return 0;
+    return table_bytes(n, W, H, R, C);
 }
 
 int mf_cell_table_f64(const double* d_unstab, const double* d_stab, int n, int W, int H, int R, int C,
@@ -90,9 +90,8 @@ int mf_cell_table_f64(const double* d_unstab, const double* d_stab, int n, int W
 {
     if (!d_unstab || !d_stab || !d_table || !d_crop || !d_status) { set_error("mf_cell_table_f64: null pointer"); return MF_ERR_INVALID_ARG; }
     if (n <= 0 || R <= 0 || C <= 0) { set_error("mf_cell_table_f64: bad sizes"); return MF_ERR_INVALID_ARG; }
-    const TableView tv = table_view(d_table, n, R, C);
-    return launch_cell_table(d_unstab, d_stab, n, W, H, R, C, tv.records, tv.boxes, tv.edges, tv.reach, tv.grid, d_crop,
-                             d_status, (hipStream_t)stream);
+    const TableView tv = table_view(d_table, n, W, H, R, C);
+    return launch_cell_table(d_unstab, d_stab, n, W, H, R, C, tv, d_crop, d_status, (hipStream_t)stream);
 }
 
 int mf_warp_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, int n, int W, int H,
@@ -101,7 +100,7 @@ int mf_warp_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, i
     if (!d_frames || !d_out || !d_table || !border_bgr || !d_crop) { set_error("mf_warp_u8c3: null pointer"); return MF_ERR_INVALID_ARG; }
     if (d_frames == d_out) { set_error("mf_warp_u8c3: d_frames and d_out alias"); return MF_ERR_INVALID_ARG; }
     if (n <= 0 || R <= 0 || C <= 0) { set_error("mf_warp_u8c3: bad sizes"); return MF_ERR_INVALID_ARG; }
-    const TableView tv = table_view(const_cast<void*>(d_table), n, R, C);
+    const TableView tv = table_view(const_cast<void*>(d_table), n, W, H, R, C);
     return launch_warp(d_frames, d_out, tv, n, W, H, R, C, pack_border(border_bgr), d_crop, (hipStream_t)stream);
 }
 
@@ -185,7 +184,7 @@ int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab,
     MF_HIP_TRY(hipEventCreate(&e1.e));
     MF_HIP_TRY(dfr.alloc(fb)); MF_HIP_TRY(dout.alloc(fb));
     MF_HIP_TRY(du.alloc(vb)); MF_HIP_TRY(ds.alloc(vb));
-    MF_HIP_TRY(dtab.alloc(mf_cell_table_bytes(n, R, C)));
+    MF_HIP_TRY(dtab.alloc(mf_cell_table_bytes(n, W, H, R, C)));
     MF_HIP_TRY(dcrop.alloc((size_t)n * 4 * sizeof(int32_t)));
     MF_HIP_TRY(dstat.alloc(sizeof(int32_t)));
     MF_HIP_TRY(hipMemsetAsync(dstat.p, 0, sizeof(int32_t), st.s));

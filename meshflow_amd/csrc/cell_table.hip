@@ -233,23 +233,92 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
     boxes[gid] = box;
 }
 
+// Footprint plan: one thread per 32 x 8 pixel footprint of the warp kernel.  Lists, in descending cell
+// order, the cells that can own a pixel of the footprint, classified with the float32 edge functions at the
+// four footprint corners (affine functions: the corners bound the footprint; margin of one unit = 1/32 px):
+//   OUT   some edge function is < -1 at all four corners            -> not listed
+//   IN    every edge function is > +1 at all four corners           -> listed, ends the list (it owns the rest)
+//   MIXED otherwise                                                 -> listed, the warp kernel tests per pixel
+// Doing this here costs one lane per footprint instead of a whole wavefront per footprint in the warp kernel.
+__global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __restrict__ edges,
+                                                             const int32_t* __restrict__ reach,
+                                                             const int32_t* __restrict__ grid, int n, int W, int H, int R,
+                                                             int C, FootPlan* __restrict__ plan)
+{
+    __shared__ int s_gx[66], s_gy[66];
+    if ((int)threadIdx.x <= C) s_gx[threadIdx.x] = grid[threadIdx.x];
+    if ((int)threadIdx.x <= R) s_gy[threadIdx.x] = grid[C + 1 + threadIdx.x];
+    __syncthreads();
+    const int nfx = (W + MF_FOOT_W - 1) / MF_FOOT_W, nfy = (H + MF_FOOT_H - 1) / MF_FOOT_H;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)n * nfy * nfx) return;
+    const int f = (int)(gid / (nfy * nfx));
+    const int rem = (int)(gid % (nfy * nfx));
+    const int fy = rem / nfx, fx = rem % nfx;
+    const int xa = fx * MF_FOOT_W, xb = min(xa + MF_FOOT_W - 1, W - 1);
+    const int ya = fy * MF_FOOT_H, yb = min(ya + MF_FOOT_H - 1, H - 1);
+    const int rxlo = reach[4 * f + 0], rylo = reach[4 * f + 1], rxhi = reach[4 * f + 2], ryhi = reach[4 * f + 3];
+    // cells whose grid rect, widened by the frame's reach, meets the footprint (contiguous index ranges)
+    int c_lo = 0, c_hi = C - 1, r_lo = 0, r_hi = R - 1;
+    while (c_lo < C - 1 && s_gx[c_lo + 1] < xa - rxhi) ++c_lo;
+    while (c_hi > 0 && s_gx[c_hi] > xb + rxlo) --c_hi;
+    while (r_lo < R - 1 && s_gy[r_lo + 1] < ya - ryhi) ++r_lo;
+    while (r_hi > 0 && s_gy[r_hi] > yb + rylo) --r_hi;
+    FootPlan p;
+    for (int i = 0; i < 8; ++i) p.e[i] = 0;
+    int cnt = 0;
+    bool overflow = false, closed = false;
+    const float cxs[2] = { (float)xa, (float)xb }, cys[2] = { (float)ya, (float)yb };
+    const float* __restrict__ fedge = edges + (size_t)f * R * C * MF_EDGE_FLOATS;
+    for (int r = r_hi; r >= r_lo && !closed && !overflow; --r)
+        for (int c = c_hi; c >= c_lo && !closed && !overflow; --c) {
+            const int k = r * C + c;
+            const float* __restrict__ ed = fedge + (size_t)k * MF_EDGE_FLOATS;
+            bool all_in = true, any_out = false;
+            for (int e = 0; e < 4; ++e) {
+                bool e_in = true, e_out = true;
+                for (int q = 0; q < 4; ++q) {
+                    const float g = ed[3 * e] * cxs[q & 1] + ed[3 * e + 1] * cys[q >> 1] + ed[3 * e + 2];
+                    e_in = e_in && g > 1.0f;
+                    e_out = e_out && g < -1.0f;
+                }
+                all_in = all_in && e_in;
+                any_out = any_out || e_out;
+            }
+            if (any_out) continue;
+            if (cnt == 8) { overflow = true; break; }
+            p.e[cnt++] = (uint16_t)(k | MF_PLAN_VALID | (all_in ? MF_PLAN_IN : 0u));
+            if (all_in) closed = true;
+        }
+    if (overflow) {
+        // more than 8 candidates: hand the whole range to the warp kernel instead
+        p.e[0] = (uint16_t)r_lo; p.e[1] = (uint16_t)r_hi; p.e[2] = (uint16_t)c_lo; p.e[3] = (uint16_t)c_hi;
+        p.e[4] = p.e[5] = p.e[6] = 0; p.e[7] = (uint16_t)MF_PLAN_OVERFLOW;
+    }
+    plan[gid] = p;
+}
+
 int launch_cell_table(const double* unstab, const double* stab, int n, int W, int H, int R, int C,
-                      double* records, CellBox* boxes, float* edges, int32_t* reach, int32_t* grid, int32_t* crop,
-                      int32_t* status, hipStream_t st)
+                      const TableView& tv, int32_t* crop, int32_t* status, hipStream_t st)
 {
     if (n <= 0 || R <= 0 || C <= 0 || W < 2 || H < 2 || W > 32767 || H > 32767 || R > 64 || C > 64) {
         set_error("mf_cell_table_f64: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
         return MF_ERR_INVALID_ARG;
     }
-    hipError_t e = hipMemsetAsync(reach, 0, (size_t)n * 4 * sizeof(int32_t), st);
+    hipError_t e = hipMemsetAsync(tv.reach, 0, (size_t)n * 4 * sizeof(int32_t), st);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(reach)");
     const long long total = (long long)n * R * C;
     long long threads = total > n ? total : n;
     if (threads < 65) threads = 65;
     const unsigned blocks = (unsigned)((threads + 63) / 64);
-    hipLaunchKernelGGL(cell_table_kernel, dim3(blocks), dim3(64), 0, st, unstab, stab, n, W, H, R, C, records, boxes,
-                       edges, reach, grid, crop, status);
-    return hip_fail(hipGetLastError(), "cell_table_kernel launch");
+    hipLaunchKernelGGL(cell_table_kernel, dim3(blocks), dim3(64), 0, st, unstab, stab, n, W, H, R, C, tv.records, tv.boxes,
+                       tv.edges, tv.reach, tv.grid, crop, status);
+    int rc = hip_fail(hipGetLastError(), "cell_table_kernel launch");
+    if (rc != MF_OK) return rc;
+    const size_t nplan = plan_count(n, W, H);
+    hipLaunchKernelGGL(footprint_plan_kernel, dim3((unsigned)((nplan + 255) / 256)), dim3(256), 0, st, tv.edges, tv.reach,
+                       tv.grid, n, W, H, R, C, tv.plan);
+    return hip_fail(hipGetLastError(), "footprint_plan_kernel launch");
 }
 
 }  // namespace mf

@@ -22,30 +22,50 @@ struct alignas(8) CellBox { int16_t x0, y0, x1, y1; };
 
 inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 
-// Layout of the cell table blob (mf_cell_table_bytes): records | boxes | edges | reach | grid.
+// Layout of the cell table blob (mf_cell_table_bytes): records | boxes | edges | plan | reach | grid.
 //   records: n*R*C x MF_CELL_DOUBLES float64      (ABI, include/meshflow_hip.h)
 //   boxes:   n*R*C x CellBox                      compact copy of the record's bbox
 //   edges:   n*R*C x MF_EDGE_FLOATS float32       4 affine edge functions {a, b, c} (cell_table.hip)
+//   plan:    n x ceil(H/8) x ceil(W/32) x 16 B    per 32x8-pixel footprint: candidate cells, descending
 //   reach:   n x 4 int32                          per-frame max extent of a box beyond its grid rect
 //   grid:    (C+1) + (R+1) int32                  vertex x / y pixel coordinates
 #define MF_EDGE_FLOATS 12
+#define MF_FOOT_W 32
+#define MF_FOOT_H 8
+// Plan entry (uint16): bits 0-11 cell index, bit 14 = entry valid, bit 15 = IN (every pixel of the footprint
+// passes the cell's mask test).  Up to 8 entries in descending cell order; the list ends at the first IN
+// entry or the first invalid one.  Entry 7 == 0xFFFF: too many candidates -- entries 0-3 then hold the
+// cell range r_lo, r_hi, c_lo, c_hi and the warp kernel tests every cell of the range.
+#define MF_PLAN_VALID 0x4000u
+#define MF_PLAN_IN 0x8000u
+#define MF_PLAN_OVERFLOW 0xFFFFu
+struct alignas(16) FootPlan { uint16_t e[8]; };
 struct TableView {
-    double* records; CellBox* boxes; float* edges; int32_t* reach; int32_t* grid;
+    double* records; CellBox* boxes; float* edges; FootPlan* plan; int32_t* reach; int32_t* grid;
 };
-inline size_t table_bytes(int n, int R, int C)
+inline size_t plan_count(int n, int W, int H)
 {
-    const size_t nrec = table_records(n, R, C);
-    return nrec * (MF_CELL_DOUBLES * sizeof(double) + sizeof(CellBox) + MF_EDGE_FLOATS * sizeof(float)) +
-           (size_t)n * 4 * sizeof(int32_t) + (size_t)(R + C + 2) * sizeof(int32_t);
+    return (size_t)n * ((H + MF_FOOT_H - 1) / MF_FOOT_H) * ((W + MF_FOOT_W - 1) / MF_FOOT_W);
 }
-inline TableView table_view(void* blob, int n, int R, int C)
+inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+inline size_t plan_offset(int n, int R, int C)
+{
+    return align16(table_records(n, R, C) * (MF_CELL_DOUBLES * sizeof(double) + sizeof(CellBox) + MF_EDGE_FLOATS * sizeof(float)));
+}
+inline size_t table_bytes(int n, int W, int H, int R, int C)
+{
+    return plan_offset(n, R, C) + plan_count(n, W, H) * sizeof(FootPlan) + (size_t)n * 4 * sizeof(int32_t) +
+           (size_t)(R + C + 2) * sizeof(int32_t);
+}
+inline TableView table_view(void* blob, int n, int W, int H, int R, int C)
 {
     const size_t nrec = table_records(n, R, C);
     TableView v;
     v.records = (double*)blob;
     v.boxes = (CellBox*)(v.records + nrec * MF_CELL_DOUBLES);
     v.edges = (float*)(v.boxes + nrec);
-    v.reach = (int32_t*)(v.edges + nrec * MF_EDGE_FLOATS);
+    v.plan = (FootPlan*)((char*)blob + plan_offset(n, R, C));
+    v.reach = (int32_t*)(v.plan + plan_count(n, W, H));
     v.grid = v.reach + (size_t)n * 4;
     return v;
 }
@@ -54,8 +74,7 @@ inline TableView table_view(void* blob, int n, int R, int C)
 int launch_jacobi(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
                   int F, int S, int omega, int iters, hipStream_t st);
 int launch_cell_table(const double* unstab, const double* stab, int n, int W, int H, int R, int C,
-                      double* records, CellBox* boxes, float* edges, int32_t* reach, int32_t* grid, int32_t* crop,
-                      int32_t* status, hipStream_t st);
+                      const TableView& tv, int32_t* crop, int32_t* status, hipStream_t st);
 int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n, int W, int H, int R, int C,
                 uint32_t border, int32_t* crop, hipStream_t st);
 int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t st);

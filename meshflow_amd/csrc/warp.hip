@@ -43,8 +43,8 @@
 namespace mf {
 
 constexpr int TILE_W = 128;
-constexpr int FOOT_W = 32;      // 8 lanes x 4 pixels
-constexpr int FOOT_H = 8;       // 64 lanes / 8
+constexpr int FOOT_W = MF_FOOT_W;   // 8 lanes x 4 pixels
+constexpr int FOOT_H = MF_FOOT_H;   // 64 lanes / 8
 constexpr int FOOTS = 2;        // footprints per wavefront, stacked vertically
 constexpr int TILE_H = FOOT_H * FOOTS;
 constexpr int MAX_MESH = 64;    // R, C <= 64
@@ -108,188 +108,183 @@ __device__ __forceinline__ double recip_unit_range(double w)
     return __builtin_fma(e, r, r);
 }
 
+// Source coordinates of the lane's four pixels under cell `rec`'s inverse homography:
+// cv2.perspectiveTransform (matmul.simd.hpp) -- float32 point, float64 matrix, float32 result.
+// SELECT = false: every pixel takes the new coordinates; true: only those in `pass`.
+template <bool SELECT>
+__device__ __forceinline__ void cell_coords(const double* __restrict__ rec, double xs0, double yy, int x0, uint32_t pass,
+                                            float (&u)[4], float (&v)[4])
+{
+    double Hi[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Hi[i] = rec[MF_CELL_OFF_HI + i];
+    const double t6 = yy * Hi[7], t0 = yy * Hi[1], t3 = yy * Hi[4];
+    double w4[4];
+    uint32_t eor = 0;                                          // |w| in [0.5, 2) <=> frexp exponent in {0, 1}
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double xs = xs0 + (double)j;                     // exact: small integers
+        w4[j] = (xs * Hi[6] + t6) + Hi[8];
+        eor |= (uint32_t)__builtin_amdgcn_frexp_exp(w4[j]);
+    }
+    if (__ballot(eor > 1u) == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double xs = xs0 + (double)j;
+            const double iw = recip_unit_range(w4[j]);
+            const float un = (float)(((xs * Hi[0] + t0) + Hi[2]) * iw);
+            const float vn = (float)(((xs * Hi[3] + t3) + Hi[5]) * iw);
+            if (SELECT) {
+                const bool p = (pass >> j) & 1u;
+                u[j] = p ? un : u[j];
+                v[j] = p ? vn : v[j];
+            } else {
+                u[j] = un;
+                v[j] = vn;
+            }
+        }
+    } else {                                                   // far-from-affine cell: generic division
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            if (SELECT && !((pass >> j) & 1u)) continue;
+            const double xs = (double)(x0 + j);
+            double w = (xs * Hi[6] + t6) + Hi[8];
+            float un = 0.0f, vn = 0.0f;
+            if (fabs(w) > 1.1920928955078125e-07) {
+                w = 1.0 / w;
+                un = (float)(((xs * Hi[0] + t0) + Hi[2]) * w);
+                vn = (float)(((xs * Hi[3] + t3) + Hi[5]) * w);
+            }
+            if (j == 0) { u[0] = un; v[0] = vn; }
+            else if (j == 1) { u[1] = un; v[1] = vn; }
+            else if (j == 2) { u[2] = un; v[2] = vn; }
+            else { u[3] = un; v[3] = vn; }
+        }
+    }
+}
+
+// Per-pixel mask test of a MIXED cell for the lane's four pixels; returns the 4-bit pass mask.
+// Division-free decision: with Xn = M0 x + M1 y + M2 and Wd = M6 x + M7 y + M8 > 0, OpenCV's
+// fX = fl(Xn * fl(32/Wd)) differs from 32 Xn / Wd by < 1e-9 relative, and rint(fX) > lo <=> fX > lo + 1/2
+// (lo is even).  So the sign of q = 32 Xn - (lo + 1/2) Wd (and its three siblings) decides the test unless
+// |q| <= 1e-6 Wd; only then is the exact arithmetic (division, rint) needed.
+__device__ __forceinline__ uint32_t cell_mask_test(const double* __restrict__ rec, double xs0, double yy, int x0, int y,
+                                                   uint32_t unowned)
+{
+    double M[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M[i] = rec[MF_CELL_OFF_M + i];
+    const double rL = rec[MF_CELL_OFF_RECT + 0], rT = rec[MF_CELL_OFF_RECT + 1];
+    const double rR = rec[MF_CELL_OFF_RECT + 2], rB = rec[MF_CELL_OFF_RECT + 3];
+    const double loxh = 32.0 * (rL - 1.0) + 0.5, hixh = 32.0 * (rR + 1.0) - 0.5;
+    const double loyh = 32.0 * (rT - 1.0) + 0.5, hiyh = 32.0 * (rB + 1.0) - 0.5;
+    const double RX = __builtin_fma(M[1], yy, M[2]);
+    const double RY = __builtin_fma(M[4], yy, M[5]);
+    const double RW = __builtin_fma(M[7], yy, M[8]);
+    uint32_t ok = 0, amb = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double xs = xs0 + (double)j;
+        const double Wd = __builtin_fma(M[6], xs, RW);
+        const double X32 = 32.0 * __builtin_fma(M[0], xs, RX);
+        const double Y32 = 32.0 * __builtin_fma(M[3], xs, RY);
+        const double qmin = fmin(fmin(__builtin_fma(-loxh, Wd, X32), __builtin_fma(hixh, Wd, -X32)),
+                                 fmin(__builtin_fma(-loyh, Wd, Y32), __builtin_fma(hiyh, Wd, -Y32)));
+        const double t = 1e-6 * Wd;
+        const bool sane = (Wd > 0.25) & (Wd < 4.0);
+        const bool yes = sane & (qmin > t), no = sane & (qmin < -t);
+        ok |= yes ? (1u << j) : 0u;
+        amb |= (yes | no) ? 0u : (1u << j);
+    }
+    amb &= unowned;
+    if (__ballot(amb != 0) != 0) {                             // rare: a pixel within 1e-6 of a mask edge
+        const int lo_x = 32 * ((int)rL - 1), hi_x = 32 * ((int)rR + 1);
+        const int lo_y = 32 * ((int)rT - 1), hi_y = 32 * ((int)rB + 1);
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j)
+            if (((amb >> j) & 1u) && mask_test_exact(M, lo_x, hi_x, lo_y, hi_y, x0 + j, y)) ok |= 1u << j;
+    }
+    return ok & unowned;
+}
+
 __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out,
                                                    const double* __restrict__ records,
-                                                   const float* __restrict__ edges,
-                                                   const int32_t* __restrict__ reach,
-                                                   const int32_t* __restrict__ grid, int n, int W, int H, int R, int C,
+                                                   const FootPlan* __restrict__ plan, int n, int W, int H, int R, int C,
                                                    uint32_t border, int32_t* __restrict__ crop)
 {
-    __shared__ int s_gx[MAX_MESH + 2];
-    __shared__ int s_gy[MAX_MESH + 2];
-    if ((int)threadIdx.x <= C) s_gx[threadIdx.x] = grid[threadIdx.x];
-    if ((int)threadIdx.x <= R) s_gy[threadIdx.x] = grid[C + 1 + threadIdx.x];
-    __syncthreads();
-
     const int f = blockIdx.z;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps plan/record loads scalar
     const int lane = threadIdx.x & 63;
-    const int xa = blockIdx.x * TILE_W + wave * FOOT_W;                  // footprint x range (inclusive)
+    const int xa = blockIdx.x * TILE_W + wave * FOOT_W;                  // footprint x range starts here
     if (xa >= W) return;                                                 // whole wave outside the frame
-    const int xb = min(xa + FOOT_W - 1, W - 1);
     const int x0 = xa + (lane & 7) * 4;                                  // first of this lane's 4 pixels
     const int ncell = R * C;
+    const int nfx = (W + FOOT_W - 1) / FOOT_W, nfy = (H + FOOT_H - 1) / FOOT_H;
 
     const size_t frame_bytes = (size_t)W * H * 3;
     const uint8_t* __restrict__ src = frames + (size_t)f * frame_bytes;
     uint8_t* __restrict__ dst = out + (size_t)f * frame_bytes;
     const size_t limit = (size_t)(n - f) * frame_bytes;
     const double* __restrict__ frec = records + (size_t)f * ncell * MF_CELL_DOUBLES;
-    const float* __restrict__ fedge = edges + (size_t)f * ncell * MF_EDGE_FLOATS;
-    const int reach_xlo = reach[4 * f + 0], reach_ylo = reach[4 * f + 1];
-    const int reach_xhi = reach[4 * f + 2], reach_yhi = reach[4 * f + 3];
-
-    // column range of candidate cells: grid rect [gx[c], gx[c+1]] widened by the reach meets [xa, xb]
-    const bool col_in = lane < C && s_gx[lane] <= xb + reach_xlo && s_gx[lane + 1] >= xa - reach_xhi;
-    const unsigned long long colmask = __ballot(col_in);
-    const int c_lo = __ffsll((long long)colmask) - 1;
-    const int c_hi = 63 - __clzll((long long)colmask);
-    const int nc = c_hi - c_lo + 1;
+    const uint4* __restrict__ fplan = reinterpret_cast<const uint4*>(plan) + ((size_t)f * nfy * nfx + (blockIdx.x * (TILE_W / FOOT_W) + wave));
 
     int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
     const float fWm1 = (float)(W - 1), fHm1 = (float)(H - 1);
     const bool fast_store = (W & 3) == 0;
-    const double xs0 = (double)x0, xs1 = (double)(x0 + 1), xs2 = (double)(x0 + 2), xs3 = (double)(x0 + 3);
+    const double xs0 = (double)x0;
 
 #pragma unroll 1
     for (int q = 0; q < FOOTS; ++q) {
         const int ya = blockIdx.y * TILE_H + q * FOOT_H;
         if (ya >= H) break;
-        const int yb = min(ya + FOOT_H - 1, H - 1);
         const int y = ya + (lane >> 3);
         const double yy = (double)y;
-
-        const bool row_in = lane < R && s_gy[lane] <= yb + reach_ylo && s_gy[lane + 1] >= ya - reach_yhi;
-        const unsigned long long rowmask = __ballot(row_in);
-        const int r_lo = __ffsll((long long)rowmask) - 1;
-        const int r_hi = 63 - __clzll((long long)rowmask);
+        const uint4 pv = fplan[(size_t)(blockIdx.y * FOOTS + q) * nfx];   // wave-uniform: scalar load
 
         // Source coordinates of the lane's 4 pixels; (W+1, H+1) = "no cell covers it" (mfs.py:983-984).
         float u[4], v[4];
-        uint32_t unowned = 0;
+        if ((pv.x & (MF_PLAN_IN | MF_PLAN_VALID)) == (MF_PLAN_IN | MF_PLAN_VALID) && (pv.w >> 16) != MF_PLAN_OVERFLOW) {
+            // one cell owns the whole footprint (the common case): no per-pixel test, no merging
+            cell_coords<false>(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy, x0, 0xFu, u, v);
+        } else {
+            uint32_t unowned = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            u[j] = (float)(W + 1);
-            v[j] = (float)(H + 1);
-            if (x0 + j < W && y < H) unowned |= 1u << j;
-        }
-        bool done = __ballot(unowned != 0) == 0;
-
-        // Candidates (r, c) in [r_lo, r_hi] x [c_lo, c_hi], visited from the last cell to the first,
-        // four per classification pass.
-        int cr = r_hi, cc = c_hi;                                         // wave-uniform cursor
-        while (cr >= r_lo && !done) {
-            // this lane's candidate = cursor stepped back (lane >> 4) times
-            int lr = cr, lc = cc - (lane >> 4);
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-                if (lc < c_lo) { lc += nc; lr -= 1; }
-            const bool lvalid = lr >= r_lo;
-            float g = 0.0f;
-            if (lvalid) {
-                const float* __restrict__ ed = fedge + (uint32_t)(lr * C + lc) * MF_EDGE_FLOATS + ((lane >> 2) & 3) * 3;
-                const float cx = (float)((lane & 1) ? xb : xa);
-                const float cy = (float)((lane & 2) ? yb : ya);
-                g = ed[0] * cx + ed[1] * cy + ed[2];
+            for (int j = 0; j < 4; ++j) {
+                u[j] = (float)(W + 1);
+                v[j] = (float)(H + 1);
+                if (x0 + j < W && y < H) unowned |= 1u << j;
             }
-            const unsigned long long inm = __ballot(lvalid && g > 1.0f);
-            const unsigned long long outm = __ballot(lvalid && g < -1.0f);
-#pragma unroll 1
-            for (int ci = 0; ci < 4 && cr >= r_lo && !done; ++ci) {
-                const int k = cr * C + cc;                                 // wave-uniform cell index
-                if (--cc < c_lo) { cc = c_hi; --cr; }
-                const uint32_t bin = (uint32_t)(inm >> (16 * ci)) & 0xFFFFu;
-                const uint32_t bout = (uint32_t)(outm >> (16 * ci)) & 0xFFFFu;
-                if ((bout & (bout >> 1) & (bout >> 2) & (bout >> 3) & 0x1111u) != 0) continue;     // OUT
+            const bool ovf = (pv.w >> 16) == MF_PLAN_OVERFLOW;
+            const int r_lo = pv.x & 0xFFFF, c_lo = pv.y & 0xFFFF, c_hi = pv.y >> 16;
+            int cr = pv.x >> 16, cc = c_hi;                                // cursor of the overflow (range) mode
+            int idx = 0;
+            bool done = __ballot(unowned != 0) == 0;
+            while (!done) {
+                int k;
+                bool all_in = false;
+                if (!ovf) {
+                    if (idx >= 8) break;
+                    const uint32_t d = idx < 2 ? pv.x : idx < 4 ? pv.y : idx < 6 ? pv.z : pv.w;
+                    const uint32_t e = (d >> (16 * (idx & 1))) & 0xFFFFu;
+                    ++idx;
+                    if (!(e & MF_PLAN_VALID)) break;
+                    k = (int)(e & 0xFFFu);
+                    all_in = (e & MF_PLAN_IN) != 0;
+                } else {
+                    if (cr < r_lo) break;
+                    k = cr * C + cc;
+                    if (--cc < c_lo) { cc = c_hi; --cr; }
+                    if (frec[(uint32_t)k * MF_CELL_DOUBLES + MF_CELL_OFF_STATUS] != 0.0) continue;
+                }
                 const double* __restrict__ rec = frec + (uint32_t)k * MF_CELL_DOUBLES;
                 uint32_t pass = unowned;                                   // IN: every unowned pixel passes
-                if (bin != 0xFFFFu) {
-                    // MIXED: per-pixel mask test.  Division-free decision: with Xn = M0 x + M1 y + M2 and
-                    // Wd = M6 x + M7 y + M8 > 0, OpenCV's fX = fl(Xn * fl(32/Wd)) differs from 32 Xn / Wd by
-                    // < 1e-9 relative, and rint(fX) > lo  <=>  fX > lo + 1/2 (lo is even).  So the sign of
-                    //   q = 32 Xn - (lo + 1/2) Wd   (and its three siblings)
-                    // decides the test unless |q| <= 1e-6 Wd; only then is the exact arithmetic needed.
-                    double M[9];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) M[i] = rec[MF_CELL_OFF_M + i];
-                    const double rL = rec[MF_CELL_OFF_RECT + 0], rT = rec[MF_CELL_OFF_RECT + 1];
-                    const double rR = rec[MF_CELL_OFF_RECT + 2], rB = rec[MF_CELL_OFF_RECT + 3];
-                    const double loxh = 32.0 * (rL - 1.0) + 0.5, hixh = 32.0 * (rR + 1.0) - 0.5;
-                    const double loyh = 32.0 * (rT - 1.0) + 0.5, hiyh = 32.0 * (rB + 1.0) - 0.5;
-                    const double RX = __builtin_fma(M[1], yy, M[2]);
-                    const double RY = __builtin_fma(M[4], yy, M[5]);
-                    const double RW = __builtin_fma(M[7], yy, M[8]);
-                    uint32_t ok = 0, amb = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const double xs = j == 0 ? xs0 : j == 1 ? xs1 : j == 2 ? xs2 : xs3;
-                        const double Wd = __builtin_fma(M[6], xs, RW);
-                        const double X32 = 32.0 * __builtin_fma(M[0], xs, RX);
-                        const double Y32 = 32.0 * __builtin_fma(M[3], xs, RY);
-                        const double qmin = fmin(fmin(__builtin_fma(-loxh, Wd, X32), __builtin_fma(hixh, Wd, -X32)),
-                                                 fmin(__builtin_fma(-loyh, Wd, Y32), __builtin_fma(hiyh, Wd, -Y32)));
-                        const double t = 1e-6 * Wd;
-                        const bool sane = Wd > 0.25 && Wd < 4.0;
-                        if (sane && qmin > t) ok |= 1u << j;
-                        else if (!(sane && qmin < -t)) amb |= 1u << j;
-                    }
-                    amb &= unowned;
-                    if (__ballot(amb != 0) != 0) {                         // rare: a pixel within 1e-6 of a mask edge
-                        const int lo_x = 32 * ((int)rL - 1), hi_x = 32 * ((int)rR + 1);
-                        const int lo_y = 32 * ((int)rT - 1), hi_y = 32 * ((int)rB + 1);
-#pragma unroll 1
-                        for (int j = 0; j < 4; ++j)
-                            if (((amb >> j) & 1u) && mask_test_exact(M, lo_x, hi_x, lo_y, hi_y, x0 + j, y)) ok |= 1u << j;
-                    }
-                    pass = ok & unowned;
+                if (!all_in) {
+                    pass = cell_mask_test(rec, xs0, yy, x0, y, unowned);
                     if (__ballot(pass != 0) == 0) continue;
                 }
                 unowned &= ~pass;
-                // cv2.perspectiveTransform (matmul.simd.hpp): float32 point, float64 matrix, for the lane's
-                // four pixels in straight-line code; results are merged under the pass mask.
-                double Hi[9];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) Hi[i] = rec[MF_CELL_OFF_HI + i];
-                const double t6 = yy * Hi[7], t0 = yy * Hi[1], t3 = yy * Hi[4];
-                double w4[4];
-                uint32_t eor = 0;                                          // |w| in [0.5, 2) <=> frexp exponent in {0, 1}
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const double xs = j == 0 ? xs0 : j == 1 ? xs1 : j == 2 ? xs2 : xs3;
-                    w4[j] = (xs * Hi[6] + t6) + Hi[8];
-                    eor |= (uint32_t)__builtin_amdgcn_frexp_exp(w4[j]);
-                }
-                const bool unit = eor <= 1u;
-                if (__ballot(!unit) == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const double xs = j == 0 ? xs0 : j == 1 ? xs1 : j == 2 ? xs2 : xs3;
-                        const double iw = recip_unit_range(w4[j]);
-                        const float un = (float)(((xs * Hi[0] + t0) + Hi[2]) * iw);
-                        const float vn = (float)(((xs * Hi[3] + t3) + Hi[5]) * iw);
-                        const bool p = (pass >> j) & 1u;
-                        u[j] = p ? un : u[j];
-                        v[j] = p ? vn : v[j];
-                    }
-                } else {                                                   // far-from-affine cell: generic division
-#pragma unroll 1
-                    for (int j = 0; j < 4; ++j) {
-                        if (!((pass >> j) & 1u)) continue;
-                        const double xs = (double)(x0 + j);
-                        double w = (xs * Hi[6] + t6) + Hi[8];
-                        float un = 0.0f, vn = 0.0f;
-                        if (fabs(w) > 1.1920928955078125e-07) {
-                            w = 1.0 / w;
-                            un = (float)(((xs * Hi[0] + t0) + Hi[2]) * w);
-                            vn = (float)(((xs * Hi[3] + t3) + Hi[5]) * w);
-                        }
-                        if (j == 0) { u[0] = un; v[0] = vn; }
-                        else if (j == 1) { u[1] = un; v[1] = vn; }
-                        else if (j == 2) { u[2] = un; v[2] = vn; }
-                        else { u[3] = un; v[3] = vn; }
-                    }
-                }
-                done = __ballot(unowned != 0) == 0;
+                cell_coords<true>(rec, xs0, yy, x0, pass, u, v);
+                done = all_in || __ballot(unowned != 0) == 0;
             }
         }
 
@@ -454,8 +449,7 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
         return MF_ERR_INVALID_ARG;
     }
     const dim3 grid((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H, n);
-    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, tv.records, tv.edges, tv.reach, tv.grid, n, W, H,
-                       R, C, border, crop);
+    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, tv.records, tv.plan, n, W, H, R, C, border, crop);
     return hip_fail(hipGetLastError(), "warp_kernel launch");
 }
 

@@ -51,7 +51,7 @@ class CellTable:
 
     def __init__(self, n, W, H, R, C, device):
         self.n, self.W, self.H, self.R, self.C = n, W, H, R, C
-        nbytes = _lib_.mf_cell_table_bytes(n, R, C)
+        nbytes = _lib_.mf_cell_table_bytes(n, W, H, R, C)
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.crop = torch.empty((n, 4), dtype=torch.int32, device=device)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
