@@ -209,9 +209,12 @@ __device__ __forceinline__ uint32_t cell_mask_test(const double* __restrict__ re
 
 __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out,
                                                    const double* __restrict__ records,
+                                                   const float* __restrict__ edges,
                                                    const FootPlan* __restrict__ plan, int n, int W, int H, int R, int C,
                                                    uint32_t border, int32_t* __restrict__ crop)
 {
+    // inverse homographies of a footprint's candidate cells, per wavefront: [entry][Hi0..Hi8, pad] (80-byte rows)
+    __shared__ __attribute__((aligned(16))) double s_hi[4][8][10];
     const int f = blockIdx.z;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps plan/record loads scalar
     const int lane = threadIdx.x & 63;
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
     uint8_t* __restrict__ dst = out + (size_t)f * frame_bytes;
     const size_t limit = (size_t)(n - f) * frame_bytes;
     const double* __restrict__ frec = records + (size_t)f * ncell * MF_CELL_DOUBLES;
+    const float* __restrict__ fedge = edges + (size_t)f * ncell * MF_EDGE_FLOATS;
     const uint4* __restrict__ fplan = reinterpret_cast<const uint4*>(plan) + ((size_t)f * nfy * nfx + (blockIdx.x * (TILE_W / FOOT_W) + wave));
 
     int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
@@ -246,7 +250,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
         if ((pv.x & (MF_PLAN_IN | MF_PLAN_VALID)) == (MF_PLAN_IN | MF_PLAN_VALID) && (pv.w >> 16) != MF_PLAN_OVERFLOW) {
             // one cell owns the whole footprint (the common case): no per-pixel test, no merging
             cell_coords<false>(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy, x0, 0xFu, u, v);
-        } else {
+        } else if ((pv.w >> 16) == MF_PLAN_OVERFLOW) {
+            // more than 8 candidate cells: test every cell of the recorded range, last cell first
             uint32_t unowned = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -254,37 +259,114 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 v[j] = (float)(H + 1);
                 if (x0 + j < W && y < H) unowned |= 1u << j;
             }
-            const bool ovf = (pv.w >> 16) == MF_PLAN_OVERFLOW;
             const int r_lo = pv.x & 0xFFFF, c_lo = pv.y & 0xFFFF, c_hi = pv.y >> 16;
-            int cr = pv.x >> 16, cc = c_hi;                                // cursor of the overflow (range) mode
-            int idx = 0;
+            int cr = pv.x >> 16, cc = c_hi;
             bool done = __ballot(unowned != 0) == 0;
-            while (!done) {
-                int k;
-                bool all_in = false;
-                if (!ovf) {
-                    if (idx >= 8) break;
-                    const uint32_t d = idx < 2 ? pv.x : idx < 4 ? pv.y : idx < 6 ? pv.z : pv.w;
-                    const uint32_t e = (d >> (16 * (idx & 1))) & 0xFFFFu;
-                    ++idx;
-                    if (!(e & MF_PLAN_VALID)) break;
-                    k = (int)(e & 0xFFFu);
-                    all_in = (e & MF_PLAN_IN) != 0;
-                } else {
-                    if (cr < r_lo) break;
-                    k = cr * C + cc;
-                    if (--cc < c_lo) { cc = c_hi; --cr; }
-                    if (frec[(uint32_t)k * MF_CELL_DOUBLES + MF_CELL_OFF_STATUS] != 0.0) continue;
-                }
+            while (!done && cr >= r_lo) {
+                const int k = cr * C + cc;
+                if (--cc < c_lo) { cc = c_hi; --cr; }
                 const double* __restrict__ rec = frec + (uint32_t)k * MF_CELL_DOUBLES;
-                uint32_t pass = unowned;                                   // IN: every unowned pixel passes
-                if (!all_in) {
-                    pass = cell_mask_test(rec, xs0, yy, x0, y, unowned);
-                    if (__ballot(pass != 0) == 0) continue;
-                }
+                if (rec[MF_CELL_OFF_STATUS] != 0.0) continue;
+                const uint32_t pass = cell_mask_test(rec, xs0, yy, x0, y, unowned);
+                if (__ballot(pass != 0) == 0) continue;
                 unowned &= ~pass;
                 cell_coords<true>(rec, xs0, yy, x0, pass, u, v);
-                done = all_in || __ballot(unowned != 0) == 0;
+                done = __ballot(unowned != 0) == 0;
+            }
+        } else {
+            // Several cells share the footprint.  (a) their inverse homographies go to LDS; (b) ownership is
+            // resolved per pixel, last cell first: a float32 evaluation of the cell's four edge functions
+            // decides unless the pixel is within 1/64 px of a mask edge, then the float64 test; (c) every
+            // pixel computes its coordinates ONCE with its owner's matrix read from LDS.
+            int ne = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t d = i < 2 ? pv.x : i < 4 ? pv.y : i < 6 ? pv.z : pv.w;
+                if (ne == i && ((d >> (16 * (i & 1))) & MF_PLAN_VALID)) ne = i + 1;
+            }
+            for (int base = 0; base < ne * 9; base += 64) {
+                const int i = base + lane;
+                if (i < ne * 9) {
+                    const int e = (i * 57) >> 9;                                  // i / 9 for i < 72
+                    const int dd = i - 9 * e;
+                    const uint32_t d = e < 2 ? pv.x : e < 4 ? pv.y : e < 6 ? pv.z : pv.w;
+                    const uint32_t k = (d >> (16 * (e & 1))) & 0xFFFu;
+                    s_hi[wave][e][dd] = frec[k * MF_CELL_DOUBLES + MF_CELL_OFF_HI + dd];
+                }
+            }
+            uint32_t unowned = 0;
+            int own[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                own[j] = -1;
+                if (x0 + j < W && y < H) unowned |= 1u << j;
+            }
+            const float yf = (float)y, xf0 = (float)x0;
+            bool done = __ballot(unowned != 0) == 0;
+#pragma unroll 1
+            for (int i = 0; i < ne && !done; ++i) {
+                const uint32_t d = i < 2 ? pv.x : i < 4 ? pv.y : i < 6 ? pv.z : pv.w;
+                const uint32_t e = (d >> (16 * (i & 1))) & 0xFFFFu;
+                const uint32_t k = e & 0xFFFu;
+                uint32_t pass = unowned;                                   // IN: every unowned pixel passes
+                if (!(e & MF_PLAN_IN)) {
+                    const float* __restrict__ ed = fedge + k * MF_EDGE_FLOATS;
+                    const float r0 = __builtin_fmaf(ed[1], yf, ed[2]), r1 = __builtin_fmaf(ed[4], yf, ed[5]);
+                    const float r2 = __builtin_fmaf(ed[7], yf, ed[8]), r3 = __builtin_fmaf(ed[10], yf, ed[11]);
+                    uint32_t ok = 0, amb = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xf = xf0 + (float)j;
+                        const float g = fminf(fminf(__builtin_fmaf(ed[0], xf, r0), __builtin_fmaf(ed[3], xf, r1)),
+                                              fminf(__builtin_fmaf(ed[6], xf, r2), __builtin_fmaf(ed[9], xf, r3)));
+                        ok |= g > 0.5f ? (1u << j) : 0u;
+                        amb |= ((g > 0.5f) | (g < -0.5f)) ? 0u : (1u << j);     // NaN (irregular cell) -> ambiguous
+                    }
+                    amb &= unowned;
+                    if (__ballot(amb != 0) != 0)
+                        ok = (ok & ~amb) | cell_mask_test(frec + k * MF_CELL_DOUBLES, xs0, yy, x0, y, amb);
+                    pass = ok & unowned;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) own[j] = ((pass >> j) & 1u) ? i : own[j];
+                unowned &= ~pass;
+                done = __ballot(unowned != 0) == 0;
+            }
+            // (c) coordinates, once per pixel, owner's matrix from LDS (same wavefront wrote it: in order)
+            double w4[4], nx[4], ny[4];
+            uint32_t eor = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double* hp = &s_hi[wave][own[j] < 0 ? 0 : own[j]][0];
+                const double2 h01 = *reinterpret_cast<const double2*>(hp), h23 = *reinterpret_cast<const double2*>(hp + 2);
+                const double2 h45 = *reinterpret_cast<const double2*>(hp + 4), h67 = *reinterpret_cast<const double2*>(hp + 6);
+                const double h8 = hp[8];
+                const double xs = xs0 + (double)j;
+                w4[j] = (xs * h67.x + yy * h67.y) + h8;
+                nx[j] = (xs * h01.x + yy * h01.y) + h23.x;
+                ny[j] = (xs * h23.y + yy * h45.x) + h45.y;
+                eor |= own[j] < 0 ? 0u : (uint32_t)__builtin_amdgcn_frexp_exp(w4[j]);
+            }
+            if (__ballot(eor > 1u) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double iw = recip_unit_range(w4[j]);
+                    const float un = (float)(nx[j] * iw), vn = (float)(ny[j] * iw);
+                    u[j] = own[j] < 0 ? (float)(W + 1) : un;
+                    v[j] = own[j] < 0 ? (float)(H + 1) : vn;
+                }
+            } else {                                                   // far-from-affine cell: generic division
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float un = 0.0f, vn = 0.0f;
+                    if (fabs(w4[j]) > 1.1920928955078125e-07) {
+                        const double iw = 1.0 / w4[j];
+                        un = (float)(nx[j] * iw);
+                        vn = (float)(ny[j] * iw);
+                    }
+                    u[j] = own[j] < 0 ? (float)(W + 1) : un;
+                    v[j] = own[j] < 0 ? (float)(H + 1) : vn;
+                }
             }
         }
 
@@ -449,7 +531,8 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
         return MF_ERR_INVALID_ARG;
     }
     const dim3 grid((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H, n);
-    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, tv.records, tv.plan, n, W, H, R, C, border, crop);
+    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, tv.records, tv.edges, tv.plan, n, W, H, R, C, border,
+                       crop);
     return hip_fail(hipGetLastError(), "warp_kernel launch");
 }
 
