@@ -49,6 +49,15 @@ constexpr int FOOTS = 2;        // footprints per wavefront, stacked vertically
 constexpr int TILE_H = FOOT_H * FOOTS;
 constexpr int MAX_MESH = 64;    // R, C <= 64
 
+// a * b + c on the 24-bit multiplier.  The empty asm makes `c` opaque so that the compiler keeps two chained
+// v_mad_u32_u24 instead of re-associating them into mul + mul + add3 (no instruction is emitted by it, so the
+// compiler still pads every hazard itself).
+__device__ __forceinline__ uint32_t umad24(uint32_t a, uint32_t b, uint32_t c)
+{
+    asm("" : "+v"(c));
+    return __umul24(a, b) + c;
+}
+
 __device__ __forceinline__ int cv_round_f32(float v)
 {
     const float r = rintf(v);
@@ -375,14 +384,15 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
         // sx = rint(32 u) by the 1.5*2^23 trick: fma rounds 32u + magic once, to nearest even, and the
         // integer sits in the low mantissa bits (valid for |32u| < 2^22; anything else lands far outside
         // the "deep interior" window below and is redone exactly by the generic path).
-        int sx[4], sy[4];
+        // Raw float bits of 32u + 1.5*2^23: the low 22 bits hold sx = rint(32u) for 0 <= sx < 2^22.
+        uint32_t bx[4], by[4];
         uint32_t dxm = 0, dym = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            sx[j] = __float_as_int(__builtin_fmaf(u[j], 32.0f, 12582912.0f)) - 0x4B400000;
-            sy[j] = __float_as_int(__builtin_fmaf(v[j], 32.0f, 12582912.0f)) - 0x4B400000;
-            dxm = max(dxm, (uint32_t)(sx[j] - 64));
-            dym = max(dym, (uint32_t)(sy[j] - 64));
+            bx[j] = __float_as_uint(__builtin_fmaf(u[j], 32.0f, 12582912.0f));
+            by[j] = __float_as_uint(__builtin_fmaf(v[j], 32.0f, 12582912.0f));
+            dxm = max(dxm, bx[j] - (0x4B400000u + 64u));
+            dym = max(dym, by[j] - (0x4B400000u + 64u));
         }
         // "deep interior": 2 <= ix <= W-3 and 2 <= iy <= H-3 for all four pixels.  Then both taps in x and
         // y are inside the frame, the 8-byte loads stay inside the row, and no crop flag can be set
@@ -392,18 +402,20 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
         if (__ballot(active && !deep) == 0) {
             // fast path (wave-uniform): every pixel of the footprint samples the deep interior
             if (!active) continue;
+            const uint8_t* __restrict__ src1 = src + 3u * (uint32_t)W;   // row iy + 1
             uint2 a[4], b[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t t = __umul24((uint32_t)(sy[j] >> 5), (uint32_t)W) + (uint32_t)(sx[j] >> 5);
+                // ix = sx >> 5 = bits[5..21] (0x4B400000 >> 5 has no low 17 bits), same for iy
+                const uint32_t t = umad24(__builtin_amdgcn_ubfe(by[j], 5, 17), (uint32_t)W, __builtin_amdgcn_ubfe(bx[j], 5, 17));
                 const uint32_t o = t + (t << 1);
                 __builtin_memcpy(&a[j], src + o, 8);
-                __builtin_memcpy(&b[j], src + (o + 3u * (uint32_t)W), 8);
+                __builtin_memcpy(&b[j], src1 + o, 8);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // a[j].x = B0 G0 R0 B1, a[j].y = G1 R1 . .   (pixel ix, pixel ix+1 of row iy; b: row iy+1)
-                const uint32_t fx = sx[j] & 31, fy = sy[j] & 31;
+                const uint32_t fx = bx[j] & 31u;
                 const uint32_t w0 = 32u - fx;
                 const uint32_t wb = w0 | (fx << 24);          // weights on bytes 0 and 3 of .x  (B0, B1)
                 const uint32_t wg = w0 | (fx << 8);           // weights on bytes 0, 1 of the permuted dword (G0, G1)
@@ -415,10 +427,10 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 const uint32_t hGa = __builtin_amdgcn_udot4(pa, wg, 0u, false), hGb = __builtin_amdgcn_udot4(pb, wg, 0u, false);
                 const uint32_t hRa = __builtin_amdgcn_udot4(pa, wr, 0u, false), hRb = __builtin_amdgcn_udot4(pb, wr, 0u, false);
                 // vertical lerp scaled by 64 so that ((sum + 512) >> 10) lands in byte 2:  (sum + 512) * 64 < 2^24
-                const uint32_t fy6 = fy << 6, wy6 = 2048u - fy6;
-                const uint32_t oB = __umul24(wy6, hBa) + (__umul24(fy6, hBb) + 32768u);
-                const uint32_t oG = __umul24(wy6, hGa) + (__umul24(fy6, hGb) + 32768u);
-                const uint32_t oR = __umul24(wy6, hRa) + (__umul24(fy6, hRb) + 32768u);
+                const uint32_t fy6 = (by[j] << 6) & 0x7C0u, wy6 = 2048u - fy6;
+                const uint32_t oB = umad24(wy6, hBa, umad24(fy6, hBb, 32768u));
+                const uint32_t oG = umad24(wy6, hGa, umad24(fy6, hGb, 32768u));
+                const uint32_t oR = umad24(wy6, hRa, umad24(fy6, hRb, 32768u));
                 const uint32_t bg = __builtin_amdgcn_perm(oG, oB, 0x0C0C0602u);           // B | G << 8
                 px[j] = __builtin_amdgcn_perm(oR, bg, 0x0C060100u);                       // | R << 16
             }
