@@ -17,30 +17,51 @@
 
 namespace mf {
 
+// Fully unrolled so that every index is a compile-time constant and the 8x9 system lives in registers
+// (a dynamically indexed local array would go to scratch memory); the row exchange of partial pivoting is a
+// predicated swap against each candidate row.  Arithmetic and its order are unchanged.
 __device__ static bool solve8(double A[8][8], double r[8], double h[8])
 {
+    bool ok = true;
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
         int p = k;
         double best = fabs(A[k][k]);
-        for (int i = k + 1; i < 8; ++i)
-            if (fabs(A[i][k]) > best) { best = fabs(A[i][k]); p = i; }
-        if (best == 0.0) return false;
-        if (p != k) {
-            for (int j = 0; j < 8; ++j) { double t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
-            double t = r[k]; r[k] = r[p]; r[p] = t;
+#pragma unroll
+        for (int i = k + 1; i < 8; ++i) {
+            const double v = fabs(A[i][k]);
+            if (v > best) { best = v; p = i; }
         }
+        ok = ok && best != 0.0;
+#pragma unroll
+        for (int i = k + 1; i < 8; ++i) {
+            const bool sw = p == i;
+#pragma unroll
+            for (int j = k; j < 8; ++j) {                // columns < k are already zero in both rows
+                const double a = A[k][j], b = A[i][j];
+                A[k][j] = sw ? b : a;
+                A[i][j] = sw ? a : b;
+            }
+            const double a = r[k], b = r[i];
+            r[k] = sw ? b : a;
+            r[i] = sw ? a : b;
+        }
+#pragma unroll
         for (int i = k + 1; i < 8; ++i) {
             const double f = A[i][k] / A[k][k];
+#pragma unroll
             for (int j = k + 1; j < 8; ++j) A[i][j] = A[i][j] - f * A[k][j];
             r[i] = r[i] - f * r[k];
         }
     }
+#pragma unroll
     for (int i = 7; i >= 0; --i) {
         double s = r[i];
+#pragma unroll
         for (int j = i + 1; j < 8; ++j) s = s - A[i][j] * h[j];
         h[i] = s / A[i][i];
     }
-    return true;
+    return ok;
 }
 
 __device__ static void matmul3(const double a[9], const double b[9], double c[9])
@@ -162,9 +183,12 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
     }
     if (gid <= C) grid[gid] = (int32_t)ceil((double)(W - 1) * ((double)gid / (double)C));             // vertex x
     if (gid <= R) grid[C + 1 + gid] = (int32_t)ceil((double)(H - 1) * ((double)gid / (double)R));     // vertex y
-    if (gid >= (long long)n * ncell) return;
-    const int f = (int)(gid / ncell);
-    const int k = (int)(gid % ncell);
+    // Lanes past the end repeat the last cell (identical values to identical addresses) so that the whole
+    // wavefront stays active for the cross-lane reduction at the end.
+    const bool live = gid < (long long)n * ncell;
+    const long long cid = live ? gid : (long long)n * ncell - 1;
+    const int f = (int)(cid / ncell);
+    const int k = (int)(cid % ncell);
     const int r = k / C, c = k % C;
     const size_t vbase = (size_t)f * (R + 1) * (C + 1);
     double ub[8], sb[8];
@@ -180,7 +204,7 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
     }
     double Hf[9], Hi[9];
     const bool ok = homography4(ub, sb, Hf) && homography4(sb, ub, Hi);
-    double* rec = records + (size_t)gid * MF_CELL_DOUBLES;
+    double* rec = records + (size_t)cid * MF_CELL_DOUBLES;
     for (int i = 0; i < MF_CELL_DOUBLES; ++i) rec[i] = 0.0;
     const double L = floor(fmin(fmin(ub[0], ub[2]), fmin(ub[4], ub[6])));
     const double Rt = ceil(fmax(fmax(ub[0], ub[2]), fmax(ub[4], ub[6])));
@@ -189,13 +213,15 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
     rec[MF_CELL_OFF_RECT + 0] = L; rec[MF_CELL_OFF_RECT + 1] = T;
     rec[MF_CELL_OFF_RECT + 2] = Rt; rec[MF_CELL_OFF_RECT + 3] = B;
     CellBox box;
-    float* ed = edges + (size_t)gid * MF_EDGE_FLOATS;
+    int rxlo = 0, rylo = 0, rxhi = 0, ryhi = 0;      // how far this cell's box reaches beyond its grid rect
+    bool has_reach = false;
+    float* ed = edges + (size_t)cid * MF_EDGE_FLOATS;
     if (!ok) {
         for (int e = 0; e < 4; ++e) { ed[3 * e] = 0.0f; ed[3 * e + 1] = 0.0f; ed[3 * e + 2] = -1e30f; }   // never a candidate
         rec[MF_CELL_OFF_STATUS] = 1.0;
         rec[MF_CELL_OFF_BBOX + 0] = 1; rec[MF_CELL_OFF_BBOX + 1] = 1; rec[MF_CELL_OFF_BBOX + 2] = 0; rec[MF_CELL_OFF_BBOX + 3] = 0;
         box.x0 = 1; box.y0 = 1; box.x1 = 0; box.y1 = 0;
-        atomicAdd(status, 1);
+        if (live) atomicAdd(status, 1);
     } else {
         double M[9], bb[4];
         invert3x3(Hf, M);
@@ -222,15 +248,29 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
             32.0 * M[3] - loy * M[6], 32.0 * M[4] - loy * M[7], 32.0 * M[5] - loy * M[8],
             hiy * M[6] - 32.0 * M[3], hiy * M[7] - 32.0 * M[4], hiy * M[8] - 32.0 * M[5] };
         for (int i = 0; i < 12; ++i) ed[i] = regular ? (float)co[i] : __builtin_nanf("");
-        // how far this cell's box reaches beyond its grid rect (per-frame maxima bound the search range)
-        if (box.x0 <= box.x1) {
-            atomicMax(&reach[4 * f + 0], (int)L - box.x0);
-            atomicMax(&reach[4 * f + 1], (int)T - box.y0);
-            atomicMax(&reach[4 * f + 2], box.x1 - (int)Rt);
-            atomicMax(&reach[4 * f + 3], box.y1 - (int)B);
-        }
+        rxlo = (int)L - box.x0; rylo = (int)T - box.y0; rxhi = box.x1 - (int)Rt; ryhi = box.y1 - (int)B;
+        has_reach = live && box.x0 <= box.x1;
     }
-    boxes[gid] = box;
+    boxes[cid] = box;
+    // Per-frame maxima of the reach bound the warp kernel's candidate search.  One atomic per wavefront and
+    // frame instead of one per cell: reduce over the lanes that share a frame first.
+    unsigned long long todo = __ballot(has_reach);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int fl = __shfl(f, leader);
+        const bool mine = has_reach && f == fl;
+        int a = mine ? rxlo : 0, b = mine ? rylo : 0, c2 = mine ? rxhi : 0, d = mine ? ryhi : 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            a = max(a, __shfl_xor(a, off)); b = max(b, __shfl_xor(b, off));
+            c2 = max(c2, __shfl_xor(c2, off)); d = max(d, __shfl_xor(d, off));
+        }
+        if ((int)(threadIdx.x & 63) == leader) {
+            atomicMax(&reach[4 * fl + 0], a); atomicMax(&reach[4 * fl + 1], b);
+            atomicMax(&reach[4 * fl + 2], c2); atomicMax(&reach[4 * fl + 3], d);
+        }
+        todo &= ~__ballot(mine);
+    }
 }
 
 // Footprint plan: one thread per 32 x 8 pixel footprint of the warp kernel.  Lists, in descending cell
