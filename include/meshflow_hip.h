@@ -6,6 +6,10 @@
  *   _get_stabilized_vertex_displacements        mfs.py:632-710   -> mf_jacobi_f64
  *   _get_stabilized_frames_and_crop_boundaries  mfs.py:909-1108  -> mf_cell_table_f64 + mf_warp_u8c3
  *
+ * and the step that follows them:
+ *
+ *   _crop_frames                                mfs.py:1111-1157 -> mf_crop_resize_u8c3
+ *
  * Every entry point takes plain pointers and sizes.  Pointers named d_* are DEVICE pointers
  * (hipMalloc / torch tensors' data_ptr()); `stream` is a hipStream_t passed as void* (NULL = the
  * default stream).  Kernel entry points are asynchronous on `stream`.  Return value: 0 on success,
@@ -94,6 +98,15 @@ int mf_warp_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, i
 /* Clip-level crop bounds (mfs.py:1103-1106): {max left, max top, min right, min bottom} over n frames.
  * d_bounds: [4] int32. */
 int mf_crop_reduce(const int32_t* d_crop, int n, int W, int H, int32_t* d_bounds, void* stream);
+
+/* ---- next row on the path: crop + bilinear resize (mfs.py:1111-1157, called at mfs.py:159) ----
+ * Crops each of the n frames to the inclusive rectangle {left, top, right, bottom} (the clip-level crop
+ * bounds) and scales it back to W x H exactly like cv2.resize(crop, (W, H)) with the default INTER_LINEAR on
+ * 8-bit data (two-pass 11-bit fixed point).  d_work: mf_crop_resize_workspace_bytes(W, H) bytes of scratch.
+ * An empty or out-of-frame rectangle is MF_ERR_INVALID_ARG (cv2.resize fails on an empty source). */
+size_t mf_crop_resize_workspace_bytes(int W, int H);
+int mf_crop_resize_u8c3(const uint8_t* d_frames, uint8_t* d_out, int n, int W, int H, int left, int top, int right,
+                        int bottom, void* d_work, void* stream);
 
 /* Device self-test: the warp kernel's trimmed reciprocal (exact for 0.5 <= |w| <= 2) against IEEE 1.0/w on
  * n hashed inputs; *mismatches receives the number of differing bit patterns (must be 0). Synchronous. */

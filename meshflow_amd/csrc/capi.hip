@@ -110,6 +110,19 @@ int mf_crop_reduce(const int32_t* d_crop, int n, int W, int H, int32_t* d_bounds
     return launch_crop_reduce(d_crop, n, W, H, d_bounds, (hipStream_t)stream);
 }
 
+size_t mf_crop_resize_workspace_bytes(int W, int H)
+{
+    return (W > 0 && H > 0) ? crop_resize_workspace_bytes(W, H) : 0;
+}
+
+int mf_crop_resize_u8c3(const uint8_t* d_frames, uint8_t* d_out, int n, int W, int H, int left, int top, int right,
+                        int bottom, void* d_work, void* stream)
+{
+    if (!d_frames || !d_out || !d_work) { set_error("mf_crop_resize_u8c3: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (d_frames == d_out) { set_error("mf_crop_resize_u8c3: d_frames and d_out alias"); return MF_ERR_INVALID_ARG; }
+    return launch_crop_resize(d_frames, d_out, n, W, H, left, top, right, bottom, d_work, (hipStream_t)stream);
+}
+
 int mf_selftest_recip(uint64_t n, uint64_t seed, uint64_t* mismatches)
 {
     if (!mismatches) { set_error("mf_selftest_recip: null"); return MF_ERR_INVALID_ARG; }

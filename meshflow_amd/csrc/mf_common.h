@@ -78,6 +78,9 @@ int launch_cell_table(const double* unstab, const double* stab, int n, int W, in
 int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n, int W, int H, int R, int C,
                 uint32_t border, int32_t* crop, hipStream_t st);
 int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t st);
+size_t crop_resize_workspace_bytes(int W, int H);
+int launch_crop_resize(const uint8_t* frames, uint8_t* out, int n, int W, int H, int left, int top, int right,
+                       int bottom, void* work, hipStream_t st);
 int launch_crop_reduce(const int32_t* crop, int n, int W, int H, int32_t* bounds, hipStream_t st);
 
 }  // namespace mf

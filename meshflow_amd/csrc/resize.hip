@@ -1,0 +1,145 @@
+// Crop + bilinear resize: the step right after the warp in the reference's stabilize()
+// (meshflowstabilizer.py:159 -> _crop_frames, :1111-1157): every frame is cropped to the clip-level bounds
+// (inclusive) and scaled back to (W, H) with cv2.resize's default INTER_LINEAR.
+//
+// cv2.resize for 8-bit images (imgproc/resize.cpp, cv::hal::resize + resizeGeneric_) is a two-pass 11-bit
+// fixed-point interpolation:
+//   scale = 1 / ((double)dst / src);  f = float((d + 0.5) * scale - 0.5);  s = floor(f);  f -= s
+//   x axis: s < 0 -> (0, 0);  s >= src-1 -> (src-1, 0)        y axis: the two row indices are clipped instead
+//   weights  a0 = cvRound((1 - f) * 2048), a1 = cvRound(f * 2048)          (int16)
+//   horizontal  t  = S[s] * a0 + S[s+1] * a1                                (int32)
+//   vertical    out = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2
+// resize_tables_kernel builds the per-column / per-row tables (W + H entries) on the device in the same
+// float / double operations; resize_kernel applies them: a lane owns 4 consecutive output pixels (one
+// 12-byte store), four 4-byte tap loads per pixel.  Memory-bound in principle (2*H*W*3 bytes per frame);
+// this first version is VALU-bound like the warp kernel and is not tuned yet.
+#include "mf_common.h"
+
+namespace mf {
+
+struct ResizeTab { int32_t ofs; uint32_t w; };     // x: ofs = sx, w = a0 | a1 << 16;  y: ofs = sy0 | sy1 << 16, w = b0 | b1 << 16
+
+__device__ __forceinline__ int cv_round_pos(float v) { return (int)rintf(v); }
+
+__global__ __launch_bounds__(256) void resize_tables_kernel(int cw, int ch, int W, int H, double scale_x, double scale_y,
+                                                            ResizeTab* __restrict__ xtab, ResizeTab* __restrict__ ytab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W) {
+        float fx = (float)(((double)i + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0.0f; sx = 0; }
+        if (sx >= cw - 1) { fx = 0.0f; sx = cw - 1; }
+        const int a0 = cv_round_pos((1.0f - fx) * 2048.0f), a1 = cv_round_pos(fx * 2048.0f);
+        xtab[i].ofs = sx;
+        xtab[i].w = (uint32_t)a0 | ((uint32_t)a1 << 16);
+    }
+    if (i < H) {
+        float fy = (float)(((double)i + 0.5) * scale_y - 0.5);
+        const int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        const int b0 = cv_round_pos((1.0f - fy) * 2048.0f), b1 = cv_round_pos(fy * 2048.0f);
+        const int sy0 = min(max(sy, 0), ch - 1), sy1 = min(max(sy + 1, 0), ch - 1);
+        ytab[i].ofs = sy0 | (sy1 << 16);
+        ytab[i].w = (uint32_t)b0 | ((uint32_t)b1 << 16);
+    }
+}
+
+// B | G << 8 | R << 16 of the pixel at byte offset o; the 4-byte load of the very last pixel of the stack is
+// shifted back by one byte instead of running past the allocation.
+__device__ __forceinline__ uint32_t load_bgr(const uint8_t* __restrict__ frame, uint32_t o, size_t limit)
+{
+    uint32_t v;
+    if ((size_t)o + 4 <= limit) {
+        __builtin_memcpy(&v, frame + o, 4);
+    } else {
+        __builtin_memcpy(&v, frame + o - 1, 4);
+        v >>= 8;
+    }
+    return v & 0xFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out, int n,
+                                                     int W, int H, int left, int top, int cw,
+                                                     const ResizeTab* __restrict__ xtab,
+                                                     const ResizeTab* __restrict__ ytab)
+{
+    const int f = blockIdx.z;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (y >= H || x0 >= W) return;
+    const size_t frame_bytes = (size_t)W * H * 3;
+    const uint8_t* __restrict__ src = frames + (size_t)f * frame_bytes;
+    uint8_t* __restrict__ dst = out + (size_t)f * frame_bytes;
+    const size_t limit = (size_t)(n - f) * frame_bytes;
+    const ResizeTab yt = ytab[y];
+    const uint32_t b0 = yt.w & 0xFFFFu, b1 = yt.w >> 16;
+    const uint32_t row0 = (uint32_t)(top + (yt.ofs & 0xFFFF)) * (uint32_t)W + (uint32_t)left;
+    const uint32_t row1 = (uint32_t)(top + (yt.ofs >> 16)) * (uint32_t)W + (uint32_t)left;
+    uint32_t px[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        px[j] = 0;
+        if (x0 + j >= W) continue;
+        const ResizeTab xt = xtab[x0 + j];
+        const uint32_t a0 = xt.w & 0xFFFFu, a1 = xt.w >> 16;
+        const uint32_t sx = (uint32_t)xt.ofs, sx1 = min(sx + 1u, (uint32_t)(cw - 1));     // a1 == 0 where sx == cw-1
+        const uint32_t p00 = load_bgr(src, (row0 + sx) * 3u, limit), p01 = load_bgr(src, (row0 + sx1) * 3u, limit);
+        const uint32_t p10 = load_bgr(src, (row1 + sx) * 3u, limit), p11 = load_bgr(src, (row1 + sx1) * 3u, limit);
+        uint32_t r = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t t0 = ((p00 >> (8 * c)) & 255u) * a0 + ((p01 >> (8 * c)) & 255u) * a1;
+            const uint32_t t1 = ((p10 >> (8 * c)) & 255u) * a0 + ((p11 >> (8 * c)) & 255u) * a1;
+            const uint32_t v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2u) >> 2;
+            r |= min(v, 255u) << (8 * c);
+        }
+        px[j] = r;
+    }
+    const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
+    if ((W & 3) == 0 && x0 + 3 < W) {
+        uint3 d;
+        d.x = px[0] | (px[1] << 24);
+        d.y = (px[1] >> 8) | (px[2] << 16);
+        d.z = (px[2] >> 16) | (px[3] << 8);
+        *reinterpret_cast<uint3*>(dst + o) = d;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x0 + j < W) {
+                dst[o + 3 * j + 0] = (uint8_t)(px[j]);
+                dst[o + 3 * j + 1] = (uint8_t)(px[j] >> 8);
+                dst[o + 3 * j + 2] = (uint8_t)(px[j] >> 16);
+            }
+    }
+}
+
+size_t crop_resize_workspace_bytes(int W, int H) { return (size_t)(W + H) * sizeof(ResizeTab); }
+
+int launch_crop_resize(const uint8_t* frames, uint8_t* out, int n, int W, int H, int left, int top, int right, int bottom,
+                       void* work, hipStream_t st)
+{
+    if (n <= 0 || n > 65535 || W < 1 || H < 1 || W > 32767 || H > 32767) {
+        set_error("mf_crop_resize_u8c3: unsupported shape n=%d W=%d H=%d", n, W, H);
+        return MF_ERR_INVALID_ARG;
+    }
+    if (left < 0 || top < 0 || right >= W || bottom >= H || right < left || bottom < top) {
+        set_error("mf_crop_resize_u8c3: empty or out-of-frame crop rectangle (%d, %d, %d, %d) for %dx%d (cv2.resize would "
+                  "fail on an empty source)", left, top, right, bottom, W, H);
+        return MF_ERR_INVALID_ARG;
+    }
+    const int cw = right - left + 1, ch = bottom - top + 1;
+    const double scale_x = 1.0 / ((double)W / (double)cw), scale_y = 1.0 / ((double)H / (double)ch);
+    ResizeTab* xtab = (ResizeTab*)work;
+    ResizeTab* ytab = xtab + W;
+    const int m = W > H ? W : H;
+    hipLaunchKernelGGL(resize_tables_kernel, dim3((m + 255) / 256), dim3(256), 0, st, cw, ch, W, H, scale_x, scale_y, xtab, ytab);
+    int rc = hip_fail(hipGetLastError(), "resize_tables_kernel launch");
+    if (rc != MF_OK) return rc;
+    const dim3 grid((W + 255) / 256, (H + 3) / 4, n);
+    hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, st, frames, out, n, W, H, left, top, cw, xtab, ytab);
+    return hip_fail(hipGetLastError(), "resize_kernel launch");
+}
+
+}  // namespace mf

@@ -109,3 +109,18 @@ def crop_reduce(crop, W, H):
     bounds = torch.empty(4, dtype=torch.int32, device=crop.device)
     _lib.check(_lib_.mf_crop_reduce(_ptr(crop), crop.shape[0], W, H, _ptr(bounds), _stream()))
     return bounds
+
+
+def crop_resize(frames, bounds, out=None):
+    """Crop to the inclusive (left, top, right, bottom) and resize back to (W, H): mfs.py:1111-1157."""
+    _need(frames, torch.uint8, 'frames')
+    n, H, W, ch = frames.shape
+    if ch != 3:
+        raise ValueError('frames must be (n, H, W, 3)')
+    left, top, right, bottom = (int(v) for v in bounds)
+    if out is None:
+        out = torch.empty_like(frames)
+    _need(out, torch.uint8, 'out')
+    work = torch.empty(_lib_.mf_crop_resize_workspace_bytes(W, H), dtype=torch.uint8, device=frames.device)
+    _lib.check(_lib_.mf_crop_resize_u8c3(_ptr(frames), _ptr(out), n, W, H, left, top, right, bottom, _ptr(work), _stream()))
+    return out

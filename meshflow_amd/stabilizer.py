@@ -82,10 +82,11 @@ class MeshFlowStabilizer:
             'build; feed stabilize_clip() from your own decoder/tracker')
 
     def stabilize_clip(self, unstabilized_frames, vertex_unstabilized_displacements_by_frame_index, homographies,
-                       adaptive_weights_definition=ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL):
-        """The hot path of `stabilize` (mfs.py:150-158, 162) on in-memory inputs.
+                       adaptive_weights_definition=ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL, crop=False):
+        """The hot path of `stabilize` (mfs.py:150-159, 162) on in-memory inputs.
 
-        Returns (stabilized_frames list, crop_boundaries, vertex_stabilized_displacements, stability_score)."""
+        Returns (stabilized_frames list, crop_boundaries, vertex_stabilized_displacements, stability_score)
+        and, with crop=True, a fifth item: the cropped + resized frames (`_crop_frames`, mfs.py:159)."""
         self._check_definition(adaptive_weights_definition)
         num_frames = len(unstabilized_frames)
         stab = self._get_stabilized_vertex_displacements(
@@ -93,7 +94,10 @@ class MeshFlowStabilizer:
             vertex_unstabilized_displacements_by_frame_index, homographies)
         frames, bounds = self._get_stabilized_frames_and_crop_boundaries(
             num_frames, unstabilized_frames, vertex_unstabilized_displacements_by_frame_index, stab)
-        return frames, bounds, stab, self._compute_stability_score(num_frames, stab)
+        score = self._compute_stability_score(num_frames, stab)
+        if crop:
+            return frames, bounds, stab, score, self._crop_frames(frames, bounds)
+        return frames, bounds, stab, score
 
     # ------------------------------------------------------------------------------------------
     # drop-in boundary, host buffers (same signatures as the reference)
@@ -142,6 +146,18 @@ class MeshFlowStabilizer:
         left, top = crop[:, 0].max(), crop[:, 1].max()                                      # mfs.py:1103-1106
         right, bottom = crop[:, 2].min(), crop[:, 3].min()
         return list(out), (np.int64(left), np.int64(top), np.int64(right), np.int64(bottom))
+
+    def _crop_frames(self, uncropped_frames, crop_boundaries):
+        """mfs.py:1111-1157: crop to the inclusive bounds and resize back to (W, H) (cv2.resize, INTER_LINEAR)."""
+        import torch
+        from . import ops
+        dev = self._torch_device()
+        if isinstance(uncropped_frames, np.ndarray):
+            stack = np.ascontiguousarray(uncropped_frames, dtype=np.uint8)
+        else:
+            stack = np.stack([np.asarray(f, dtype=np.uint8) for f in uncropped_frames])
+        out = ops.crop_resize(torch.from_numpy(stack).to(dev), crop_boundaries)
+        return list(out.cpu().numpy())
 
     def _compute_stability_score(self, num_frames, vertex_stabilized_displacements_by_frame_index):
         """mfs.py:1216-1259."""

@@ -525,3 +525,61 @@ def stabilized_frames_and_crop_boundaries(frames, mesh_rows, mesh_cols, unstab_d
     pf = np.asarray(per_frame, dtype=np.int64).reshape(-1, 4)
     bounds = (int(pf[:, 0].max()), int(pf[:, 1].max()), int(pf[:, 2].min()), int(pf[:, 3].min()))  # mfs.py:1103-1106
     return outs, bounds, pf
+
+
+# ------------------------------------------------------------------------------------------------
+# Next row: crop + resize  (mfs.py:1111-1157)
+# ------------------------------------------------------------------------------------------------
+
+def resize_linear_tables(src_len, dst_len):
+    """Per-output-index source offset and 11-bit fixed-point weights of cv2.resize INTER_LINEAR for 8-bit
+    images (imgproc/resize.cpp, cv::hal::resize): scale = 1/((double)dst/src); f = float((d+0.5)*scale-0.5);
+    s = floor(f); f -= s; s < 0 -> (s, f) = (0, 0); s >= src-1 -> (src-1, 0) [x axis only; the y axis clips
+    its two row indices instead]; weights = cvRound(float(1-f)*2048), cvRound(f*2048) as int16."""
+    inv_scale = float(dst_len) / float(src_len)
+    scale = 1.0 / inv_scale
+    d = np.arange(dst_len, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    return s, f
+
+
+def _coef(f):
+    w0 = np.rint((np.float32(1.0) - f) * np.float32(2048)).astype(np.int64)
+    w1 = np.rint(f * np.float32(2048)).astype(np.int64)
+    return w0, w1
+
+
+def resize_linear_u8(src, dst_w, dst_h):
+    """cv2.resize(src uint8 HxWxC, (dst_w, dst_h)) with the default INTER_LINEAR (mfs.py:1150-1155; the fx/fy
+    arguments are ignored because dsize is given).  Two-pass fixed point exactly as resize.cpp:
+    horizontal t = S[sx]*a0 + S[sx+1]*a1 (int32, scale 2^11); vertical
+    out = (((b0*(t0 >> 4)) >> 16) + ((b1*(t1 >> 4)) >> 16) + 2) >> 2."""
+    src = np.asarray(src, dtype=np.uint8)
+    sh, sw = src.shape[:2]
+    if sh == 0 or sw == 0:
+        raise ValueError('cv2.resize: empty source (the crop rectangle is empty)')
+    sx, fx = resize_linear_tables(sw, dst_w)
+    low = sx < 0
+    sx = np.where(low, 0, sx); fx = np.where(low, np.float32(0), fx)
+    high = sx >= sw - 1
+    sx = np.where(high, sw - 1, sx); fx = np.where(high, np.float32(0), fx)
+    a0, a1 = _coef(fx.astype(np.float32))
+    sy, fy = resize_linear_tables(sh, dst_h)
+    b0, b1 = _coef(fy)
+    sy0 = np.clip(sy, 0, sh - 1)
+    sy1 = np.clip(sy + 1, 0, sh - 1)
+    sx1 = np.minimum(sx + 1, sw - 1)                 # where sx = sw-1 the second weight is 0
+    S = src.astype(np.int64)
+    t0 = S[sy0][:, sx] * a0[None, :, None] + S[sy0][:, sx1] * a1[None, :, None]
+    t1 = S[sy1][:, sx] * a0[None, :, None] + S[sy1][:, sx1] * a1[None, :, None]
+    out = (((b0[:, None, None] * (t0 >> 4)) >> 16) + ((b1[:, None, None] * (t1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def crop_frames(uncropped_frames, crop_boundaries):
+    """mfs.py:1111-1157: crop every frame to the inclusive bounds and resize back to (W, H)."""
+    frame_height, frame_width = uncropped_frames[0].shape[:2]
+    left, top, right, bottom = (int(v) for v in crop_boundaries)
+    return [resize_linear_u8(f[top:bottom + 1, left:right + 1], frame_width, frame_height) for f in uncropped_frames]

@@ -258,3 +258,32 @@ def test_warp_host_wrapper(dev):
     want, want_crop, _ = clib.warp_clip(frames, R, C, disp, stab)
     np.testing.assert_array_equal(out, want)
     np.testing.assert_array_equal(crop, want_crop)
+
+
+# ---------------------------------------------------------------------------------------------- crop + resize
+
+@pytest.mark.parametrize('H,W,bounds', [
+    (48, 64, (5, 3, 60, 44)), (48, 64, (0, 0, 63, 47)), (75, 101, (7, 9, 90, 70)), (40, 60, (10, 10, 10, 10)),
+    (360, 640, (13, 11, 629, 350)), (33, 31, (1, 2, 29, 30)),
+])
+def test_crop_resize_bit_exact_vs_oracle(dev, H, W, bounds):
+    from meshflow_amd import ops, synthetic
+    from oracle import meshflow_oracle as mo
+    frames = synthetic.frames_numpy(3, H, W, seed=H, kind='noise')
+    got = ops.crop_resize(torch.from_numpy(frames).to(dev), bounds).cpu().numpy()
+    want = np.stack(mo.crop_frames(list(frames), bounds))
+    np.testing.assert_array_equal(got, want)
+
+
+def test_crop_resize_1080p_and_errors(dev):
+    from meshflow_amd import ops, synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    from oracle import meshflow_oracle as mo
+    frames = synthetic.frames_numpy(2, 1080, 1920, seed=5, kind='noise')
+    bounds = (13, 11, 1909, 1068)
+    got = MeshFlowStabilizer()._crop_frames(list(frames), bounds)
+    want = mo.crop_frames(list(frames), bounds)
+    assert isinstance(got, list) and len(got) == 2
+    np.testing.assert_array_equal(np.stack(got), np.stack(want))
+    with pytest.raises(ValueError):
+        ops.crop_resize(torch.from_numpy(frames[:1]).to(dev), (50, 10, 40, 100))       # right < left: empty crop
