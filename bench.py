@@ -5,7 +5,9 @@
 
 A "step" is one pass of the hot path over one synthetic clip whose inputs (frames, vertex
 displacements) are already resident in HBM: Jacobi coefficient setup (host, O(F)) -> Jacobi sweep ->
-per-cell homography table -> mesh warp + crop scan -> clip-level crop bounds.  N = 1 runs
+per-cell homography table -> mesh warp + crop scan -> clip-level crop bounds.  Steps are issued back to back
+(the host prepares clip i+1 while the GPU works on clip i); the degenerate-mesh counter of all steps is read
+once, before the closing barrier.  N = 1 runs
 BASELINE.json configs[1] (1080p, 300 frames, 16x16 mesh, 100 Jacobi sweeps, ORIGINAL weights).
 N > 1 (launched by torch.distributed.run, one rank per GPU) shards ONE clip of 300*N frames by contiguous
 frame range: Jacobi replicated, each rank warps its own 300 frames, one 16-byte all-reduce of the crop
@@ -104,15 +106,14 @@ def main():
         d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
         if i is not None:
             jev[i][1].record()
-        ops.cell_table(d_disp[lo:hi], d_stab[lo:hi], W, H, R, C, table=table)
+        ops.cell_table(d_disp[lo:hi], d_stab[lo:hi], W, H, R, C, table=table, reset_status=False)
         if i is not None:
             ev[i][0].record()
         ops.warp(d_frames, table, stab.color_outside_image_area_bgr, out=d_out)
         if i is not None:
             ev[i][1].record()
         bounds = mfdist.allreduce_crop(ops.crop_reduce(table.crop, W, H))
-        table.check()                      # degenerate-mesh check: one 4-byte D2H, synchronises the step
-        return d_stab, bounds
+        return d_stab, bounds              # degenerate-mesh counter accumulates in table.status (checked below)
 
     def barrier():
         if world > 1:
@@ -125,6 +126,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         d_stab, bounds = step(i)
+    table.check()                          # degenerate-mesh check of all K steps: one 4-byte D2H, inside the timing
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

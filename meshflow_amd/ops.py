@@ -69,7 +69,7 @@ class CellTable:
                              '(cv2.findHomography would return None)')
 
 
-def cell_table(unstab, stab, W, H, R, C, table=None):
+def cell_table(unstab, stab, W, H, R, C, table=None, reset_status=True):
     """Per-cell homographies of n frames (mfs.py:1039-1048).  unstab/stab: (n, R+1, C+1, 2) or (n, V*2)
     float64 device tensors.  Also resets the per-frame crop values to their defaults (mfs.py:992-995)."""
     _need(unstab, torch.float64, 'unstab')
@@ -80,8 +80,8 @@ def cell_table(unstab, stab, W, H, R, C, table=None):
         raise ValueError('displacement tensors do not match (n, R+1, C+1, 2)')
     if table is None:
         table = CellTable(n, W, H, R, C, unstab.device)
-    else:
-        table.status.zero_()
+    elif reset_status:
+        table.status.zero_()          # reset_status=False: keep accumulating; the caller checks once later
     _lib.check(_lib_.mf_cell_table_f64(_ptr(unstab), _ptr(stab), n, W, H, R, C, _ptr(table.buf), _ptr(table.crop),
                                        _ptr(table.status), _stream()))
     return table

@@ -1,0 +1,66 @@
+// Which part of the warp kernel's memory pattern is slow?  Same tiling as warp_kernel (128x16 tiles, lane = 4 px).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+template <int MODE>
+__global__ __launch_bounds__(256) void k(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int W, int H)
+{
+    const int f = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * 128 + wave * 32 + (lane & 7) * 4;
+    const uint8_t* src = in + (size_t)f * W * H * 3;
+    uint8_t* dst = out + (size_t)f * W * H * 3;
+    for (int q = 0; q < 2; ++q) {
+        const int y = blockIdx.y * 16 + q * 8 + (lane >> 3);
+        if (y >= H - 1 || x0 + 6 >= W) continue;
+        uint32_t acc[4] = {0, 0, 0, 0};
+        if (MODE == 0 || MODE == 1) {           // two unaligned 8-byte loads per pixel
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t o = ((uint32_t)y * W + x0 + j) * 3u;
+                uint2 a, b; __builtin_memcpy(&a, src + o, 8); __builtin_memcpy(&b, src + o + 3u * W, 8);
+                acc[j] = (a.x ^ a.y ^ b.x ^ b.y) & 0xFFFFFFu;
+            }
+        } else if (MODE == 2) {                 // one aligned 16-byte load per row (covers the 4 px + 1): 2 loads per lane
+            const uint32_t o = ((uint32_t)y * W + x0) * 3u;       // 12-byte aligned -> 4-byte aligned
+            uint4 a, b; __builtin_memcpy(&a, src + o, 16); __builtin_memcpy(&b, src + o + 3u * W, 16);
+            acc[0] = a.x ^ b.x; acc[1] = a.y ^ b.y; acc[2] = a.z ^ b.z; acc[3] = (a.w ^ b.w) & 0xFFFFFF;
+        } else if (MODE == 3) {                 // no loads
+            acc[0] = x0; acc[1] = y; acc[2] = f; acc[3] = lane;
+        } else if (MODE == 4) {                 // four unaligned 4-byte loads per pixel
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t o = ((uint32_t)y * W + x0 + j) * 3u;
+                uint32_t a, b, c, d; __builtin_memcpy(&a, src + o, 4); __builtin_memcpy(&b, src + o + 3, 4);
+                __builtin_memcpy(&c, src + o + 3u * W, 4); __builtin_memcpy(&d, src + o + 3u * W + 3, 4);
+                acc[j] = (a ^ b ^ c ^ d) & 0xFFFFFFu;
+            }
+        }
+        if (MODE == 1) {                        // loads only: store one byte per wave-row rarely
+            if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) dst[0] = 1;
+        } else {
+            uint3 d; d.x = acc[0] | (acc[1] << 24); d.y = (acc[1] >> 8) | (acc[2] << 16); d.z = (acc[2] >> 16) | (acc[3] << 8);
+            *reinterpret_cast<uint3*>(dst + ((size_t)y * W + x0) * 3) = d;
+        }
+    }
+}
+template <int MODE> void run(const char* name, const uint8_t* in, uint8_t* out)
+{
+    const int W = 1920, H = 1080, n = 300;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<dim3(15, 68, n), 256>>>(in, out, W, H);
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) k<MODE><<<dim3(15, 68, n), 256>>>(in, out, W, H);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-48s %.3f ms\n", name, ms / 5);
+}
+int main()
+{
+    const size_t N = (size_t)1920 * 1080 * 3 * 300;
+    uint8_t *in, *out; hipMalloc(&in, N + 64); hipMalloc(&out, N + 64);
+    hipMemset(in, 0x5A, N + 64); hipMemset(out, 0, N + 64);
+    run<0>("2x unaligned 8B loads/px + 12B store", in, out);
+    run<1>("2x unaligned 8B loads/px, no store", in, out);
+    run<2>("2x 16B loads per 4 px + 12B store", in, out);
+    run<3>("no loads, 12B store", in, out);
+    run<4>("4x unaligned 4B loads/px + 12B store", in, out);
+    return 0;
+}
