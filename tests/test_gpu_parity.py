@@ -156,6 +156,36 @@ def test_warp_bit_exact_vs_c_oracle(dev, H, W, R, C, kw):
         np.testing.assert_array_equal(crop[f], want_crop)
 
 
+@pytest.mark.parametrize('H,W,R,C,sigma,seed', [
+    (130, 260, 4, 4, 8.0, 1),       # strongly non-affine quads: generic division path, wide reach
+    (130, 260, 4, 4, 20.0, 2),      # folded quads: projective denominators change sign inside the frame
+    (64, 96, 8, 8, 6.0, 3),         # more than 8 candidate cells per footprint: range-scan path
+    (200, 300, 64, 64, 0.4, 4),     # largest supported mesh
+    (17, 23, 2, 3, 1.0, 5),         # frame smaller than one tile
+])
+def test_warp_stress_geometries_bit_exact(dev, H, W, R, C, sigma, seed):
+    """iid vertex jitter far beyond what a smoothed path produces: exercises the rare paths (irregular cells,
+    overflowing candidate plans, generic division, border handling).  Degenerate cells are tolerated only
+    if the oracle reports them too."""
+    from meshflow_amd import synthetic
+    from oracle import clib
+    frames = synthetic.frames_numpy(2, H, W, seed=seed, kind='noise')
+    n = np.arange(2 * (R + 1) * (C + 1) * 2, dtype=np.int64).reshape(2, R + 1, C + 1, 2)
+    unstab = np.zeros((2, R + 1, C + 1, 2))
+    stab = sigma * synthetic.normal(n, seed=100 + seed)
+    want, want_crop, bad = clib.warp_clip(frames, R, C, unstab, stab)
+    if bad:
+        with pytest.raises(ValueError, match='degenerate'):
+            _hip_warp(dev, frames, R, C, unstab, stab)
+        return
+    out, crop, rec = _hip_warp(dev, frames, R, C, unstab, stab)
+    for f in range(2):
+        table, _ = clib.cell_table(W, H, R, C, unstab[f], stab[f])
+        np.testing.assert_array_equal(rec[f], table)
+    assert np.array_equal(out, want), f'{(out != want).sum()} bytes differ'
+    np.testing.assert_array_equal(crop, want_crop)
+
+
 def test_warp_matches_numpy_oracle_painter_loop(dev):
     """Against the reference-shaped per-cell painter loop (oracle/meshflow_oracle.py), small frame."""
     from oracle import meshflow_oracle as mo
