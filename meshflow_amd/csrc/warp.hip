@@ -19,25 +19,25 @@
 // 128-byte boundary of the 3-byte-per-pixel output when W % 128 == 0: 1080p, 4K).  Each wavefront owns a
 // 32-pixel-wide column of the tile and walks it in 32 x 8 "footprints"; a lane owns 4 consecutive pixels
 // of one row (12 contiguous output bytes -> one global_store_dwordx3).  Per footprint:
-//   1. Candidate cells: the cells whose grid rect, widened by the frame's "reach" (how far any cell's
-//      conservative box extends beyond its grid rect, from the cell-table kernel), meets the footprint --
-//      a small r x c index range found with two __ballot's over the vertex coordinates held in LDS.
-//   2. Classification, 4 candidates per pass: lane = (candidate, edge, corner) evaluates one float32 edge
-//      function of the cell's mask quad at one footprint corner; two __ballot's tell, per candidate,
-//      OUT (some edge excludes all four corners: skip), IN (every edge admits all four corners: every
-//      pixel passes, no per-pixel test) or MIXED.  The functions are affine, so corners bound the
-//      footprint; a one-unit (1/32 px) margin dwarfs their float32 error.
-//   3. Candidates are visited in DESCENDING cell order (last painter wins).  The cell index is
-//      wave-uniform, so its record (M, rect, Hi) comes in through scalar loads into SGPRs -- nothing
-//      per-cell is held per lane or in LDS.  MIXED cells run the mask test per pixel: a division-free
-//      float64 comparison that decides whenever the pixel is not within 1e-6 of the mask edge, else
-//      OpenCV's exact arithmetic (division, rint).  Owned pixels get their coordinates at once; the loop
-//      ends when every pixel of the footprint is owned.
-//   4. Source taps: two unaligned 8-byte loads per pixel (two horizontally adjacent BGR pixels per row),
-//      served by L1/L2 -- neighbouring lanes touch neighbouring bytes because the motion is a few
-//      pixels; border / frame-edge pixels take a per-tap path.
+//   1. The candidate cells come from the footprint PLAN written by footprint_plan_kernel (cell_table.hip):
+//      up to 8 cells in descending order, each IN (all 256 pixels pass its mask test) or MIXED, cells that
+//      cannot own a pixel already dropped.  The plan is wave-uniform: one scalar load.
+//   2. One IN cell (the common case, ~65 % of footprints at config-2 geometry): no per-pixel test; the
+//      cell's Hi comes in through scalar loads and the four coordinates are straight-line float64 code with
+//      an IEEE-exact reciprocal trimmed for 0.5 <= |w| < 2.
+//   3. Several cells: their Hi go to LDS; ownership is resolved last cell first with a float32 evaluation
+//      of the cell's four affine edge functions, which decides unless the pixel is within 1/64 px of the
+//      mask edge -- then a division-free float64 comparison, and OpenCV's exact arithmetic (division, rint)
+//      only within 1e-6 of the edge; every pixel then computes its coordinates once with its owner's Hi
+//      read from LDS.  More than 8 candidates: every cell of the recorded index range is tested.
+//   4. cv2.remap: sx = rint(32u) via one fma against 1.5*2^23; if every tap of the wave lies at least two
+//      pixels inside the frame (one max-reduction per lane, one ballot) two unaligned 8-byte loads per
+//      pixel fetch the 2x2 taps, the horizontal lerps are v_dot4_u32_u8, the vertical lerp two chained
+//      v_mad_u32_u24 scaled so that the rounded byte lands in byte 2, v_perm_b32 packs B,G,R; otherwise a
+//      per-tap path handles frame borders, uncovered pixels and the crop flags.
 // Algorithmic HBM traffic: 2*H*W*3 bytes per frame (each source byte read once, each output byte written
-// once); the cell table adds R*C*312 bytes per frame (< 1.5 %).  No dense contraction: no MFMA.
+// once); cell table + plan add < 2 %.  No dense contraction: no MFMA.  The kernel is VALU-issue bound (exact
+// float64 coordinates), not HBM bound: DESIGN.md section 4.3, profiles/.
 #include "mf_common.h"
 
 namespace mf {
