@@ -24,3 +24,6 @@ def t(fn, n=10):
 print('cell_table+plan ms', t(lambda: ops.cell_table(d_disp, d_stab, W, H, R, C, table=table)))
 print('warp ms', t(lambda: ops.warp(frames, table, out=out)))
 print('jacobi ms (incl host coeffs)', t(lambda: s._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)))
+bounds = (13, 11, 1909, 1068)
+out2 = torch.empty_like(frames)
+print('crop_resize ms', t(lambda: ops.crop_resize(out, bounds, out=out2)))
