@@ -82,22 +82,50 @@ class MeshFlowStabilizer:
             'build; feed stabilize_clip() from your own decoder/tracker')
 
     def stabilize_clip(self, unstabilized_frames, vertex_unstabilized_displacements_by_frame_index, homographies,
-                       adaptive_weights_definition=ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL, crop=False):
-        """The hot path of `stabilize` (mfs.py:150-159, 162) on in-memory inputs.
+                       adaptive_weights_definition=ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL, crop=False,
+                       keep_uncropped=True):
+        """The hot path of `stabilize` (mfs.py:150-159, 162) on in-memory inputs, with ONE host->device and ONE
+        device->host pass over the frames (the two private methods below each pay their own, like any drop-in
+        for NumPy-in / NumPy-out methods must).
 
         Returns (stabilized_frames list, crop_boundaries, vertex_stabilized_displacements, stability_score)
-        and, with crop=True, a fifth item: the cropped + resized frames (`_crop_frames`, mfs.py:159)."""
+        and, with crop=True, a fifth item: the cropped + resized frames (`_crop_frames`, mfs.py:159), produced
+        on the device from the stabilized frames; keep_uncropped=False then skips copying the uncropped
+        stabilized frames back (the reference only uses the cropped ones afterwards) and returns None for them."""
+        import torch
+        from . import ops
         self._check_definition(adaptive_weights_definition)
         num_frames = len(unstabilized_frames)
-        stab = self._get_stabilized_vertex_displacements(
-            num_frames, unstabilized_frames, adaptive_weights_definition,
-            vertex_unstabilized_displacements_by_frame_index, homographies)
-        frames, bounds = self._get_stabilized_frames_and_crop_boundaries(
-            num_frames, unstabilized_frames, vertex_unstabilized_displacements_by_frame_index, stab)
+        dev = self._torch_device()
+        unstab = np.ascontiguousarray(vertex_unstabilized_displacements_by_frame_index, dtype=np.float64)
+        self._check_mesh_shape(unstab, num_frames)
+        stack = self._as_frame_stack(unstabilized_frames, num_frames)
+        frame_height, frame_width = stack.shape[1:3]
+        d_unstab = torch.from_numpy(unstab).to(dev)
+        d_stab = self._stabilized_vertex_displacements_device(d_unstab, frame_width, frame_height,
+                                                              adaptive_weights_definition, homographies)
+        d_frames = torch.from_numpy(stack).to(dev)
+        d_out, d_crop = self._stabilized_frames_device(d_frames, d_unstab, d_stab)
+        crop_h = d_crop.cpu().numpy()
+        bounds = (np.int64(crop_h[:, 0].max()), np.int64(crop_h[:, 1].max()),
+                  np.int64(crop_h[:, 2].min()), np.int64(crop_h[:, 3].min()))                 # mfs.py:1103-1106
+        stab = d_stab.cpu().numpy()
         score = self._compute_stability_score(num_frames, stab)
-        if crop:
-            return frames, bounds, stab, score, self._crop_frames(frames, bounds)
-        return frames, bounds, stab, score
+        if not crop:
+            return list(d_out.cpu().numpy()), bounds, stab, score
+        d_cropped = ops.crop_resize(d_out, bounds, out=d_frames)        # the input stack is no longer needed
+        frames = list(d_out.cpu().numpy()) if keep_uncropped else None
+        return frames, bounds, stab, score, list(d_cropped.cpu().numpy())
+
+    @staticmethod
+    def _as_frame_stack(frames, num_frames):
+        if isinstance(frames, np.ndarray):
+            stack = np.ascontiguousarray(frames, dtype=np.uint8)
+        else:
+            stack = np.stack([np.asarray(f, dtype=np.uint8) for f in frames])
+        if stack.ndim != 4 or stack.shape[0] != num_frames or stack.shape[3] != 3:
+            raise ValueError('frames must be num_frames arrays of shape (H, W, 3)')
+        return stack
 
     # ------------------------------------------------------------------------------------------
     # drop-in boundary, host buffers (same signatures as the reference)

@@ -271,6 +271,15 @@ def test_stabilizer_class_end_to_end(dev):
     np.testing.assert_array_equal(np.stack(out_frames), want)
     assert tuple(int(v) for v in bounds) == (want_crop[:, 0].max(), want_crop[:, 1].max(),
                                              want_crop[:, 2].min(), want_crop[:, 3].min())
+    # the two private methods with the reference's own signatures give the same arrays
+    np.testing.assert_array_equal(s._get_stabilized_vertex_displacements(F, list(frames), 0, disp, hom), stab)
+    fr2, b2 = s._get_stabilized_frames_and_crop_boundaries(F, list(frames), disp, stab)
+    np.testing.assert_array_equal(np.stack(fr2), want)
+    assert tuple(int(v) for v in b2) == tuple(int(v) for v in bounds)
+    # crop=True: device-resident crop + resize of the stabilized frames
+    res = s.stabilize_clip(list(frames), disp, hom, crop=True, keep_uncropped=False)
+    assert res[0] is None and len(res) == 5
+    np.testing.assert_array_equal(np.stack(res[4]), np.stack(mo.crop_frames(list(want), bounds)))
 
 
 def test_warp_host_wrapper(dev):
