@@ -299,8 +299,15 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     const int ya = fy * MF_FOOT_H, yb = min(ya + MF_FOOT_H - 1, H - 1);
     const int rxlo = reach[4 * f + 0], rylo = reach[4 * f + 1], rxhi = reach[4 * f + 2], ryhi = reach[4 * f + 3];
     // cells whose grid rect, widened by the frame's reach, meets the footprint (contiguous index ranges)
-    int c_lo = 0, c_hi = C - 1, r_lo = 0, r_hi = R - 1;
-    while (c_lo < C - 1 && s_gx[c_lo + 1] < xa - rxhi) ++c_lo;
+    // (start from the uniform-grid estimate, then walk the exact vertex coordinates: a step or two)
+    const float cs = (float)C / (float)(W - 1), rs = (float)R / (float)(H - 1);
+    int c_lo = min(max((int)((float)(xa - rxhi) * cs) - 1, 0), C - 1), c_hi = min(max((int)((float)(xb + rxlo) * cs) + 1, 0), C - 1);
+    int r_lo = min(max((int)((float)(ya - ryhi) * rs) - 1, 0), R - 1), r_hi = min(max((int)((float)(yb + rylo) * rs) + 1, 0), R - 1);
+    while (c_lo > 0 && s_gx[c_lo] >= xa - rxhi) --c_lo;                       // make sure the estimate is not too tight
+    while (c_hi < C - 1 && s_gx[c_hi + 1] <= xb + rxlo) ++c_hi;
+    while (r_lo > 0 && s_gy[r_lo] >= ya - ryhi) --r_lo;
+    while (r_hi < R - 1 && s_gy[r_hi + 1] <= yb + rylo) ++r_hi;
+    while (c_lo < C - 1 && s_gx[c_lo + 1] < xa - rxhi) ++c_lo;                // then tighten exactly as before
     while (c_hi > 0 && s_gx[c_hi] > xb + rxlo) --c_hi;
     while (r_lo < R - 1 && s_gy[r_lo + 1] < ya - ryhi) ++r_lo;
     while (r_hi > 0 && s_gy[r_hi] > yb + rylo) --r_hi;
@@ -316,14 +323,14 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
             const float* __restrict__ ed = fedge + (size_t)k * MF_EDGE_FLOATS;
             bool all_in = true, any_out = false;
             for (int e = 0; e < 4; ++e) {
-                bool e_in = true, e_out = true;
-                for (int q = 0; q < 4; ++q) {
-                    const float g = ed[3 * e] * cxs[q & 1] + ed[3 * e + 1] * cys[q >> 1] + ed[3 * e + 2];
-                    e_in = e_in && g > 1.0f;
-                    e_out = e_out && g < -1.0f;
-                }
-                all_in = all_in && e_in;
-                any_out = any_out || e_out;
+                // extrema of the affine function a x + b y + c over the footprint rectangle sit on its corners:
+                // min = c + min(a xa, a xb) + min(b ya, b yb), max likewise (NaN coefficients fail both tests)
+                const float ax0 = ed[3 * e] * cxs[0], ax1 = ed[3 * e] * cxs[1];
+                const float by0 = ed[3 * e + 1] * cys[0], by1 = ed[3 * e + 1] * cys[1];
+                const float gmin = (fminf(ax0, ax1) + fminf(by0, by1)) + ed[3 * e + 2];
+                const float gmax = (fmaxf(ax0, ax1) + fmaxf(by0, by1)) + ed[3 * e + 2];
+                all_in = all_in && gmin > 1.0f;
+                any_out = any_out || gmax < -1.0f;
             }
             if (any_out) continue;
             if (cnt == 8) { overflow = true; break; }
