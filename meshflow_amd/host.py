@@ -88,3 +88,37 @@ def shard_range(num_frames, world_size, rank):
     lo = min(rank * per, num_frames)
     hi = min(lo + per, num_frames)
     return lo, hi
+
+
+def mesh_cropping_ratio_and_distortion(frame_width, frame_height, mesh_rows, mesh_cols, unstab_disp, stab_disp,
+                                       crop_boundaries):
+    """(cropping_ratio, distortion_score) from the mesh itself -- a DEVIATION from mfs.py:1160-1212, not parity-pinned.
+
+    The reference estimates, for every frame, a homography between the unstabilized and the cropped frame from
+    FAST/LK feature matches (mfs.py:1195) and takes 1/(H00*H11) (mean over frames, mfs.py:1203, 1212) and the ratio
+    of the two largest eigenvalue magnitudes of its affine part (MIN over frames, mfs.py:1206-1212).  The feature
+    tracker is outside this build; here the same two formulas are applied to the least-squares homography through
+    the (R+1)(C+1) exactly known vertex correspondences: unstabilized grid vertex -> its stabilized position ->
+    crop + resize (pixel centres: x_c = (x_s - left + 0.5) * W/cw - 0.5)."""
+    left, top, right, bottom = (float(v) for v in crop_boundaries)
+    cw, ch = right - left + 1.0, bottom - top + 1.0
+    grid = vertex_x_y(frame_width, frame_height, mesh_rows, mesh_cols).reshape(-1, 2).astype(np.float64)
+    motion = (np.asarray(stab_disp, dtype=np.float64) - np.asarray(unstab_disp, dtype=np.float64)).reshape(len(stab_disp), -1, 2)
+    ratios = np.empty(len(motion), dtype=np.float32)
+    distortions = np.empty(len(motion), dtype=np.float32)
+    X, Y = grid[:, 0], grid[:, 1]
+    for f in range(len(motion)):
+        ps = grid + motion[f]
+        x = (ps[:, 0] - left + 0.5) * (frame_width / cw) - 0.5
+        y = (ps[:, 1] - top + 0.5) * (frame_height / ch) - 0.5
+        zeros, ones = np.zeros_like(X), np.ones_like(X)
+        A = np.concatenate([np.stack([X, Y, ones, zeros, zeros, zeros, -x * X, -x * Y], axis=1),
+                            np.stack([zeros, zeros, zeros, X, Y, ones, -y * X, -y * Y], axis=1)])
+        h, *_ = np.linalg.lstsq(A, np.concatenate([x, y]), rcond=None)
+        Hm = np.append(h, 1.0).reshape(3, 3)
+        ratios[f] = 1 / (Hm[0][0] * Hm[1][1])                                             # mfs.py:1203
+        affine = Hm.copy()
+        affine[2] = [0, 0, 1]                                                            # mfs.py:1207
+        mags = np.sort(np.abs(np.linalg.eigvals(affine)))
+        distortions[f] = mags[-2] / mags[-1]                                              # mfs.py:1209
+    return np.mean(ratios), np.min(distortions)                                           # mfs.py:1212

@@ -187,6 +187,18 @@ class MeshFlowStabilizer:
         out = ops.crop_resize(torch.from_numpy(stack).to(dev), crop_boundaries)
         return list(out.cpu().numpy())
 
+    def compute_scores(self, frame_width, frame_height, vertex_unstabilized_displacements_by_frame_index,
+                       vertex_stabilized_displacements_by_frame_index, crop_boundaries):
+        """(cropping_ratio, distortion_score, stability_score) in the order `stabilize` returns them (mfs.py:169).
+        stability_score is the reference's own formula (mfs.py:1216-1259); the other two are computed from the
+        mesh correspondences instead of tracked features -- see host.mesh_cropping_ratio_and_distortion."""
+        ratio, distortion = host.mesh_cropping_ratio_and_distortion(
+            frame_width, frame_height, self.mesh_row_count, self.mesh_col_count,
+            vertex_unstabilized_displacements_by_frame_index, vertex_stabilized_displacements_by_frame_index,
+            crop_boundaries)
+        stab = np.asarray(vertex_stabilized_displacements_by_frame_index)
+        return ratio, distortion, self._compute_stability_score(stab.shape[0], stab)
+
     def _compute_stability_score(self, num_frames, vertex_stabilized_displacements_by_frame_index):
         """mfs.py:1216-1259."""
         return host.stability_score(np.asarray(vertex_stabilized_displacements_by_frame_index))

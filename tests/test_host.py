@@ -119,3 +119,21 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(root, fn)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), fn
                 assert 'liboracle' not in src, fn
+
+
+def test_mesh_metrics_known_answers():
+    """Identity motion, no crop -> ratio 1, distortion 1; a pure crop of a centred window -> ratio = area fraction."""
+    W, H, R, C, F = 640, 360, 8, 8, 5
+    z = np.zeros((F, R + 1, C + 1, 2))
+    ratio, dist = host.mesh_cropping_ratio_and_distortion(W, H, R, C, z, z, (0, 0, W - 1, H - 1))
+    assert ratio.dtype == np.float32 and abs(ratio - 1) < 1e-6 and abs(dist - 1) < 1e-6
+    ratio, dist = host.mesh_cropping_ratio_and_distortion(W, H, R, C, z, z, (32, 18, W - 33, H - 19))
+    assert abs(ratio - ((W - 64) * (H - 36)) / (W * H)) < 1e-5 and abs(dist - 1) < 1e-6
+    # anisotropic crop: the affine part is diag(sx, sy, 1) -> distortion = second largest / largest of {sx, sy, 1}
+    ratio, dist = host.mesh_cropping_ratio_and_distortion(W, H, R, C, z, z, (64, 0, W - 65, H - 1))
+    sx = W / (W - 128)
+    assert abs(dist - 1 / sx) < 1e-5 and abs(ratio - 1 / sx) < 1e-5
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C)
+    disp, _ = synthetic.motion(F, R, C, seed=1)
+    r3 = s.compute_scores(W, H, disp, 0.5 * disp, (10, 8, W - 12, H - 9))
+    assert len(r3) == 3 and 0 < r3[0] <= 1.01 and 0 < r3[1] <= 1 and 0 <= r3[2] <= 1
