@@ -46,7 +46,7 @@ def cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, budget_frames):
     from meshflow_amd import synthetic
     from oracle import clib, meshflow_oracle as mo
     threads = min(os.cpu_count() or 1, max(budget_frames, 1))
-    os.environ['OMP_NUM_THREADS'] = str(threads)
+    threads = clib.set_threads(threads)      # the environment may pin OMP_NUM_THREADS (torchrun sets it to 1)
     taps, lam, on = mo.jacobi_band_coefficients(F, W, H, 0, hom, omega)
     b = np.ascontiguousarray(disp.reshape(F, -1))
     t0 = time.perf_counter()
@@ -76,6 +76,9 @@ def main():
     ap.add_argument('--frames-kind', default='pattern', choices=['pattern', 'noise'])
     ap.add_argument('--cpu-frames', type=int, default=300, help='frames warped by the CPU baseline (0 = skip)')
     ap.add_argument('--gather', action='store_true', help='also time one RCCL gather of all frames to rank 0')
+    ap.add_argument('--mode', default='shard', choices=['shard', 'clips'],
+                    help='N > 1: "shard" = ONE clip of N x frames sharded by frame range (Jacobi replicated, 16-byte crop '
+                         'all-reduce); "clips" = N independent clips, one per GPU, no collective (BASELINE config 5)')
     args = ap.parse_args()
 
     import torch
@@ -87,14 +90,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     H, W, per_gpu, R, C, omega, iters = WORKLOADS[args.workload]
-    F = per_gpu * world
-    lo, hi = host.shard_range(F, world, rank)
+    clips_mode = args.mode == 'clips' and world > 1
+    if clips_mode:                       # every rank owns a whole clip of its own (seed = rank)
+        F, lo, hi = per_gpu, 0, per_gpu
+    else:
+        F = per_gpu * world
+        lo, hi = host.shard_range(F, world, rank)
 
     stab = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=omega,
                               optimization_num_iterations=iters, device=str(device))
-    disp, hom = synthetic.motion(F, R, C, seed=0)
+    seed = rank if clips_mode else 0
+    disp, hom = synthetic.motion(F, R, C, seed=seed)
     d_disp = torch.from_numpy(disp).to(device)
-    d_frames = synthetic.frames_torch(hi - lo, H, W, device, seed=0, kind=args.frames_kind, first_frame=lo)
+    d_frames = synthetic.frames_torch(hi - lo, H, W, device, seed=seed, kind=args.frames_kind, first_frame=lo)
     d_out = torch.empty_like(d_frames)
     table = ops.CellTable(hi - lo, W, H, R, C, device)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -112,7 +120,9 @@ def main():
         ops.warp(d_frames, table, stab.color_outside_image_area_bgr, out=d_out)
         if i is not None:
             ev[i][1].record()
-        bounds = mfdist.allreduce_crop(ops.crop_reduce(table.crop, W, H))
+        bounds = ops.crop_reduce(table.crop, W, H)
+        if not clips_mode:
+            bounds = mfdist.allreduce_crop(bounds)
         return d_stab, bounds              # degenerate-mesh counter accumulates in table.status (checked below)
 
     def barrier():
@@ -131,8 +141,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(mfdist.all_reduce_max(t).item())
 
     warp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     jac_ms = float(np.mean([a.elapsed_time(b) for a, b in jev]))
@@ -155,14 +164,15 @@ def main():
             pass
         result = {
             'metric': 'frames/sec stabilize() hot path (Jacobi + mesh warp + crop scan), inputs resident in HBM',
-            'value': F * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'value': (F * world if clips_mode else F) * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'dtype_note': 'float64 vertex paths and pixel coordinates (as the reference), integer fixed-point interpolation on uint8',
             'data': f'synthetic ({args.frames_kind} frames, injected random mesh motion, seed 0)',
-            'config': {'workload': f'{args.workload}: {W}x{H}, {per_gpu} frames/GPU ({F} total), {R}x{C} mesh, '
+            'config': {'workload': f'{args.workload}: {W}x{H}, {per_gpu} frames/GPU ({per_gpu * world} total), {R}x{C} mesh, '
                                    f'omega={omega}, {iters} Jacobi sweeps, ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL',
-                       'parallelism': f'frame-range shards x{world}, Jacobi replicated, 16-byte crop all-reduce'},
+                       'parallelism': (f'{world} independent clips, one per GPU, no collective' if clips_mode else
+                                       f'frame-range shards x{world}, Jacobi replicated, 16-byte crop all-reduce')},
             'roofline': {'kernel': 'warp_kernel', 'bound': 'hbm', 'achieved': achieved / 1e9,
                          'peak': HBM_PEAK_BYTES_PER_S / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_BYTES_PER_S,
                          'traffic': traffic, 'traffic_source': 'profiles/traffic.json (PMC FETCH_SIZE/WRITE_SIZE, calibrated)'

@@ -30,23 +30,45 @@ def init_from_env(device_type=None):
     local = int(os.environ.get('LOCAL_RANK', str(rank)))
     if device_type is None:
         device_type = 'cuda' if torch.cuda.device_count() > 0 else 'cpu'
+    # MESHFLOW_DIST_BACKEND=gloo lets several ranks share one GPU (functional testing of the N > 1 path on a
+    # 1-GPU box); the default on GPUs is nccl (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get('MESHFLOW_DIST_BACKEND', 'nccl' if device_type == 'cuda' else 'gloo')
     if device_type == 'cuda':
-        torch.cuda.set_device(local)
-        device = torch.device('cuda', local)
+        index = local % torch.cuda.device_count() if backend != 'nccl' else local
+        torch.cuda.set_device(index)
+        device = torch.device('cuda', index)
     else:
         device = torch.device('cpu')
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         kwargs = {}
-        if device_type == 'cuda':
+        if backend == 'nccl':
             kwargs['device_id'] = device
-        dist.init_process_group('nccl' if device_type == 'cuda' else 'gloo', rank=rank, world_size=world, **kwargs)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
     return rank, world, device
 
 
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def _through_host():
+    """gloo moves tensors through host memory; device tensors are staged explicitly so that it works on every build."""
+    return dist.is_initialized() and dist.get_backend() == 'gloo'
+
+
+def all_reduce_max(t):
+    """In-place MAX all-reduce of a small tensor on whatever backend is active."""
+    if world_size() == 1:
+        return t
+    if _through_host() and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
 
 
 def allreduce_crop(bounds):
@@ -56,7 +78,7 @@ def allreduce_crop(bounds):
         return bounds
     sign = torch.tensor([1, 1, -1, -1], dtype=bounds.dtype, device=bounds.device)
     packed = bounds * sign
-    dist.all_reduce(packed, op=dist.ReduceOp.MAX)
+    all_reduce_max(packed)
     return packed * sign
 
 
@@ -75,10 +97,13 @@ def gather_frames(local_frames, num_frames, dst=0):
     else:
         send = torch.zeros(shape, dtype=local_frames.dtype, device=local_frames.device)
         send[:local_frames.shape[0]] = local_frames
+    device = send.device
+    if _through_host() and send.is_cuda:
+        send = send.cpu()
     if rank == dst:
-        full = torch.empty((G,) + shape, dtype=local_frames.dtype, device=local_frames.device)
+        full = torch.empty((G,) + shape, dtype=send.dtype, device=send.device)
         dist.gather(send, list(full.unbind(0)), dst=dst)
-        return full.reshape((G * per,) + shape[1:])[:num_frames]
+        return full.reshape((G * per,) + shape[1:])[:num_frames].to(device)
     dist.gather(send, None, dst=dst)
     return None
 

@@ -44,6 +44,8 @@ def load(openmp=False):
     lib.mfo_warp_frame.restype = None
     lib.mfo_warp_clip.argtypes = [_u8p, _u8p] + [ctypes.c_int] * 5 + [_dp, _dp, _u8p, ctypes.c_int, _i32p]
     lib.mfo_warp_clip.restype = ctypes.c_int
+    lib.mfo_set_threads.argtypes = [ctypes.c_int]
+    lib.mfo_set_threads.restype = ctypes.c_int
     lib.mfo_cell_doubles.restype = ctypes.c_int
     assert lib.mfo_cell_doubles() == CELL_DOUBLES
     _LIBS[name] = lib
@@ -117,3 +119,8 @@ def warp_clip(frames, R, C, unstab, stab, border_bgr=(0, 0, 255), use_bbox=False
     bad = load(openmp).mfo_warp_clip(_p(frames, _u8p), _p(out, _u8p), n, W, H, R, C, _p(u, _dp), _p(s, _dp),
                                     _p(border, _u8p), int(use_bbox), _p(crop, _i32p))
     return out, crop, bad
+
+
+def set_threads(n):
+    """Thread count of the OpenMP build; returns the count in effect."""
+    return load(True).mfo_set_threads(int(n))

@@ -369,3 +369,11 @@ int mfo_warp_clip(const uint8_t* frames, uint8_t* out, int n, int W, int H, int 
 }
 
 int mfo_cell_doubles(void) { return MFO_CELL_DOUBLES; }
+
+/* Thread count of the OpenMP build (the environment may pin OMP_NUM_THREADS, e.g. torchrun sets it to 1). */
+#ifdef _OPENMP
+#include <omp.h>
+int mfo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int mfo_set_threads(int n) { (void)n; return 1; }
+#endif
