@@ -40,12 +40,32 @@ WORKLOADS = {
 HBM_PEAK_BYTES_PER_S = 8.0e12     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def usable_cpus():
+    """Host threads this process can really use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (('/sys/fs/cgroup/cpu.max', lambda t: t.split()),
+                        ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', lambda t: (t.strip(), open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota not in ('max', '-1'):
+                n = min(n, max(1, int(int(quota) / int(period))))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, budget_frames):
     """Time the C oracle on the host: Jacobi for the whole clip + warp of `budget_frames` frames (scaled
     linearly to F frames).  The oracle is only the thing timed here, never part of the product path."""
     from meshflow_amd import synthetic
     from oracle import clib, meshflow_oracle as mo
-    threads = min(os.cpu_count() or 1, max(budget_frames, 1))
+    # more than 32 threads did not help on the 256-thread hosts measured (tools/cpu_threads.py: 16 -> 60 frames/s,
+    # 32 -> 61, 64 -> 53, 256 -> 35), so the baseline is capped there
+    threads = min(usable_cpus(), 32, max(budget_frames, 1))
     threads = clib.set_threads(threads)      # the environment may pin OMP_NUM_THREADS (torchrun sets it to 1)
     taps, lam, on = mo.jacobi_band_coefficients(F, W, H, 0, hom, omega)
     b = np.ascontiguousarray(disp.reshape(F, -1))
@@ -75,6 +95,7 @@ def main():
     ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
     ap.add_argument('--frames-kind', default='pattern', choices=['pattern', 'noise'])
     ap.add_argument('--cpu-frames', type=int, default=300, help='frames warped by the CPU baseline (0 = skip)')
+    # default: the whole clip, ~5-10 s of host time
     ap.add_argument('--gather', action='store_true', help='also time one RCCL gather of all frames to rank 0')
     ap.add_argument('--mode', default='shard', choices=['shard', 'clips'],
                     help='N > 1: "shard" = ONE clip of N x frames sharded by frame range (Jacobi replicated, 16-byte crop '

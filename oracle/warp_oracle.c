@@ -39,30 +39,39 @@
 void mfo_jacobi_banded(const double* b, double* x_out, const double* taps, const double* lam,
                        const double* inv_on, int F, int S, int omega, int iters)
 {
-    size_t n = (size_t)F * (size_t)S;
-    double* cur = (double*)malloc(n * sizeof(double));
-    double* nxt = (double*)malloc(n * sizeof(double));
-    memcpy(cur, b, n * sizeof(double));                       /* x_start = b, mfs.py:699-703, 871 */
-    for (int it = 0; it < iters; ++it) {
+    /* The S series are independent (one vertex component each, mfs.py:695-704): blocks of series are swept
+       through all iterations by one thread each, with no synchronisation; per series the arithmetic and its
+       order are exactly as in the single-threaded loop. */
+    const int BS = 8;
+    const int nblocks = (S + BS - 1) / BS;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic)
 #endif
-        for (int t = 0; t < F; ++t) {
-            double two_lam = 2.0 * lam[t];
-            for (int s = 0; s < S; ++s) {
-                double acc = 0.0;
-                for (int d = -omega; d <= omega; ++d) {
-                    int r = t + d;
-                    if (r < 0 || r >= F) continue;
-                    acc = fma(taps[d + omega], cur[(size_t)r * S + s], acc);
+    for (int blk = 0; blk < nblocks; ++blk) {
+        const int s0 = blk * BS, ns = (s0 + BS <= S) ? BS : S - s0;
+        double* cur = (double*)malloc((size_t)F * BS * sizeof(double));
+        double* nxt = (double*)malloc((size_t)F * BS * sizeof(double));
+        for (int t = 0; t < F; ++t)
+            for (int s = 0; s < ns; ++s) cur[(size_t)t * BS + s] = b[(size_t)t * S + s0 + s];   /* x_start = b, mfs.py:699-703, 871 */
+        for (int it = 0; it < iters; ++it) {
+            for (int t = 0; t < F; ++t) {
+                const double two_lam = 2.0 * lam[t];
+                for (int s = 0; s < ns; ++s) {
+                    double acc = 0.0;
+                    for (int d = -omega; d <= omega; ++d) {
+                        const int r = t + d;
+                        if (r < 0 || r >= F) continue;
+                        acc = fma(taps[d + omega], cur[(size_t)r * BS + s], acc);
+                    }
+                    nxt[(size_t)t * BS + s] = inv_on[t] * fma(two_lam, acc, b[(size_t)t * S + s0 + s]);
                 }
-                nxt[(size_t)t * S + s] = inv_on[t] * fma(two_lam, acc, b[(size_t)t * S + s]);
             }
+            double* tmp = cur; cur = nxt; nxt = tmp;
         }
-        double* tmp = cur; cur = nxt; nxt = tmp;
+        for (int t = 0; t < F; ++t)
+            for (int s = 0; s < ns; ++s) x_out[(size_t)t * S + s0 + s] = cur[(size_t)t * BS + s];
+        free(cur); free(nxt);
     }
-    memcpy(x_out, cur, n * sizeof(double));
-    free(cur); free(nxt);
 }
 
 /* ---------------------------------------------------------------------------------------------- */
