@@ -444,10 +444,12 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 const int x = x0 + j;
                 // crop-boundary scan, mfs.py:1075-1098: |u - e| < 1.  The float32 differences are exact
                 // whenever they are smaller than 1 in magnitude (Sterbenz), so the tests are exact.
-                if (fabsf(uu) < 1.0f) c_left = max(c_left, x);
-                if (fabsf(uu - fWm1) < 1.0f) c_right = min(c_right, x);
-                if (fabsf(vv) < 1.0f) c_top = max(c_top, y);
-                if (fabsf(vv - fHm1) < 1.0f) c_bottom = min(c_bottom, y);
+                if (x < W) {                                 // (a lane's last pixels may lie beyond the frame when W % 4 != 0)
+                    if (fabsf(uu) < 1.0f) c_left = max(c_left, x);
+                    if (fabsf(uu - fWm1) < 1.0f) c_right = min(c_right, x);
+                    if (fabsf(vv) < 1.0f) c_top = max(c_top, y);
+                    if (fabsf(vv - fHm1) < 1.0f) c_bottom = min(c_bottom, y);
+                }
                 const int sxx = cv_round_f32(uu * 32.0f), syy = cv_round_f32(vv * 32.0f);
                 const int ix = sxx >> 5, iy = syy >> 5;      // (saturation to int16 cannot change any decision below)
                 const uint32_t fx = sxx & 31, fy = syy & 31;

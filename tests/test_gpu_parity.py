@@ -326,3 +326,15 @@ def test_crop_resize_1080p_and_errors(dev):
     np.testing.assert_array_equal(np.stack(got), np.stack(want))
     with pytest.raises(ValueError):
         ops.crop_resize(torch.from_numpy(frames[:1]).to(dev), (50, 10, 40, 100))       # right < left: empty crop
+
+
+def test_randomised_parity_campaign(dev):
+    """300 random geometries (warp incl. W % 4 != 0, borders, folded quads; Jacobi incl. the generic kernel;
+    crop + resize) against the C / NumPy oracles, bit for bit.  Seed 1 contains the case that exposed the
+    crop-flag bug for pixels beyond the right frame edge."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_parity.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, stats = mod.run(300, 1)
+    assert bad == 0 and stats['warp'] > 100 and stats['jacobi'] > 30 and stats['resize'] > 30
