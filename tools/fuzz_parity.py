@@ -8,7 +8,7 @@ from oracle import clib, meshflow_oracle as mo
 
 
 
-def run(cases=200, seed0=0, only=-1):
+def run(cases=200, seed0=0, only=-1, big=False):
     """Returns (number of mismatching cases, per-kind counts)."""
     dev = torch.device('cuda:0')
     g = np.random.default_rng(seed0)
@@ -18,9 +18,9 @@ def run(cases=200, seed0=0, only=-1):
     for case in range(cases):
         kind = g.choice(['warp', 'warp', 'warp', 'jacobi', 'resize'])
         if kind == 'warp':
-            W = int(g.integers(8, 420)); H = int(g.integers(8, 300))
-            R = int(g.integers(1, min(24, H // 2) + 1)); C = int(g.integers(1, min(24, W // 2) + 1))
-            n = int(g.integers(1, 4))
+            W = int(g.integers(8, 2100 if big else 420)); H = int(g.integers(8, 1200 if big else 300))
+            R = int(g.integers(1, min(64 if big else 24, H // 2) + 1)); C = int(g.integers(1, min(64 if big else 24, W // 2) + 1))
+            n = int(g.integers(1, 3 if big else 4))
             sigma = float(g.choice([0.2, 1.0, 3.0, 8.0, 25.0])) * min(1.0, min(W / C, H / R) / 20.0 + 0.05)
             frames = synthetic.frames_numpy(n, H, W, seed=case, kind='noise')
             idx = np.arange(n * (R + 1) * (C + 1) * 2, dtype=np.int64).reshape(n, R + 1, C + 1, 2)
@@ -32,7 +32,7 @@ def run(cases=200, seed0=0, only=-1):
             use_bbox = bool(g.random() < 0.5)
             if only >= 0 and case != only:
                 continue
-            want, want_crop, bad = clib.warp_clip(frames, R, C, unstab, stab, border_bgr=border, use_bbox=use_bbox)
+            want, want_crop, bad = clib.warp_clip(frames, R, C, unstab, stab, border_bgr=border, use_bbox=use_bbox or big, openmp=big)
             table = ops.cell_table(torch.from_numpy(unstab).to(dev), torch.from_numpy(stab).to(dev), W, H, R, C)
             out = ops.warp(torch.from_numpy(frames).to(dev), table, border)
             torch.cuda.synchronize()
@@ -89,4 +89,5 @@ if __name__ == '__main__':
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     one = int(sys.argv[3]) if len(sys.argv) > 3 else -1            # re-run just this case, verbosely
-    sys.exit(1 if run(n, sd, one)[0] else 0)
+    big = len(sys.argv) > 4 and sys.argv[4] == 'big'                # frames up to 2100 x 1200, meshes up to 64 x 64
+    sys.exit(1 if run(n, sd, one, big)[0] else 0)
