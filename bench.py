@@ -166,6 +166,20 @@ def main():
 
     warp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     jac_ms = float(np.mean([a.elapsed_time(b) for a, b in jev]))
+    # Next row on the path, measured outside the timed region: crop to the clip-level bounds and
+    # resize back, device-resident (mfs.py:1111-1157).
+    resize_ms = None
+    if not (bounds[2] < bounds[0] or bounds[3] < bounds[1]):
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        scratch = torch.empty_like(d_frames)
+        ops.crop_resize(d_out, bounds.tolist(), out=scratch)
+        r0.record()
+        for _ in range(3):
+            ops.crop_resize(d_out, bounds.tolist(), out=scratch)
+        r1.record()
+        torch.cuda.synchronize()
+        resize_ms = r0.elapsed_time(r1) / 3
+        del scratch
     gather_ms = None
     if args.gather and world > 1:
         barrier()
@@ -203,6 +217,11 @@ def main():
             'jacobi': {'avg_ms_incl_host_setup': jac_ms, 'series': int(d_disp[0].numel()), 'frames': F},
             'crop_bounds': [int(v) for v in bounds.tolist()],
         }
+        if resize_ms is not None:
+            result['next_rows'] = {'crop_resize': {'kernel': 'resize_kernel', 'avg_launch_ms': resize_ms, 'bound': 'hbm',
+                                                   'achieved': algo_bytes / (resize_ms * 1e-3) / 1e9, 'unit': 'GB/s',
+                                                   'frac': algo_bytes / (resize_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
+                                                   'note': 'outside the timed region; algorithmic bytes 2*H*W*3 per frame'}}
         if gather_ms is not None:
             result['gather_to_rank0_ms'] = gather_ms
         if world == 1 and args.cpu_frames > 0:

@@ -11,8 +11,8 @@
 //   vertical    out = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2
 // resize_tables_kernel builds the per-column / per-row tables (W + H entries) on the device in the same
 // float / double operations; resize_kernel applies them: a lane owns 4 consecutive output pixels (one
-// 12-byte store), four 4-byte tap loads per pixel.  Memory-bound in principle (2*H*W*3 bytes per frame);
-// this first version is VALU-bound like the warp kernel and is not tuned yet.
+// 12-byte store), two unaligned 8-byte tap loads per pixel, v_dot2_u32_u16 for the horizontal pass.  Memory-bound
+// in principle (2*H*W*3 bytes per frame); VALU-bound in practice like the warp kernel.
 #include "mf_common.h"
 
 namespace mf {
@@ -60,6 +60,13 @@ __device__ __forceinline__ uint32_t load_bgr(const uint8_t* __restrict__ frame, 
     return v & 0xFFFFFFu;
 }
 
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b), c, false);
+}
+
 __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out, int n,
                                                      int W, int H, int left, int top, int cw,
                                                      const ResizeTab* __restrict__ xtab,
@@ -78,24 +85,54 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
     const uint32_t row0 = (uint32_t)(top + (yt.ofs & 0xFFFF)) * (uint32_t)W + (uint32_t)left;
     const uint32_t row1 = (uint32_t)(top + (yt.ofs >> 16)) * (uint32_t)W + (uint32_t)left;
     uint32_t px[4];
+    // Fast path: the lane's four pixels are inside the frame and every 8-byte tap load (pixels sx, sx+1 and two
+    // bytes more) stays inside the frame stack.  Where sx is the last column of the crop the second weight is 0,
+    // so whatever lies right of it may be read.
+    const bool whole = x0 + 3 < W && ((size_t)(max(row0, row1) + (uint32_t)cw) * 3u + 8u <= limit);
+    if (whole) {
+        ResizeTab xt[4];
+        uint2 a[4], b[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        px[j] = 0;
-        if (x0 + j >= W) continue;
-        const ResizeTab xt = xtab[x0 + j];
-        const uint32_t a0 = xt.w & 0xFFFFu, a1 = xt.w >> 16;
-        const uint32_t sx = (uint32_t)xt.ofs, sx1 = min(sx + 1u, (uint32_t)(cw - 1));     // a1 == 0 where sx == cw-1
-        const uint32_t p00 = load_bgr(src, (row0 + sx) * 3u, limit), p01 = load_bgr(src, (row0 + sx1) * 3u, limit);
-        const uint32_t p10 = load_bgr(src, (row1 + sx) * 3u, limit), p11 = load_bgr(src, (row1 + sx1) * 3u, limit);
-        uint32_t r = 0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const uint32_t t0 = ((p00 >> (8 * c)) & 255u) * a0 + ((p01 >> (8 * c)) & 255u) * a1;
-            const uint32_t t1 = ((p10 >> (8 * c)) & 255u) * a0 + ((p11 >> (8 * c)) & 255u) * a1;
-            const uint32_t v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2u) >> 2;
-            r |= min(v, 255u) << (8 * c);
+        for (int j = 0; j < 4; ++j) {
+            xt[j] = xtab[x0 + j];
+            __builtin_memcpy(&a[j], src + (row0 + (uint32_t)xt[j].ofs) * 3u, 8);
+            __builtin_memcpy(&b[j], src + (row1 + (uint32_t)xt[j].ofs) * 3u, 8);
         }
-        px[j] = r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // bytes: B0 G0 R0 B1 | G1 R1 . .  -> (S[sx], S[sx+1]) as two uint16 per channel, then v_dot2_u32_u16
+            const uint32_t w = xt[j].w;                                        // a0 | a1 << 16
+            const uint32_t tB0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C030C00u), w, 0u);
+            const uint32_t tG0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C040C01u), w, 0u);
+            const uint32_t tR0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C050C02u), w, 0u);
+            const uint32_t tB1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C030C00u), w, 0u);
+            const uint32_t tG1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C040C01u), w, 0u);
+            const uint32_t tR1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C050C02u), w, 0u);
+            const uint32_t vB = ((__umul24(b0, tB0 >> 4) >> 16) + (__umul24(b1, tB1 >> 4) >> 16) + 2u) >> 2;
+            const uint32_t vG = ((__umul24(b0, tG0 >> 4) >> 16) + (__umul24(b1, tG1 >> 4) >> 16) + 2u) >> 2;
+            const uint32_t vR = ((__umul24(b0, tR0 >> 4) >> 16) + (__umul24(b1, tR1 >> 4) >> 16) + 2u) >> 2;
+            px[j] = min(vB, 255u) | (min(vG, 255u) << 8) | (min(vR, 255u) << 16);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            px[j] = 0;
+            if (x0 + j >= W) continue;
+            const ResizeTab xt = xtab[x0 + j];
+            const uint32_t a0 = xt.w & 0xFFFFu, a1 = xt.w >> 16;
+            const uint32_t sx = (uint32_t)xt.ofs, sx1 = min(sx + 1u, (uint32_t)(cw - 1));     // a1 == 0 where sx == cw-1
+            const uint32_t p00 = load_bgr(src, (row0 + sx) * 3u, limit), p01 = load_bgr(src, (row0 + sx1) * 3u, limit);
+            const uint32_t p10 = load_bgr(src, (row1 + sx) * 3u, limit), p11 = load_bgr(src, (row1 + sx1) * 3u, limit);
+            uint32_t r = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t t0 = ((p00 >> (8 * c)) & 255u) * a0 + ((p01 >> (8 * c)) & 255u) * a1;
+                const uint32_t t1 = ((p10 >> (8 * c)) & 255u) * a0 + ((p11 >> (8 * c)) & 255u) * a1;
+                const uint32_t v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2u) >> 2;
+                r |= min(v, 255u) << (8 * c);
+            }
+            px[j] = r;
+        }
     }
     const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
     if ((W & 3) == 0 && x0 + 3 < W) {
