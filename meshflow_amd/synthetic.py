@@ -128,6 +128,33 @@ def motion(num_frames, mesh_rows, mesh_cols, seed=0, translation_sigma=3.0, fiel
     return disp, hom
 
 
+def features(num_frames, height, width, homographies, seed=0, per_pair=(600, 900), residual_sigma=1.5,
+             noise_sigma=0.4):
+    """Matched features per frame pair, in the shape and dtype the reference's tracker hands on (mfs.py:518-528,
+    578: float64 (K, 1, 2) arrays whose values are float32 positions plus integer sub-frame offsets):
+    a list of F-1 `(early, late)` tuples.  `early` is uniform over the frame; `late` = the pair's homography
+    applied to it + a smooth residual field (rms ~ residual_sigma px) + iid noise, rounded to float32."""
+    F = num_frames
+    lo, hi = per_pair
+    out = []
+    for t in range(F - 1):
+        k = lo + int(hash32(np.array([t]), seed * 16 + 9)[0]) % max(hi - lo + 1, 1)
+        i = np.arange(k, dtype=np.int64) + t * 65536
+        ex = (uniform01(i * 2, seed * 16 + 10) * (width - 1)).astype(np.float32).astype(np.float64)
+        ey = (uniform01(i * 2 + 1, seed * 16 + 10) * (height - 1)).astype(np.float32).astype(np.float64)
+        m = np.asarray(homographies[t], dtype=np.float64).reshape(9)
+        w = ex * m[6] + ey * m[7] + m[8]
+        gx = (ex * m[0] + ey * m[1] + m[2]) / w
+        gy = (ex * m[3] + ey * m[4] + m[5]) / w
+        ph = 2 * np.pi * uniform01(t * 4 + np.arange(4, dtype=np.int64), seed * 16 + 11)
+        rx = residual_sigma * 1.4 * np.cos(2 * np.pi * (0.9 * ex / width + 0.6 * ey / height) + ph[0]) * np.cos(ph[1])
+        ry = residual_sigma * 1.4 * np.cos(2 * np.pi * (0.5 * ex / width + 1.1 * ey / height) + ph[2]) * np.cos(ph[3])
+        lx = (gx + rx + noise_sigma * normal(i * 2, seed * 16 + 12)).astype(np.float32).astype(np.float64)
+        ly = (gy + ry + noise_sigma * normal(i * 2 + 1, seed * 16 + 12)).astype(np.float32).astype(np.float64)
+        out.append((np.stack([ex, ey], axis=-1)[:, None, :], np.stack([lx, ly], axis=-1)[:, None, :]))
+    return out
+
+
 def clip(num_frames, height, width, mesh_rows=16, mesh_cols=16, seed=0, kind='pattern', **motion_kw):
     """Convenience: (frames uint8 (F,H,W,3), displacements, homographies)."""
     disp, hom = motion(num_frames, mesh_rows, mesh_cols, seed=seed, **motion_kw)

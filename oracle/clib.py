@@ -1,4 +1,4 @@
-"""ctypes loader for the C oracle (oracle/warp_oracle.c).  TEST INFRASTRUCTURE ONLY.
+"""ctypes loader for the C oracle (oracle/warp_oracle.c, oracle/motion_oracle.c).  TEST INFRASTRUCTURE ONLY.
 
 `load()` builds `oracle/_build/liboracle*.so` with `make -C oracle` when missing (gcc only)."""
 import ctypes
@@ -28,8 +28,8 @@ def load(openmp=False):
     if name in _LIBS:
         return _LIBS[name]
     path = os.path.join(_HERE, '_build', name)
-    src = os.path.join(_HERE, 'warp_oracle.c')
-    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ('warp_oracle.c', 'motion_oracle.c'))
+    if not os.path.exists(path) or os.path.getmtime(path) < newest:
         build()
     lib = ctypes.CDLL(path)
     lib.mfo_jacobi_banded.argtypes = [_dp, _dp, _dp, _dp, _dp] + [ctypes.c_int] * 4
@@ -47,6 +47,8 @@ def load(openmp=False):
     lib.mfo_set_threads.argtypes = [ctypes.c_int]
     lib.mfo_set_threads.restype = ctypes.c_int
     lib.mfo_cell_doubles.restype = ctypes.c_int
+    lib.mfo_vertex_motion.argtypes = [_dp, _dp, _i32p, _dp] + [ctypes.c_int] * 7 + [_fp, _dp]
+    lib.mfo_vertex_motion.restype = ctypes.c_int
     assert lib.mfo_cell_doubles() == CELL_DOUBLES
     _LIBS[name] = lib
     return lib
@@ -124,3 +126,26 @@ def warp_clip(frames, R, C, unstab, stab, border_bgr=(0, 0, 255), use_bbox=False
 def set_threads(n):
     """Thread count of the OpenMP build; returns the count in effect."""
     return load(True).mfo_set_threads(int(n))
+
+
+def pack_features(features_by_pair):
+    """[(early (K,1,2), late (K,1,2)) or (None, None), ...] -> (early (Ktot,2) f64, late (Ktot,2) f64, offsets int32)."""
+    early = [np.zeros((0, 2)) if e is None else np.asarray(e, dtype=np.float64).reshape(-1, 2) for e, _ in features_by_pair]
+    late = [np.zeros((0, 2)) if l is None else np.asarray(l, dtype=np.float64).reshape(-1, 2) for _, l in features_by_pair]
+    offsets = np.cumsum([0] + [len(e) for e in early]).astype(np.int32)
+    cat = lambda parts: np.ascontiguousarray(np.concatenate(parts)) if parts else np.zeros((0, 2))
+    return cat(early), cat(late), offsets
+
+
+def vertex_motion(W, H, R, C, ell_rows, ell_cols, features_by_pair, homographies, openmp=False):
+    """(displacements float64 (P+1,R+1,C+1,2), velocities float32 (P,R+1,C+1,2)); ValueError like math.sqrt."""
+    early, late, offsets = pack_features(features_by_pair)
+    P = len(features_by_pair)
+    hom = np.ascontiguousarray(np.asarray(homographies, dtype=np.float64)[:P]).reshape(P, 9)
+    vel = np.zeros((P, R + 1, C + 1, 2), dtype=np.float32)
+    disp = np.zeros((P + 1, R + 1, C + 1, 2), dtype=np.float64)
+    status = load(openmp).mfo_vertex_motion(_p(early, _dp), _p(late, _dp), _p(offsets, _i32p), _p(hom, _dp), P,
+                                            W, H, R, C, ell_rows, ell_cols, _p(vel, _fp), _p(disp, _dp))
+    if status:
+        raise ValueError('math domain error')
+    return disp, vel

@@ -10,6 +10,12 @@ The reference itself never travels to the GPU box: only the vectors written here
 the reference's outputs), together with this script.  Run from the repo root:
 
     python oracle/gen_golden.py            # needs /root/reference
+    python oracle/gen_golden.py motion     # only the vertex-motion vectors (mfs.py:236-452)
+
+For the vertex-motion vectors the stub additionally provides `cv2.perspectiveTransform` and `cv2.medianBlur`
+(the build's own restatements from oracle/), and `_get_matched_features_and_homography` (the FAST/LK/RANSAC
+tracker, mfs.py:455-629) is replaced by a lookup into synthetic features; everything else -- the ellipse splat,
+`statistics.median`, the dtype flow, the running sum -- is the reference's own code.
 """
 import os
 import sys
@@ -26,6 +32,19 @@ REFERENCE_DIR = os.environ.get('MESHFLOW_REFERENCE_DIR', '/root/reference')
 def import_reference():
     stub = types.ModuleType('cv2')
     stub.FastFeatureDetector_create = lambda *a, **k: None
+
+    def perspective_transform(points, m):
+        from oracle import meshflow_oracle as mo, motion_oracle as mt
+        points = np.asarray(points)
+        return mo.perspective_transform_f32(points, m) if points.dtype == np.float32 else mt.perspective_transform_f64(points, m)
+
+    def median_blur(img, ksize):
+        from oracle import motion_oracle as mt
+        assert ksize == 3
+        return mt.median_blur3_f32(img)
+
+    stub.perspectiveTransform = perspective_transform
+    stub.medianBlur = median_blur
     sys.modules['cv2'] = stub
     sys.path.insert(0, REFERENCE_DIR)
     import meshflowstabilizer as mfs
@@ -46,10 +65,60 @@ def random_homographies(num_frames, seed):
     return hom
 
 
+MOTION_CASES = (
+    # name, W, H, R, C, ellipse rows, ellipse cols, frames, features per pair, seed
+    ('motion_small', 640, 360, 8, 8, 5, 5, 6, (120, 180), 3),
+    ('motion_1080p', 1920, 1080, 16, 16, 10, 10, 4, (500, 700), 0),
+    ('motion_ragged', 100, 75, 3, 5, 3, 4, 5, (6, 14), 5),
+)
+
+
+def motion_inputs(W, H, R, C, F, per_pair, seed):
+    """Features + homographies of one case, from the build's hash-based generator (regenerated in the tests)."""
+    from meshflow_amd import synthetic
+    n = np.arange((F - 1) * 9, dtype=np.int64).reshape(F - 1, 3, 3)
+    g = synthetic.normal(n, seed * 16 + 13)
+    hom = np.tile(np.identity(3), (F, 1, 1))
+    hom[:-1, :2, :2] += 0.004 * g[:, :2, :2]
+    hom[:-1, 0, 2] = 0.004 * W * g[:, 0, 2]
+    hom[:-1, 1, 2] = 0.004 * H * g[:, 1, 2]
+    hom[:-1, 2, :2] = 2e-6 * g[:, 2, :2]
+    feats = synthetic.features(F, H, W, hom, seed=seed, per_pair=per_pair)
+    return feats, hom
+
+
+def motion_goldens(MFS):
+    """(6) vertex-motion accumulation (mfs.py:236-452) -- see the module docstring for what is stubbed."""
+    for name, W, H, R, C, er, ec, F, per_pair, seed in MOTION_CASES:
+        feats, hom = motion_inputs(W, H, R, C, F, per_pair, seed)
+        s = MFS(mesh_row_count=R, mesh_col_count=C, feature_ellipse_row_count=er, feature_ellipse_col_count=ec)
+        frames = [np.broadcast_to(np.uint8(0), (H, W, 3)) for _ in range(F)]
+        index = {id(f): i for i, f in enumerate(frames)}
+        s._get_matched_features_and_homography = lambda early, late: (*feats[index[id(early)]], hom[index[id(early)]])
+        disp, hom_out = s._get_unstabilized_vertex_displacements_and_homographies(F, frames)
+        vel = np.stack([s._get_unstabilized_vertex_velocities(frames[t], frames[t + 1])[0] for t in range(F - 1)])
+        assert vel.dtype == np.float32 and disp.dtype == np.float64 and np.array_equal(hom_out, hom)
+        lx, ly = s._get_vertex_nearby_feature_residual_velocities(W, H, feats[0][0], feats[0][1], hom[0])
+        counts = np.array([[len(v) for v in row] for row in lx], dtype=np.int32)
+        flat_x = np.array([x for row in lx for v in row for x in v], dtype=np.float64)
+        flat_y = np.array([y for row in ly for v in row for y in v], dtype=np.float64)
+        assert all(isinstance(x, np.float64) for row in lx for v in row for x in v)
+        np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), width=W, height=H, R=R, C=C, ell_rows=er, ell_cols=ec,
+                            F=F, per_pair=np.array(per_pair), seed=seed, hom=hom,
+                            offsets=np.cumsum([0] + [len(e) for e, _ in feats]),
+                            early=np.concatenate([e.reshape(-1, 2) for e, _ in feats]),
+                            late=np.concatenate([l.reshape(-1, 2) for _, l in feats]),
+                            velocities=vel, displacements=disp, counts0=counts, lists0_x=flat_x, lists0_y=flat_y)
+
+
 def main():
     from meshflow_amd import synthetic
     MFS = import_reference()
     os.makedirs(GOLDEN, exist_ok=True)
+    if sys.argv[1:] == ['motion']:
+        motion_goldens(MFS)
+        print('vertex-motion vectors written to', GOLDEN)
+        return
 
     # (1) coefficient setup, all four weight definitions  (mfs.py:713-841)
     out = {}
@@ -122,6 +191,8 @@ def main():
         out[f'disp{i}'] = disp
         out[f'score{i}'] = np.float64(s._compute_stability_score(F, disp))
     np.savez_compressed(os.path.join(GOLDEN, 'stability.npz'), **out)
+
+    motion_goldens(MFS)
     print('golden vectors written to', GOLDEN)
 
 
