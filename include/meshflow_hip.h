@@ -108,6 +108,28 @@ size_t mf_crop_resize_workspace_bytes(int W, int H);
 int mf_crop_resize_u8c3(const uint8_t* d_frames, uint8_t* d_out, int n, int W, int H, int left, int top, int right,
                         int bottom, void* d_work, void* stream);
 
+/* ---- the row before the path: vertex-motion accumulation (mfs.py:236-452 from the matched features on) ----
+ * Replaces the Python loops of _get_vertex_nearby_feature_residual_velocities (mfs.py:365-452), the medians, global
+ * motion and median blur of _get_unstabilized_vertex_velocities (mfs.py:316-362, everything after the tracker call)
+ * and the running sum of _get_unstabilized_vertex_displacements_and_homographies (mfs.py:268-282).  The tracker
+ * itself (_get_matched_features_and_homography, mfs.py:455-629: FAST / LK / RANSAC) stays with the caller.
+ * d_early, d_late: [total_features][2] float64 (x, y), the features of the P frame pairs back to back;
+ * d_offsets: [P+1] int32, pair p owns features d_offsets[p] .. d_offsets[p+1]-1 (an empty range = no features);
+ * max_per_pair >= every range length; d_hom: [P][9] float64 early-to-late homographies.
+ * d_velocities: [P][(R+1)*(C+1)][2] float32 (what _get_unstabilized_vertex_velocities returns per pair);
+ * d_displacements: [P+1][(R+1)*(C+1)][2] float64, [0] = 0 (mfs.py:271).
+ * d_work: mf_vertex_motion_workspace_bytes(...) bytes, 16-byte aligned.  d_status: one int32 (zero it before the
+ * call); non-zero afterwards = the reference's math.sqrt would have raised ValueError (mfs.py:444). */
+size_t mf_vertex_motion_workspace_bytes(int total_features, int max_per_pair, int P, int R, int C);
+int mf_vertex_motion_f64(const double* d_early, const double* d_late, const int32_t* d_offsets, const double* d_hom,
+                         int P, int total_features, int max_per_pair, int W, int H, int R, int C,
+                         int ellipse_rows, int ellipse_cols, float* d_velocities, double* d_displacements,
+                         void* d_work, int32_t* d_status, void* stream);
+
+/* Device self-test: sqrt() on (0, 0.25] (the ellipse half-width, mfs.py:444) must be correctly rounded; *mismatches
+ * receives the number of inputs where it is not (must be 0).  Synchronous. */
+int mf_selftest_sqrt(uint64_t n, uint64_t seed, uint64_t* mismatches);
+
 /* Device self-test: the warp kernel's trimmed reciprocal (exact for 0.5 <= |w| <= 2) against IEEE 1.0/w on
  * n hashed inputs; *mismatches receives the number of differing bit patterns (must be 0). Synchronous. */
 int mf_selftest_recip(uint64_t n, uint64_t seed, uint64_t* mismatches);

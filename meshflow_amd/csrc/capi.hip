@@ -123,16 +123,48 @@ int mf_crop_resize_u8c3(const uint8_t* d_frames, uint8_t* d_out, int n, int W, i
     return launch_crop_resize(d_frames, d_out, n, W, H, left, top, right, bottom, d_work, (hipStream_t)stream);
 }
 
-int mf_selftest_recip(uint64_t n, uint64_t seed, uint64_t* mismatches)
+size_t mf_vertex_motion_workspace_bytes(int total_features, int max_per_pair, int P, int R, int C)
 {
-    if (!mismatches) { set_error("mf_selftest_recip: null"); return MF_ERR_INVALID_ARG; }
+    if (total_features < 0 || max_per_pair < 0 || P < 0 || R <= 0 || C <= 0) return 0;
+    return vertex_motion_workspace_bytes(total_features, max_per_pair, P, R, C);
+}
+
+int mf_vertex_motion_f64(const double* d_early, const double* d_late, const int32_t* d_offsets, const double* d_hom,
+                         int P, int total_features, int max_per_pair, int W, int H, int R, int C,
+                         int ellipse_rows, int ellipse_cols, float* d_velocities, double* d_displacements,
+                         void* d_work, int32_t* d_status, void* stream)
+{
+    if (!d_offsets || !d_displacements || !d_work || !d_status || (P > 0 && (!d_hom || !d_velocities)) ||
+        (total_features > 0 && (!d_early || !d_late))) {
+        set_error("mf_vertex_motion_f64: null pointer");
+        return MF_ERR_INVALID_ARG;
+    }
+    return launch_vertex_motion(d_early, d_late, d_offsets, d_hom, P, total_features, max_per_pair, W, H, R, C,
+                                ellipse_rows, ellipse_cols, d_velocities, d_displacements, d_work, d_status, (hipStream_t)stream);
+}
+
+static int run_selftest(int (*launch)(unsigned long long, unsigned long long, unsigned long long*, hipStream_t),
+                        uint64_t n, uint64_t seed, uint64_t* mismatches)
+{
     void* d = nullptr;
     MF_HIP_TRY(hipMalloc(&d, sizeof(uint64_t)));
     hipError_t e = hipMemset(d, 0, sizeof(uint64_t));
-    int rc = e == hipSuccess ? launch_selftest_recip(n, seed, (unsigned long long*)d, nullptr) : hip_fail(e, "hipMemset");
+    int rc = e == hipSuccess ? launch(n, seed, (unsigned long long*)d, nullptr) : hip_fail(e, "hipMemset");
     if (rc == MF_OK) rc = hip_fail(hipMemcpy(mismatches, d, sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy");
     (void)hipFree(d);
     return rc;
+}
+
+int mf_selftest_sqrt(uint64_t n, uint64_t seed, uint64_t* mismatches)
+{
+    if (!mismatches) { set_error("mf_selftest_sqrt: null"); return MF_ERR_INVALID_ARG; }
+    return run_selftest(launch_selftest_sqrt, n, seed, mismatches);
+}
+
+int mf_selftest_recip(uint64_t n, uint64_t seed, uint64_t* mismatches)
+{
+    if (!mismatches) { set_error("mf_selftest_recip: null"); return MF_ERR_INVALID_ARG; }
+    return run_selftest(launch_selftest_recip, n, seed, mismatches);
 }
 
 // ---- host-buffer wrappers ------------------------------------------------------------------------

@@ -81,6 +81,11 @@ int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigne
 size_t crop_resize_workspace_bytes(int W, int H);
 int launch_crop_resize(const uint8_t* frames, uint8_t* out, int n, int W, int H, int left, int top, int right,
                        int bottom, void* work, hipStream_t st);
+size_t vertex_motion_workspace_bytes(int total_features, int max_per_pair, int P, int R, int C);
+int launch_vertex_motion(const double* early, const double* late, const int32_t* offsets, const double* hom, int P,
+                         int total_features, int max_per_pair, int W, int H, int R, int C, int ell_rows, int ell_cols,
+                         float* vel, double* disp, void* work, int32_t* status, hipStream_t st);
+int launch_selftest_sqrt(unsigned long long n, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t st);
 int launch_crop_reduce(const int32_t* crop, int n, int W, int H, int32_t* bounds, hipStream_t st);
 
 }  // namespace mf

@@ -122,3 +122,22 @@ def mesh_cropping_ratio_and_distortion(frame_width, frame_height, mesh_rows, mes
         mags = np.sort(np.abs(np.linalg.eigvals(affine)))
         distortions[f] = mags[-2] / mags[-1]                                              # mfs.py:1209
     return np.mean(ratios), np.min(distortions)                                           # mfs.py:1212
+
+
+def pack_features(features_by_pair):
+    """[(early, late), ...] as `_get_matched_features_and_homography` returns them (mfs.py:528: (K, 1, 2) arrays, or
+    None when too few features were found) -> (early (K_total, 2) float64, late, offsets (P+1,) int32, max per pair).
+    float32 inputs are widened exactly; the reference's own flow already carries float64 (mfs.py:578)."""
+    early, late = [], []
+    for pair in features_by_pair:
+        e, l = pair[0], pair[1]
+        e = np.zeros((0, 2)) if e is None else np.asarray(e, dtype=np.float64).reshape(-1, 2)
+        l = np.zeros((0, 2)) if l is None else np.asarray(l, dtype=np.float64).reshape(-1, 2)
+        if e.shape != l.shape:
+            raise ValueError('early and late features of a pair must have the same shape')
+        early.append(e)
+        late.append(l)
+    counts = [len(e) for e in early]
+    offsets = np.cumsum([0] + counts).astype(np.int32)
+    cat = lambda parts: np.ascontiguousarray(np.concatenate(parts)) if parts else np.zeros((0, 2))
+    return cat(early), cat(late), offsets, max(counts, default=0)

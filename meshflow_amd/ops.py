@@ -124,3 +124,32 @@ def crop_resize(frames, bounds, out=None):
     work = torch.empty(_lib_.mf_crop_resize_workspace_bytes(W, H), dtype=torch.uint8, device=frames.device)
     _lib.check(_lib_.mf_crop_resize_u8c3(_ptr(frames), _ptr(out), n, W, H, left, top, right, bottom, _ptr(work), _stream()))
     return out
+
+
+def vertex_motion(early, late, offsets, homographies, max_per_pair, W, H, R, C, ellipse_rows, ellipse_cols):
+    """Vertex velocities and their running sum from matched features (mfs.py:236-452 after the tracker).
+    early/late: (K_total, 2) float64 device tensors; offsets: (P+1,) int32; homographies: (P, 3, 3) float64.
+    Returns (displacements (P+1, R+1, C+1, 2) float64, velocities (P, R+1, C+1, 2) float32, status (1,) int32);
+    status != 0 means the reference's math.sqrt would have raised (mfs.py:444) -- see `vertex_motion_check`."""
+    _need(early, torch.float64, 'early')
+    _need(late, torch.float64, 'late')
+    _need(offsets, torch.int32, 'offsets')
+    _need(homographies, torch.float64, 'homographies')
+    P = offsets.numel() - 1
+    K = early.shape[0]
+    if early.shape != late.shape or early.dim() != 2 or early.shape[1] != 2 or P < 0 or homographies.numel() != 9 * P:
+        raise ValueError('features must be (K, 2) pairs with (P+1,) offsets and (P, 3, 3) homographies')
+    dev = early.device
+    vel = torch.empty((P, R + 1, C + 1, 2), dtype=torch.float32, device=dev)
+    disp = torch.empty((P + 1, R + 1, C + 1, 2), dtype=torch.float64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    work = torch.empty(_lib_.mf_vertex_motion_workspace_bytes(K, int(max_per_pair), P, R, C), dtype=torch.uint8, device=dev)
+    _lib.check(_lib_.mf_vertex_motion_f64(_ptr(early), _ptr(late), _ptr(offsets), _ptr(homographies), P, K,
+                                          int(max_per_pair), W, H, R, C, int(ellipse_rows), int(ellipse_cols),
+                                          _ptr(vel), _ptr(disp), _ptr(work), _ptr(status), _stream()))
+    return disp, vel, status
+
+
+def vertex_motion_check(status):
+    if int(status.item()):
+        raise ValueError('math domain error')          # what math.sqrt raises at mfs.py:444

@@ -175,6 +175,39 @@ class MeshFlowStabilizer:
         right, bottom = crop[:, 2].min(), crop[:, 3].min()
         return list(out), (np.int64(left), np.int64(top), np.int64(right), np.int64(bottom))
 
+    def _get_unstabilized_vertex_displacements_from_features(self, num_frames, frame_width, frame_height,
+                                                             features_by_pair, homographies):
+        """mfs.py:236-284 with the tracker's outputs injected: `features_by_pair[t]` = (early_features,
+        late_features) of frames t, t+1 as `_get_matched_features_and_homography` returns them (mfs.py:455-528),
+        `homographies` (F, 3, 3) with the identity last (mfs.py:274).  Returns the reference's tuple
+        (vertex_unstabilized_displacements_by_frame_index float64 (F, R+1, C+1, 2), homographies)."""
+        disp, _ = self._vertex_motion_from_features(num_frames, frame_width, frame_height, features_by_pair, homographies)
+        return disp, np.asarray(homographies, dtype=np.float64)
+
+    def _get_unstabilized_vertex_velocities_from_features(self, frame_width, frame_height, early_features,
+                                                          late_features, early_to_late_homography):
+        """mfs.py:287-362 after the tracker call at :316: float32 (R+1, C+1, 2) velocities of one frame pair."""
+        hom = np.asarray(early_to_late_homography, dtype=np.float64).reshape(1, 3, 3)
+        _, vel = self._vertex_motion_from_features(2, frame_width, frame_height, [(early_features, late_features)], hom)
+        return vel[0]
+
+    def _vertex_motion_from_features(self, num_frames, frame_width, frame_height, features_by_pair, homographies):
+        import torch
+        from . import ops
+        if len(features_by_pair) != num_frames - 1:
+            raise ValueError('features_by_pair must hold num_frames - 1 (early, late) pairs')
+        hom = np.ascontiguousarray(np.asarray(homographies, dtype=np.float64)[:num_frames - 1]).reshape(-1, 3, 3)
+        if hom.shape[0] != num_frames - 1:
+            raise ValueError('homographies must hold at least num_frames - 1 matrices')
+        early, late, offsets, kmax = host.pack_features(features_by_pair)
+        dev = self._torch_device()
+        d_disp, d_vel, status = ops.vertex_motion(
+            torch.from_numpy(early).to(dev), torch.from_numpy(late).to(dev), torch.from_numpy(offsets).to(dev),
+            torch.from_numpy(hom).to(dev), kmax, frame_width, frame_height, self.mesh_row_count, self.mesh_col_count,
+            self.feature_ellipse_row_count, self.feature_ellipse_col_count)
+        ops.vertex_motion_check(status)
+        return d_disp.cpu().numpy(), d_vel.cpu().numpy()
+
     def _crop_frames(self, uncropped_frames, crop_boundaries):
         """mfs.py:1111-1157: crop to the inclusive bounds and resize back to (W, H) (cv2.resize, INTER_LINEAR)."""
         import torch
