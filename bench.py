@@ -180,6 +180,36 @@ def main():
         torch.cuda.synchronize()
         resize_ms = r0.elapsed_time(r1) / 3
         del scratch
+    # The row before the path, also outside the timed region: matched features -> vertex displacements
+    # (mfs.py:236-452 after the tracker), synthetic features for the same number of frame pairs.
+    motion_row = None
+    if rank == 0:
+        from meshflow_amd import host as mfhost
+        feats = synthetic.features(F, H, W, hom, seed=seed, per_pair=(1500, 2500))
+        early, late, offsets, kmax = mfhost.pack_features(feats)
+        d_in = [torch.from_numpy(a).to(device) for a in (early, late, offsets, np.ascontiguousarray(hom[:-1]))]
+        ops.vertex_motion(*d_in, kmax, W, H, R, C, stab.feature_ellipse_row_count, stab.feature_ellipse_col_count)
+        m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        m0.record()
+        for _ in range(3):
+            _, _, status = ops.vertex_motion(*d_in, kmax, W, H, R, C, stab.feature_ellipse_row_count,
+                                             stab.feature_ellipse_col_count)
+        m1.record()
+        torch.cuda.synchronize()
+        ops.vertex_motion_check(status)
+        motion_ms = m0.elapsed_time(m1) / 3
+        motion_row = {'kernels': 'feature_prep + bitonic sort + vertex_median + median_blur + accumulate',
+                      'avg_ms': motion_ms, 'frame_pairs': F - 1, 'features': int(early.shape[0]),
+                      'pairs_per_s': (F - 1) / (motion_ms * 1e-3),
+                      'note': 'outside the timed region; latency/ALU bound (no meaningful HBM roofline: 14 MB of features)'}
+        del d_in
+        if world == 1 and args.cpu_frames > 0:
+            from oracle import clib
+            threads = clib.set_threads(min(usable_cpus(), 32))
+            t1 = time.perf_counter()
+            clib.vertex_motion(W, H, R, C, stab.feature_ellipse_row_count, stab.feature_ellipse_col_count, feats, hom, openmp=True)
+            motion_row['cpu_port_pairs_per_s'] = (F - 1) / (time.perf_counter() - t1)
+            motion_row['cpu_port_threads'] = threads
     gather_ms = None
     if args.gather and world > 1:
         barrier()
@@ -222,6 +252,8 @@ def main():
                                                    'achieved': algo_bytes / (resize_ms * 1e-3) / 1e9, 'unit': 'GB/s',
                                                    'frac': algo_bytes / (resize_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
                                                    'note': 'outside the timed region; algorithmic bytes 2*H*W*3 per frame'}}
+        if motion_row is not None:
+            result.setdefault('next_rows', {})['vertex_motion'] = motion_row
         if gather_ms is not None:
             result['gather_to_rank0_ms'] = gather_ms
         if world == 1 and args.cpu_frames > 0:
