@@ -83,39 +83,74 @@ class MeshFlowStabilizer:
 
     def stabilize_clip(self, unstabilized_frames, vertex_unstabilized_displacements_by_frame_index, homographies,
                        adaptive_weights_definition=ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL, crop=False,
-                       keep_uncropped=True):
+                       keep_uncropped=True, chunk_frames=16, io_threads=3):
         """The hot path of `stabilize` (mfs.py:150-159, 162) on in-memory inputs, with ONE host->device and ONE
         device->host pass over the frames (the two private methods below each pay their own, like any drop-in
-        for NumPy-in / NumPy-out methods must).
+        for NumPy-in / NumPy-out methods must).  The passes are chunked and overlapped with each other and with
+        the kernels (`pipeline.py`): frames go up `chunk_frames` at a time on `io_threads` copy threads, each
+        chunk is warped as soon as it has landed and comes back while later chunks are still going up.
 
         Returns (stabilized_frames list, crop_boundaries, vertex_stabilized_displacements, stability_score)
         and, with crop=True, a fifth item: the cropped + resized frames (`_crop_frames`, mfs.py:159), produced
         on the device from the stabilized frames; keep_uncropped=False then skips copying the uncropped
         stabilized frames back (the reference only uses the cropped ones afterwards) and returns None for them."""
         import torch
-        from . import ops
+        from . import ops, pipeline
         self._check_definition(adaptive_weights_definition)
         num_frames = len(unstabilized_frames)
         dev = self._torch_device()
         unstab = np.ascontiguousarray(vertex_unstabilized_displacements_by_frame_index, dtype=np.float64)
         self._check_mesh_shape(unstab, num_frames)
-        stack = self._as_frame_stack(unstabilized_frames, num_frames)
-        frame_height, frame_width = stack.shape[1:3]
-        d_unstab = torch.from_numpy(unstab).to(dev)
-        d_stab = self._stabilized_vertex_displacements_device(d_unstab, frame_width, frame_height,
-                                                              adaptive_weights_definition, homographies)
-        d_frames = torch.from_numpy(stack).to(dev)
-        d_out, d_crop = self._stabilized_frames_device(d_frames, d_unstab, d_stab)
-        crop_h = d_crop.cpu().numpy()
-        bounds = (np.int64(crop_h[:, 0].max()), np.int64(crop_h[:, 1].max()),
-                  np.int64(crop_h[:, 2].min()), np.int64(crop_h[:, 3].min()))                 # mfs.py:1103-1106
-        stab = d_stab.cpu().numpy()
-        score = self._compute_stability_score(num_frames, stab)
+        clip = pipeline.HostClip(unstabilized_frames, num_frames)
+        H, W = clip.height, clip.width
+        R, C = self.mesh_row_count, self.mesh_col_count
+        ranges = pipeline.chunk_ranges(num_frames, chunk_frames)
+        io = pipeline.ChunkedTransfer(dev, io_threads, io_threads)
+        try:
+            d_frames = torch.empty((num_frames, H, W, 3), dtype=torch.uint8, device=dev)
+            d_out = torch.empty_like(d_frames)
+            compute = torch.cuda.current_stream(dev)
+            allocated = torch.cuda.Event()
+            allocated.record(compute)
+            uploads = io.upload_all(clip, d_frames, ranges, allocated)      # copies start now, on their own streams
+            d_unstab = torch.from_numpy(unstab).to(dev)
+            d_stab = self._stabilized_vertex_displacements_device(d_unstab, W, H, adaptive_weights_definition, homographies)
+            d_crop = torch.empty((num_frames, 4), dtype=torch.int32, device=dev)
+            want_uncropped = keep_uncropped or not crop
+            out_host = np.empty((num_frames, H, W, 3), dtype=np.uint8) if want_uncropped else None
+            tables = {}
+            for k, (i0, i1) in enumerate(ranges):
+                compute.wait_event(uploads[k].result())
+                table = tables.get(i1 - i0)
+                table = ops.cell_table(d_unstab[i0:i1], d_stab[i0:i1], W, H, R, C, table=table, reset_status=False)
+                tables[i1 - i0] = table
+                ops.warp(d_frames[i0:i1], table, self.color_outside_image_area_bgr, out=d_out[i0:i1])
+                d_crop[i0:i1].copy_(table.crop)
+                if want_uncropped:
+                    done = torch.cuda.Event()
+                    done.record(compute)
+                    io.download(d_out[i0:i1], out_host[i0:i1], done, k)
+            bounds_h = ops.crop_reduce(d_crop, W, H).cpu().numpy()                              # mfs.py:1103-1106
+            for table in tables.values():
+                table.check()
+            bounds = tuple(np.int64(v) for v in bounds_h)
+            stab = d_stab.cpu().numpy()
+            score = self._compute_stability_score(num_frames, stab)
+            cropped_host = None
+            if crop:
+                d_cropped = ops.crop_resize(d_out, bounds, out=d_frames)    # the input stack is no longer needed
+                cropped_host = np.empty((num_frames, H, W, 3), dtype=np.uint8)
+                done = torch.cuda.Event()
+                done.record(compute)
+                for k, (i0, i1) in enumerate(ranges):
+                    io.download(d_cropped[i0:i1], cropped_host[i0:i1], done, k)
+            io.finish()
+        finally:
+            io.close()
+        frames = list(out_host) if want_uncropped else None
         if not crop:
-            return list(d_out.cpu().numpy()), bounds, stab, score
-        d_cropped = ops.crop_resize(d_out, bounds, out=d_frames)        # the input stack is no longer needed
-        frames = list(d_out.cpu().numpy()) if keep_uncropped else None
-        return frames, bounds, stab, score, list(d_cropped.cpu().numpy())
+            return frames, bounds, stab, score
+        return frames, bounds, stab, score, list(cropped_host)
 
     @staticmethod
     def _as_frame_stack(frames, num_frames):

@@ -282,6 +282,41 @@ def test_stabilizer_class_end_to_end(dev):
     np.testing.assert_array_equal(np.stack(res[4]), np.stack(mo.crop_frames(list(want), bounds)))
 
 
+@pytest.mark.parametrize('chunk_frames,io_threads', [(1, 1), (7, 2), (5, 4), (64, 3)])
+def test_chunked_staging_gives_the_same_clip(dev, chunk_frames, io_threads):
+    """pipeline.py: any chunking / thread count, list or array input, every output identical (ragged last chunk,
+    more threads than chunks, one frame per chunk)."""
+    from meshflow_amd import synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    from oracle import clib, meshflow_oracle as mo
+    F, H, W, R, C = 23, 72, 100, 3, 5
+    frames, disp, hom = synthetic.clip(F, H, W, R, C, seed=9, kind='noise', jitter_sigma=0.7)
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=4, optimization_num_iterations=15)
+    separate = [f.copy() for f in frames]
+    for inp in (separate, frames):
+        got = s.stabilize_clip(inp, disp, hom, crop=True, chunk_frames=chunk_frames, io_threads=io_threads)
+        out, bounds, stab, score, cropped = got
+        want, want_crop, _ = clib.warp_clip(frames, R, C, disp, stab)
+        np.testing.assert_array_equal(np.stack(out), want)
+        assert tuple(int(v) for v in bounds) == (want_crop[:, 0].max(), want_crop[:, 1].max(),
+                                                 want_crop[:, 2].min(), want_crop[:, 3].min())
+        np.testing.assert_array_equal(np.stack(cropped), np.stack(mo.crop_frames(list(want), bounds)))
+
+
+def test_chunked_staging_reports_a_bad_frame(dev):
+    from meshflow_amd import synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    F, H, W, R, C = 9, 48, 64, 2, 2
+    frames, disp, hom = synthetic.clip(F, H, W, R, C, seed=1)
+    bad = [f.copy() for f in frames]
+    bad[6] = np.zeros((H, W + 1, 3), np.uint8)
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=2, optimization_num_iterations=5)
+    with pytest.raises(ValueError, match='shape'):
+        s.stabilize_clip(bad, disp, hom, chunk_frames=2, io_threads=2)
+    out, *_ = s.stabilize_clip([f.copy() for f in frames], disp, hom, chunk_frames=2, io_threads=2)    # still usable
+    assert len(out) == F
+
+
 def test_warp_host_wrapper(dev):
     from meshflow_amd import _lib
     from oracle import clib
