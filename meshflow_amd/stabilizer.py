@@ -103,45 +103,22 @@ class MeshFlowStabilizer:
         self._check_mesh_shape(unstab, num_frames)
         clip = pipeline.HostClip(unstabilized_frames, num_frames)
         H, W = clip.height, clip.width
-        R, C = self.mesh_row_count, self.mesh_col_count
-        ranges = pipeline.chunk_ranges(num_frames, chunk_frames)
         io = pipeline.ChunkedTransfer(dev, io_threads, io_threads)
         try:
-            d_frames = torch.empty((num_frames, H, W, 3), dtype=torch.uint8, device=dev)
-            d_out = torch.empty_like(d_frames)
-            compute = torch.cuda.current_stream(dev)
-            allocated = torch.cuda.Event()
-            allocated.record(compute)
-            uploads = io.upload_all(clip, d_frames, ranges, allocated)      # copies start now, on their own streams
             d_unstab = torch.from_numpy(unstab).to(dev)
-            d_stab = self._stabilized_vertex_displacements_device(d_unstab, W, H, adaptive_weights_definition, homographies)
-            d_crop = torch.empty((num_frames, 4), dtype=torch.int32, device=dev)
             want_uncropped = keep_uncropped or not crop
-            out_host = np.empty((num_frames, H, W, 3), dtype=np.uint8) if want_uncropped else None
-            tables = {}
-            for k, (i0, i1) in enumerate(ranges):
-                compute.wait_event(uploads[k].result())
-                table = tables.get(i1 - i0)
-                table = ops.cell_table(d_unstab[i0:i1], d_stab[i0:i1], W, H, R, C, table=table, reset_status=False)
-                tables[i1 - i0] = table
-                ops.warp(d_frames[i0:i1], table, self.color_outside_image_area_bgr, out=d_out[i0:i1])
-                d_crop[i0:i1].copy_(table.crop)
-                if want_uncropped:
-                    done = torch.cuda.Event()
-                    done.record(compute)
-                    io.download(d_out[i0:i1], out_host[i0:i1], done, k)
-            bounds_h = ops.crop_reduce(d_crop, W, H).cpu().numpy()                              # mfs.py:1103-1106
-            for table in tables.values():
-                table.check()
-            bounds = tuple(np.int64(v) for v in bounds_h)
+            staged = self._start_upload(io, clip, chunk_frames)            # copies start now, on their own streams
+            d_stab = self._stabilized_vertex_displacements_device(d_unstab, W, H, adaptive_weights_definition, homographies)
+            out_host, d_out, bounds = self._warp_staged(io, staged, d_unstab, d_stab, want_uncropped)
             stab = d_stab.cpu().numpy()
             score = self._compute_stability_score(num_frames, stab)
             cropped_host = None
             if crop:
+                d_frames, ranges = staged[0], staged[1]
                 d_cropped = ops.crop_resize(d_out, bounds, out=d_frames)    # the input stack is no longer needed
                 cropped_host = np.empty((num_frames, H, W, 3), dtype=np.uint8)
                 done = torch.cuda.Event()
-                done.record(compute)
+                done.record(torch.cuda.current_stream(dev))
                 for k, (i0, i1) in enumerate(ranges):
                     io.download(d_cropped[i0:i1], cropped_host[i0:i1], done, k)
             io.finish()
@@ -152,15 +129,45 @@ class MeshFlowStabilizer:
             return frames, bounds, stab, score
         return frames, bounds, stab, score, list(cropped_host)
 
-    @staticmethod
-    def _as_frame_stack(frames, num_frames):
-        if isinstance(frames, np.ndarray):
-            stack = np.ascontiguousarray(frames, dtype=np.uint8)
-        else:
-            stack = np.stack([np.asarray(f, dtype=np.uint8) for f in frames])
-        if stack.ndim != 4 or stack.shape[0] != num_frames or stack.shape[3] != 3:
-            raise ValueError('frames must be num_frames arrays of shape (H, W, 3)')
-        return stack
+    def _start_upload(self, io, clip, chunk_frames):
+        """Allocates the device clip and starts the chunked upload; returns (d_frames, ranges, upload futures, clip)."""
+        import torch
+        from . import pipeline
+        dev = io.device
+        ranges = pipeline.chunk_ranges(clip.num_frames, chunk_frames)
+        d_frames = torch.empty((clip.num_frames, clip.height, clip.width, 3), dtype=torch.uint8, device=dev)
+        allocated = torch.cuda.Event()
+        allocated.record(torch.cuda.current_stream(dev))
+        return d_frames, ranges, io.upload_all(clip, d_frames, ranges, allocated), clip
+
+    def _warp_staged(self, io, staged, d_unstab, d_stab, want_host):
+        """Warps every chunk as it lands and (want_host) queues its way back.  Returns (host frames or None,
+        device frames, clip-level crop bounds as np.int64 (left, top, right, bottom), mfs.py:1103-1106)."""
+        import torch
+        from . import ops
+        d_frames, ranges, uploads, clip = staged
+        dev = io.device
+        num_frames, H, W = clip.num_frames, clip.height, clip.width
+        R, C = self.mesh_row_count, self.mesh_col_count
+        d_out = torch.empty_like(d_frames)
+        d_crop = torch.empty((num_frames, 4), dtype=torch.int32, device=dev)
+        out_host = np.empty((num_frames, H, W, 3), dtype=np.uint8) if want_host else None
+        tables = {}
+        compute = torch.cuda.current_stream(dev)
+        for k, (i0, i1) in enumerate(ranges):
+            compute.wait_event(uploads[k].result())
+            table = ops.cell_table(d_unstab[i0:i1], d_stab[i0:i1], W, H, R, C, table=tables.get(i1 - i0), reset_status=False)
+            tables[i1 - i0] = table
+            ops.warp(d_frames[i0:i1], table, self.color_outside_image_area_bgr, out=d_out[i0:i1])
+            d_crop[i0:i1].copy_(table.crop)
+            if want_host:
+                done = torch.cuda.Event()
+                done.record(compute)
+                io.download(d_out[i0:i1], out_host[i0:i1], done, k)
+        bounds_h = ops.crop_reduce(d_crop, W, H).cpu().numpy()
+        for table in tables.values():
+            table.check()
+        return out_host, d_out, tuple(np.int64(v) for v in bounds_h)
 
     # ------------------------------------------------------------------------------------------
     # drop-in boundary, host buffers (same signatures as the reference)
@@ -187,28 +194,26 @@ class MeshFlowStabilizer:
 
     def _get_stabilized_frames_and_crop_boundaries(self, num_frames, unstabilized_frames,
                                                    vertex_unstabilized_displacements_by_frame_index,
-                                                   vertex_stabilized_displacements_by_frame_index):
+                                                   vertex_stabilized_displacements_by_frame_index,
+                                                   chunk_frames=16, io_threads=3):
         """mfs.py:909-1108.  Returns (list of F uint8 (H, W, 3) arrays, (left, top, right, bottom))."""
         import torch
+        from . import pipeline
         dev = self._torch_device()
         unstab = np.ascontiguousarray(vertex_unstabilized_displacements_by_frame_index, dtype=np.float64)
         stab = np.ascontiguousarray(vertex_stabilized_displacements_by_frame_index, dtype=np.float64)
         self._check_mesh_shape(unstab, num_frames)
         self._check_mesh_shape(stab, num_frames)
-        if isinstance(unstabilized_frames, np.ndarray):
-            stack = np.ascontiguousarray(unstabilized_frames, dtype=np.uint8)
-        else:
-            stack = np.stack([np.asarray(f, dtype=np.uint8) for f in unstabilized_frames])
-        if stack.ndim != 4 or stack.shape[0] != num_frames or stack.shape[3] != 3:
-            raise ValueError('unstabilized_frames must be num_frames arrays of shape (H, W, 3)')
-        d_frames = torch.from_numpy(stack).to(dev)
-        d_out, d_crop = self._stabilized_frames_device(d_frames, torch.from_numpy(unstab).to(dev),
-                                                       torch.from_numpy(stab).to(dev))
-        out = d_out.cpu().numpy()
-        crop = d_crop.cpu().numpy()
-        left, top = crop[:, 0].max(), crop[:, 1].max()                                      # mfs.py:1103-1106
-        right, bottom = crop[:, 2].min(), crop[:, 3].min()
-        return list(out), (np.int64(left), np.int64(top), np.int64(right), np.int64(bottom))
+        clip = pipeline.HostClip(unstabilized_frames, num_frames)
+        io = pipeline.ChunkedTransfer(dev, io_threads, io_threads)
+        try:
+            staged = self._start_upload(io, clip, chunk_frames)
+            out_host, _, bounds = self._warp_staged(io, staged, torch.from_numpy(unstab).to(dev),
+                                                    torch.from_numpy(stab).to(dev), True)
+            io.finish()
+        finally:
+            io.close()
+        return list(out_host), bounds
 
     def _get_unstabilized_vertex_displacements_from_features(self, num_frames, frame_width, frame_height,
                                                              features_by_pair, homographies):
@@ -243,17 +248,29 @@ class MeshFlowStabilizer:
         ops.vertex_motion_check(status)
         return d_disp.cpu().numpy(), d_vel.cpu().numpy()
 
-    def _crop_frames(self, uncropped_frames, crop_boundaries):
-        """mfs.py:1111-1157: crop to the inclusive bounds and resize back to (W, H) (cv2.resize, INTER_LINEAR)."""
+    def _crop_frames(self, uncropped_frames, crop_boundaries, chunk_frames=16, io_threads=3):
+        """mfs.py:1111-1157: crop to the inclusive bounds and resize back to (W, H) (cv2.resize, INTER_LINEAR).
+        The bounds are known up front, so upload, resize and download of the chunks all overlap."""
         import torch
-        from . import ops
+        from . import ops, pipeline
         dev = self._torch_device()
-        if isinstance(uncropped_frames, np.ndarray):
-            stack = np.ascontiguousarray(uncropped_frames, dtype=np.uint8)
-        else:
-            stack = np.stack([np.asarray(f, dtype=np.uint8) for f in uncropped_frames])
-        out = ops.crop_resize(torch.from_numpy(stack).to(dev), crop_boundaries)
-        return list(out.cpu().numpy())
+        clip = pipeline.HostClip(uncropped_frames, len(uncropped_frames))
+        io = pipeline.ChunkedTransfer(dev, io_threads, io_threads)
+        try:
+            d_frames, ranges, uploads, _ = self._start_upload(io, clip, chunk_frames)
+            d_out = torch.empty_like(d_frames)
+            out_host = np.empty((clip.num_frames, clip.height, clip.width, 3), dtype=np.uint8)
+            compute = torch.cuda.current_stream(dev)
+            for k, (i0, i1) in enumerate(ranges):
+                compute.wait_event(uploads[k].result())
+                ops.crop_resize(d_frames[i0:i1], crop_boundaries, out=d_out[i0:i1])
+                done = torch.cuda.Event()
+                done.record(compute)
+                io.download(d_out[i0:i1], out_host[i0:i1], done, k)
+            io.finish()
+        finally:
+            io.close()
+        return list(out_host)
 
     def compute_scores(self, frame_width, frame_height, vertex_unstabilized_displacements_by_frame_index,
                        vertex_stabilized_displacements_by_frame_index, crop_boundaries):
