@@ -67,19 +67,67 @@ class MeshFlowStabilizer:
                 '`MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_CONSTANT_LOW`.')
 
     def stabilize(self, input_path, output_path, adaptive_weights_definition=ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL):
-        """Same contract as mfs.py:102-169.  The stages outside the accelerated path (video I/O,
-        feature tracking, feature-based metrics) are OpenCV calls in the reference and need `cv2`."""
+        """Same contract as mfs.py:102-169: reads `input_path`, writes the stabilized video to `output_path`, returns
+        (cropping_ratio, distortion_score, stability_score).  Video I/O, the FAST/LK/RANSAC tracker and the two
+        feature-based scores are OpenCV calls in the reference and stay OpenCV calls here (`frontend_cv2.py`, needs
+        `cv2`); everything between the tracker and the encoder runs on the MI355X."""
         self._check_definition(adaptive_weights_definition)
-        try:
-            import cv2  # noqa: F401
-        except ImportError as e:
-            raise ImportError(
-                'MeshFlowStabilizer.stabilize(path, path) needs OpenCV (cv2) for video decode/encode and the '
-                'FAST/LK/RANSAC front-end, which are outside the MI355X path. Use stabilize_clip(frames, '
-                'vertex_unstabilized_displacements, homographies) with in-memory inputs instead.') from e
-        raise NotImplementedError(
-            'video I/O and the feature front-end (mfs.py:172-629, 1160-1212, 1290-1322) are not part of this '
-            'build; feed stabilize_clip() from your own decoder/tracker')
+        from . import frontend_cv2
+        cv2 = frontend_cv2.require_cv2()
+        unstabilized_frames, num_frames, frames_per_second, codec = self._get_unstabilized_frames_and_video_features(input_path)
+        disp, homographies = self._get_unstabilized_vertex_displacements_and_homographies(num_frames, unstabilized_frames)
+        _, _, stab, stability_score, cropped_frames = self.stabilize_clip(
+            unstabilized_frames, disp, homographies, adaptive_weights_definition, crop=True, keep_uncropped=False)
+        cropping_ratio, distortion_score = self._compute_cropping_ratio_and_distortion_score(
+            num_frames, unstabilized_frames, cropped_frames)
+        self._write_stabilized_video(output_path, num_frames, frames_per_second, codec, cropped_frames)
+        if self.visualize:
+            frontend_cv2.show_loop(cv2, frames_per_second, unstabilized_frames, cropped_frames)
+        return (cropping_ratio, distortion_score, stability_score)
+
+    # ---- the reference's OpenCV-side helpers, same names, delegating to cv2 (frontend_cv2.py) ----
+
+    def _tracker(self):
+        from . import frontend_cv2
+        return frontend_cv2.Tracker(frontend_cv2.require_cv2(), self.mesh_outlier_subframe_row_count,
+                                    self.mesh_outlier_subframe_col_count,
+                                    self.homography_min_number_corresponding_features)
+
+    def _get_unstabilized_frames_and_video_features(self, input_path):
+        """mfs.py:172-213."""
+        from . import frontend_cv2
+        return frontend_cv2.read_video(frontend_cv2.require_cv2(), input_path)
+
+    def _get_matched_features_and_homography(self, early_frame, late_frame):
+        """mfs.py:455-528."""
+        return self._tracker().track_pair(early_frame, late_frame)
+
+    def _get_unstabilized_vertex_displacements_and_homographies(self, num_frames, unstabilized_frames):
+        """mfs.py:236-284: the tracker on every adjacent frame pair (cv2, host threads), then the accumulation of
+        their features into vertex displacements on the device."""
+        tracked = self._tracker().track_pairs(unstabilized_frames[:-1], unstabilized_frames[1:])
+        homographies = np.empty((num_frames, 3, 3))
+        homographies[-1] = np.identity(3)                                                   # mfs.py:274
+        for t, (_, _, h) in enumerate(tracked):
+            if h is None:      # the reference hands None to cv2.perspectiveTransform (mfs.py:325) and dies in cv2
+                raise ValueError(f'fewer than {self.homography_min_number_corresponding_features} features could be '
+                                 f'tracked from frame {t} to frame {t + 1}')
+            homographies[t] = h
+        frame_height, frame_width = unstabilized_frames[0].shape[:2]
+        return self._get_unstabilized_vertex_displacements_from_features(
+            num_frames, frame_width, frame_height, [(e, l) for e, l, _ in tracked], homographies)
+
+    def _compute_cropping_ratio_and_distortion_score(self, num_frames, unstabilized_frames, cropped_frames):
+        """mfs.py:1160-1212."""
+        from . import frontend_cv2
+        return frontend_cv2.cropping_and_distortion(self._tracker(), unstabilized_frames[:num_frames],
+                                                    cropped_frames[:num_frames])
+
+    def _write_stabilized_video(self, output_path, num_frames, frames_per_second, codec, stabilized_frames):
+        """mfs.py:1290-1322."""
+        from . import frontend_cv2
+        frontend_cv2.write_video(frontend_cv2.require_cv2(), output_path, frames_per_second, codec,
+                                 stabilized_frames[:num_frames])
 
     def stabilize_clip(self, unstabilized_frames, vertex_unstabilized_displacements_by_frame_index, homographies,
                        adaptive_weights_definition=ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL, crop=False,

@@ -1,0 +1,69 @@
+"""`MeshFlowStabilizer.stabilize(input_path, output_path)` end to end: decode -> track -> (device) accumulate, smooth,
+warp, crop -> scores -> encode.  OpenCV's part is played by tests/fake_cv2.py (OpenCV is not installed here), so this
+checks the ORCHESTRATION and the device stages in between, not OpenCV.  Needs an MI355X."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture()
+def cv2_stub(monkeypatch):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fake_cv2
+    fake_cv2.VIDEOS.clear(); fake_cv2.WRITTEN.clear(); fake_cv2.MOTION.clear()
+    monkeypatch.setitem(sys.modules, 'cv2', fake_cv2.module())
+    return fake_cv2
+
+
+def _make_video(fake, path, F=10, H=96, W=128, claimed=None):
+    from meshflow_amd import synthetic
+    frames = [f.copy() for f in synthetic.frames_numpy(F, H, W, seed=4)]
+    for t, f in enumerate(frames):
+        fake.MOTION[id(f)] = (1.5 * np.sin(t), -1.0 * np.cos(2 * t))
+    fake.VIDEOS[path] = dict(frames=frames, fps=30.0, fourcc=0x31637661, claimed=claimed)
+    return frames
+
+
+def test_stabilize_path_to_path(cv2_stub):
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: the -m gpu tests must run on an MI355X')
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    frames = _make_video(cv2_stub, 'in.m4v')
+    s = MeshFlowStabilizer(mesh_row_count=4, mesh_col_count=4, mesh_outlier_subframe_row_count=2,
+                           mesh_outlier_subframe_col_count=2, feature_ellipse_row_count=3, feature_ellipse_col_count=3,
+                           temporal_smoothing_radius=3, optimization_num_iterations=10)
+    ratio, distortion, stability = s.stabilize('in.m4v', 'out.m4v', MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL)
+    rec = cv2_stub.WRITTEN['out.m4v']
+    assert len(rec['frames']) == 10 and rec['fps'] == 30.0 and rec['fourcc'] == 0x31637661 and rec['size'] == (128, 96)
+    assert isinstance(ratio, np.float32) and isinstance(distortion, np.float32) and 0.0 < float(stability) <= 1.0
+
+    # the same result assembled by hand from the public pieces
+    tracked = [s._get_matched_features_and_homography(a, b) for a, b in zip(frames[:-1], frames[1:])]
+    assert all(e.dtype == np.float64 and e.shape[1:] == (1, 2) for e, _, _ in tracked)        # promoted, mfs.py:578
+    hom = np.stack([h for _, _, h in tracked] + [np.identity(3)])
+    disp, _ = s._get_unstabilized_vertex_displacements_from_features(10, 128, 96, [(e, l) for e, l, _ in tracked], hom)
+    assert np.abs(disp[-1]).max() > 0.5
+    _, bounds, stab, score, cropped = s.stabilize_clip(frames, disp, hom, crop=True, keep_uncropped=False)
+    assert score == stability
+    np.testing.assert_array_equal(np.stack(cropped), np.stack(rec['frames']))
+
+
+def test_stabilize_short_video_raises_ioerror(cv2_stub):
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    _make_video(cv2_stub, 'short.m4v', F=5, claimed=8)
+    with pytest.raises(IOError, match='did not have frame 5 of 8'):
+        MeshFlowStabilizer(mesh_row_count=4, mesh_col_count=4).stabilize('short.m4v', 'out.m4v')
+
+
+def test_stabilize_without_trackable_features_raises(cv2_stub):
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    _make_video(cv2_stub, 'in.m4v', F=4)
+    s = MeshFlowStabilizer(mesh_row_count=4, mesh_col_count=4, homography_min_number_corresponding_features=10 ** 6)
+    with pytest.raises(ValueError, match='features could be tracked'):
+        s.stabilize('in.m4v', 'out.m4v')
