@@ -134,3 +134,12 @@ def test_features_to_stabilized_frames_end_to_end(dev):
     assert np.abs(stab - want_stab).max() <= 1e-9          # coefficient set-up differs in the last bits (eigvals)
     want_out, crop, bad = clib.warp_clip(frames, R, C, want_disp, stab)
     assert bad == 0 and np.array_equal(np.stack(out), want_out)
+
+
+def test_randomised_motion_campaign(dev):
+    """tools/fuzz_motion.py: random frame sizes, meshes up to 39x39, ellipses up to 3x the mesh, 0-5000 features per
+    pair incl. points outside the frame, points exactly on vertices / ellipse extremes, repeated residuals."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import fuzz_motion
+    assert fuzz_motion.run(150, 7) == 0
