@@ -100,6 +100,9 @@ def main():
     ap.add_argument('--mode', default='shard', choices=['shard', 'clips'],
                     help='N > 1: "shard" = ONE clip of N x frames sharded by frame range (Jacobi replicated, 16-byte crop '
                          'all-reduce); "clips" = N independent clips, one per GPU, no collective (BASELINE config 5)')
+    ap.add_argument('--as-rank-of', type=int, default=0, metavar='N',
+                    help='single process only: do the work rank 0 of an N-GPU "shard" run does (clip of N x frames, own '
+                         'frame range, replicated Jacobi) without the collective -- predicts weak scaling on one GPU')
     args = ap.parse_args()
 
     import torch
@@ -114,6 +117,9 @@ def main():
     clips_mode = args.mode == 'clips' and world > 1
     if clips_mode:                       # every rank owns a whole clip of its own (seed = rank)
         F, lo, hi = per_gpu, 0, per_gpu
+    elif args.as_rank_of > 1 and world == 1:
+        F = per_gpu * args.as_rank_of
+        lo, hi = host.shard_range(F, args.as_rank_of, 0)
     else:
         F = per_gpu * world
         lo, hi = host.shard_range(F, world, rank)
@@ -252,6 +258,10 @@ def main():
                                                    'achieved': algo_bytes / (resize_ms * 1e-3) / 1e9, 'unit': 'GB/s',
                                                    'frac': algo_bytes / (resize_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
                                                    'note': 'outside the timed region; algorithmic bytes 2*H*W*3 per frame'}}
+        if args.as_rank_of > 1 and world == 1:
+            result['as_rank_of'] = args.as_rank_of
+            result['note'] = (f'PREDICTION, not a measurement of {args.as_rank_of} GPUs: one GPU did rank 0\'s share of a '
+                              f'{args.as_rank_of}-GPU run; value = frames of the whole clip / that time')
         if motion_row is not None:
             result.setdefault('next_rows', {})['vertex_motion'] = motion_row
         if gather_ms is not None:

@@ -280,10 +280,16 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
 //   IN    every edge function is > +1 at all four corners           -> listed, ends the list (it owns the rest)
 //   MIXED otherwise                                                 -> listed, the warp kernel tests per pixel
 // Doing this here costs one lane per footprint instead of a whole wavefront per footprint in the warp kernel.
+//
+// Also the footprint's SOURCE region (mf_common.h, MF_REGION_STAGED): the inverse homography of every listed cell
+// maps the footprint rectangle onto a convex quadrilateral (w > 0 at the four corners), so the bounding box of the
+// mapped corners, widened by the bilinear footprint and a pixel of slack, holds every tap of every pixel whichever
+// listed cell owns it.  If that box fits the staging window and the frame, the warp kernel fetches it once.
 __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __restrict__ edges,
+                                                             const double* __restrict__ records,
                                                              const int32_t* __restrict__ reach,
                                                              const int32_t* __restrict__ grid, int n, int W, int H, int R,
-                                                             int C, FootPlan* __restrict__ plan)
+                                                             int C, FootPlan* __restrict__ plan, uint32_t* __restrict__ regions)
 {
     __shared__ int s_gx[66], s_gy[66];
     if ((int)threadIdx.x <= C) s_gx[threadIdx.x] = grid[threadIdx.x];
@@ -317,6 +323,9 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     bool overflow = false, closed = false;
     const float cxs[2] = { (float)xa, (float)xb }, cys[2] = { (float)ya, (float)yb };
     const float* __restrict__ fedge = edges + (size_t)f * R * C * MF_EDGE_FLOATS;
+    const double* __restrict__ frec = records + (size_t)f * R * C * MF_CELL_DOUBLES;
+    double umin = 1e30, umax = -1e30, vmin = 1e30, vmax = -1e30;
+    bool sane = true;
     for (int r = r_hi; r >= r_lo && !closed && !overflow; --r)
         for (int c = c_hi; c >= c_lo && !closed && !overflow; --c) {
             const int k = r * C + c;
@@ -336,6 +345,16 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
             if (cnt == 8) { overflow = true; break; }
             p.e[cnt++] = (uint16_t)(k | MF_PLAN_VALID | (all_in ? MF_PLAN_IN : 0u));
             if (all_in) closed = true;
+            const double* __restrict__ hi = frec + (size_t)k * MF_CELL_DOUBLES + MF_CELL_OFF_HI;
+            for (int q = 0; q < 4; ++q) {
+                const double cx = (double)cxs[q & 1], cy = (double)cys[q >> 1];
+                const double w = hi[6] * cx + hi[7] * cy + hi[8];
+                sane = sane && w > 0.25 && w < 4.0;                       // (NaN fails)
+                const double iw = 1.0 / w;
+                const double u = (hi[0] * cx + hi[1] * cy + hi[2]) * iw, v = (hi[3] * cx + hi[4] * cy + hi[5]) * iw;
+                umin = fmin(umin, u); umax = fmax(umax, u);
+                vmin = fmin(vmin, v); vmax = fmax(vmax, v);
+            }
         }
     if (overflow) {
         // more than 8 candidates: hand the whole range to the warp kernel instead
@@ -343,6 +362,17 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
         p.e[4] = p.e[5] = p.e[6] = 0; p.e[7] = (uint16_t)MF_PLAN_OVERFLOW;
     }
     plan[gid] = p;
+    uint32_t region = 0;
+    if (sane && cnt > 0 && !overflow && (W & 3) == 0 && 3 * W >= MF_STAGE_PITCH && H > MF_STAGE_ROWS &&
+        umin > -4.0 && vmin > -4.0 && umax < 40000.0 && vmax < 40000.0) {
+        // taps of a pixel at (u, v): columns floor(u) .. floor(u)+1 up to 1/64 px of rounding -> one pixel of slack
+        const int ix_lo = (int)floor(umin) - 1, ix_hi = (int)floor(umax) + 2;
+        const int iy_lo = (int)floor(vmin) - 1, iy_hi = (int)floor(vmax) + 2;
+        const int sx0 = min(max(ix_lo, 0), (3 * W - MF_STAGE_PITCH) / 3), sy0 = min(max(iy_lo, 0), H - MF_STAGE_ROWS - 1);
+        if (ix_lo >= sx0 && ix_hi <= sx0 + MF_STAGE_COLS - 1 && iy_lo >= sy0 && iy_hi <= sy0 + MF_STAGE_ROWS - 1)
+            region = MF_REGION_STAGED | ((uint32_t)sy0 << 15) | (uint32_t)sx0;
+    }
+    regions[gid] = region;
 }
 
 int launch_cell_table(const double* unstab, const double* stab, int n, int W, int H, int R, int C,
@@ -363,8 +393,8 @@ int launch_cell_table(const double* unstab, const double* stab, int n, int W, in
     int rc = hip_fail(hipGetLastError(), "cell_table_kernel launch");
     if (rc != MF_OK) return rc;
     const size_t nplan = plan_count(n, W, H);
-    hipLaunchKernelGGL(footprint_plan_kernel, dim3((unsigned)((nplan + 255) / 256)), dim3(256), 0, st, tv.edges, tv.reach,
-                       tv.grid, n, W, H, R, C, tv.plan);
+    hipLaunchKernelGGL(footprint_plan_kernel, dim3((unsigned)((nplan + 255) / 256)), dim3(256), 0, st, tv.edges, tv.records,
+                       tv.reach, tv.grid, n, W, H, R, C, tv.plan, tv.regions);
     return hip_fail(hipGetLastError(), "footprint_plan_kernel launch");
 }
 

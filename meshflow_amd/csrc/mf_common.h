@@ -29,6 +29,7 @@ inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 //   plan:    n x ceil(H/8) x ceil(W/32) x 16 B    per 32x8-pixel footprint: candidate cells, descending
 //   reach:   n x 4 int32                          per-frame max extent of a box beyond its grid rect
 //   grid:    (C+1) + (R+1) int32                  vertex x / y pixel coordinates
+//   regions: n x ceil(H/8) x ceil(W/32) x 4 B     per footprint: source region the warp kernel stages in LDS
 #define MF_EDGE_FLOATS 12
 #define MF_FOOT_W 32
 #define MF_FOOT_H 8
@@ -40,8 +41,18 @@ inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 #define MF_PLAN_IN 0x8000u
 #define MF_PLAN_OVERFLOW 0xFFFFu
 struct alignas(16) FootPlan { uint16_t e[8]; };
+// Source region of a footprint (uint32): bits 0-14 first source column sx0, bits 15-29 first source row sy0,
+// bit 31 = STAGED: every bilinear tap of every pixel of the footprint lies in columns sx0 .. sx0+MF_STAGE_COLS-1 and
+// rows sy0 .. sy0+MF_STAGE_ROWS-1, and rows sy0 .. sy0+MF_STAGE_ROWS are inside the frame.  The warp kernel then
+// copies MF_STAGE_CHUNKS 16-byte chunks (rows of MF_STAGE_PITCH bytes starting at the dword holding column sx0) into
+// LDS with two global->LDS loads per lane and reads the taps from there.
+#define MF_STAGE_PITCH 160
+#define MF_STAGE_ROWS 12
+#define MF_STAGE_COLS 52
+#define MF_REGION_STAGED 0x80000000u
+#define MF_STAGE_CHUNKS 128            // two 16-byte chunks per lane: 12 rows x 10 chunks + 8 chunks of a 13th row (unused)
 struct TableView {
-    double* records; CellBox* boxes; float* edges; FootPlan* plan; int32_t* reach; int32_t* grid;
+    double* records; CellBox* boxes; float* edges; FootPlan* plan; int32_t* reach; int32_t* grid; uint32_t* regions;
 };
 inline size_t plan_count(int n, int W, int H)
 {
@@ -54,8 +65,8 @@ inline size_t plan_offset(int n, int R, int C)
 }
 inline size_t table_bytes(int n, int W, int H, int R, int C)
 {
-    return plan_offset(n, R, C) + plan_count(n, W, H) * sizeof(FootPlan) + (size_t)n * 4 * sizeof(int32_t) +
-           (size_t)(R + C + 2) * sizeof(int32_t);
+    return plan_offset(n, R, C) + plan_count(n, W, H) * (sizeof(FootPlan) + sizeof(uint32_t)) +
+           (size_t)n * 4 * sizeof(int32_t) + (size_t)(R + C + 2) * sizeof(int32_t);
 }
 inline TableView table_view(void* blob, int n, int W, int H, int R, int C)
 {
@@ -67,6 +78,7 @@ inline TableView table_view(void* blob, int n, int W, int H, int R, int C)
     v.plan = (FootPlan*)((char*)blob + plan_offset(n, R, C));
     v.reach = (int32_t*)(v.plan + plan_count(n, W, H));
     v.grid = v.reach + (size_t)n * 4;
+    v.regions = (uint32_t*)(v.grid + (R + C + 2));
     return v;
 }
 

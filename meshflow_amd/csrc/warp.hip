@@ -219,11 +219,15 @@ __device__ __forceinline__ uint32_t cell_mask_test(const double* __restrict__ re
 __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out,
                                                    const double* __restrict__ records,
                                                    const float* __restrict__ edges,
-                                                   const FootPlan* __restrict__ plan, int n, int W, int H, int R, int C,
+                                                   const FootPlan* __restrict__ plan, const uint32_t* __restrict__ regions,
+                                                   int stage_ok, int n, int W, int H, int R, int C,
                                                    uint32_t border, int32_t* __restrict__ crop)
 {
     // inverse homographies of a footprint's candidate cells, per wavefront: [entry][Hi0..Hi8, pad] (80-byte rows)
     __shared__ __attribute__((aligned(16))) double s_hi[4][8][10];
+    // source region of the footprint, per wavefront: MF_STAGE_ROWS rows of MF_STAGE_PITCH bytes (+ slack for the
+    // third dword of the last tap)
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[4][MF_STAGE_CHUNKS * 16 + 64];
     const int f = blockIdx.z;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps plan/record loads scalar
     const int lane = threadIdx.x & 63;
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
     const double* __restrict__ frec = records + (size_t)f * ncell * MF_CELL_DOUBLES;
     const float* __restrict__ fedge = edges + (size_t)f * ncell * MF_EDGE_FLOATS;
     const uint4* __restrict__ fplan = reinterpret_cast<const uint4*>(plan) + ((size_t)f * nfy * nfx + (blockIdx.x * (TILE_W / FOOT_W) + wave));
+    const uint32_t* __restrict__ fregion = regions + ((size_t)f * nfy * nfx + (blockIdx.x * (TILE_W / FOOT_W) + wave));
 
     int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
     const float fWm1 = (float)(W - 1), fHm1 = (float)(H - 1);
@@ -253,6 +258,30 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
         const int y = ya + (lane >> 3);
         const double yy = (double)y;
         const uint4 pv = fplan[(size_t)(blockIdx.y * FOOTS + q) * nfx];   // wave-uniform: scalar load
+        const uint32_t rg = fregion[(size_t)(blockIdx.y * FOOTS + q) * nfx];
+        // Source region -> LDS, asynchronously (global_load_lds: no VGPRs, no ds_write): lane i fetches the i-th and
+        // (64+i)-th 16-byte chunk of the window (10 chunks = 160 bytes per row), which land at LDS offsets 16 i and
+        // 1024 + 16 i.
+        const bool staged = (rg & MF_REGION_STAGED) != 0 && stage_ok != 0;
+        uint32_t lds_origin = 0;                                          // LDS byte address = 160 iy + 3 ix - lds_origin
+        if (staged) {
+            const uint32_t sx0 = rg & 0x7FFFu, sy0 = (rg >> 15) & 0x7FFFu;
+            const uint32_t bs = (3u * sx0) & ~3u;                         // dword holding the first column
+            const uint32_t row_bytes = 3u * (uint32_t)W;
+            const uint8_t* __restrict__ gbase = src + (size_t)sy0 * row_bytes + bs;
+            // chunk i sits at row i / 10, byte 16 (i % 10) of the window = byte (i / 10) (row_bytes - 160) + 16 i from gbase;
+            // uniform base + opaque 32-bit lane offset keeps the address arithmetic 32-bit (saddr + voffset form)
+            uint32_t o0 = __umul24(((uint32_t)lane * 205u) >> 11, row_bytes - (uint32_t)MF_STAGE_PITCH) + ((uint32_t)lane << 4);
+            uint32_t o1 = __umul24((((uint32_t)lane + 64u) * 205u) >> 11, row_bytes - (uint32_t)MF_STAGE_PITCH) +
+                          (((uint32_t)lane << 4) + 1024u);
+            asm("" : "+v"(o0));
+            asm("" : "+v"(o1));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o0),
+                                             (__attribute__((address_space(3))) void*)&s_src[wave][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o1),
+                                             (__attribute__((address_space(3))) void*)&s_src[wave][1024], 16, 0, 0);
+            lds_origin = sy0 * (uint32_t)MF_STAGE_PITCH + bs;
+        }
 
         // Source coordinates of the lane's 4 pixels; (W+1, H+1) = "no cell covers it" (mfs.py:983-984).
         float u[4], v[4];
@@ -399,18 +428,36 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
         // (u >= 2 - 1/64 and u < W - 2, same for v).
         const bool deep = dxm <= (uint32_t)(32 * (W - 3) + 31 - 64) && dym <= (uint32_t)(32 * (H - 3) + 31 - 64);
         uint32_t px[4];
+        if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the region has landed in LDS
         if (__ballot(active && !deep) == 0) {
             // fast path (wave-uniform): every pixel of the footprint samples the deep interior
             if (!active) continue;
-            const uint8_t* __restrict__ src1 = src + 3u * (uint32_t)W;   // row iy + 1
             uint2 a[4], b[4];
+            if (staged) {
+                // taps from the staged region: three dwords around byte 160 iy + 3 ix of each of the two rows,
+                // shifted down by the byte misalignment (v_alignbyte takes the low two bits of the address)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // ix = sx >> 5 = bits[5..21] (0x4B400000 >> 5 has no low 17 bits), same for iy
-                const uint32_t t = umad24(__builtin_amdgcn_ubfe(by[j], 5, 17), (uint32_t)W, __builtin_amdgcn_ubfe(bx[j], 5, 17));
-                const uint32_t o = t + (t << 1);
-                __builtin_memcpy(&a[j], src + o, 8);
-                __builtin_memcpy(&b[j], src1 + o, 8);
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t at = umad24(__builtin_amdgcn_ubfe(by[j], 5, 17), (uint32_t)MF_STAGE_PITCH,
+                                               umad24(__builtin_amdgcn_ubfe(bx[j], 5, 17), 3u, 0u - lds_origin));
+                    const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(&s_src[wave][at & ~3u]);
+                    const uint32_t t0 = p[0], t1 = p[1], t2 = p[2];
+                    const uint32_t u0 = p[MF_STAGE_PITCH / 4], u1 = p[MF_STAGE_PITCH / 4 + 1], u2 = p[MF_STAGE_PITCH / 4 + 2];
+                    a[j].x = __builtin_amdgcn_alignbyte(t1, t0, at);
+                    a[j].y = __builtin_amdgcn_alignbyte(t2, t1, at);
+                    b[j].x = __builtin_amdgcn_alignbyte(u1, u0, at);
+                    b[j].y = __builtin_amdgcn_alignbyte(u2, u1, at);
+                }
+            } else {
+                const uint8_t* __restrict__ src1 = src + 3u * (uint32_t)W;   // row iy + 1
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // ix = sx >> 5 = bits[5..21] (0x4B400000 >> 5 has no low 17 bits), same for iy
+                    const uint32_t t = umad24(__builtin_amdgcn_ubfe(by[j], 5, 17), (uint32_t)W, __builtin_amdgcn_ubfe(bx[j], 5, 17));
+                    const uint32_t o = t + (t << 1);
+                    __builtin_memcpy(&a[j], src + o, 8);
+                    __builtin_memcpy(&b[j], src1 + o, 8);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -545,7 +592,9 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
         return MF_ERR_INVALID_ARG;
     }
     const dim3 grid((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H, n);
-    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, tv.records, tv.edges, tv.plan, n, W, H, R, C, border,
+    // staging reads dword-aligned 16-byte chunks: needs a 4-byte aligned clip (W % 4 == 0 is checked by the plan)
+    const int stage_ok = ((uintptr_t)frames & 3u) == 0 ? 1 : 0;
+    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, tv.records, tv.edges, tv.plan, tv.regions, stage_ok, n, W, H, R, C, border,
                        crop);
     return hip_fail(hipGetLastError(), "warp_kernel launch");
 }
