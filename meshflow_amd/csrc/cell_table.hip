@@ -370,7 +370,8 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
         const int iy_lo = (int)floor(vmin) - 1, iy_hi = (int)floor(vmax) + 2;
         const int sx0 = min(max(ix_lo, 0), (3 * W - MF_STAGE_PITCH) / 3), sy0 = min(max(iy_lo, 0), H - MF_STAGE_ROWS - 1);
         if (ix_lo >= sx0 && ix_hi <= sx0 + MF_STAGE_COLS - 1 && iy_lo >= sy0 && iy_hi <= sy0 + MF_STAGE_ROWS - 1)
-            region = MF_REGION_STAGED | ((uint32_t)sy0 << 15) | (uint32_t)sx0;
+            region = MF_REGION_STAGED | ((uint32_t)sy0 << 15) | (uint32_t)sx0 |
+                     (closed && ix_lo >= 2 && ix_hi <= W - 3 && iy_lo >= 2 && iy_hi <= H - 3 ? MF_REGION_DEEP : 0u);
     }
     regions[gid] = region;
 }

@@ -415,21 +415,34 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
         // the "deep interior" window below and is redone exactly by the generic path).
         // Raw float bits of 32u + 1.5*2^23: the low 22 bits hold sx = rint(32u) for 0 <= sx < 2^22.
         uint32_t bx[4], by[4];
-        uint32_t dxm = 0, dym = 0;
+        bool fast;
+        if (staged && (rg & MF_REGION_DEEP)) {
+            // the plan certifies that every pixel has an owner and every tap lies at least two pixels inside the
+            // frame (hence no crop flag either): nothing to check
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bx[j] = __float_as_uint(__builtin_fmaf(u[j], 32.0f, 12582912.0f));
-            by[j] = __float_as_uint(__builtin_fmaf(v[j], 32.0f, 12582912.0f));
-            dxm = max(dxm, bx[j] - (0x4B400000u + 64u));
-            dym = max(dym, by[j] - (0x4B400000u + 64u));
+            for (int j = 0; j < 4; ++j) {
+                bx[j] = __float_as_uint(__builtin_fmaf(u[j], 32.0f, 12582912.0f));
+                by[j] = __float_as_uint(__builtin_fmaf(v[j], 32.0f, 12582912.0f));
+            }
+            fast = true;
+        } else {
+            uint32_t dxm = 0, dym = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bx[j] = __float_as_uint(__builtin_fmaf(u[j], 32.0f, 12582912.0f));
+                by[j] = __float_as_uint(__builtin_fmaf(v[j], 32.0f, 12582912.0f));
+                dxm = max(dxm, bx[j] - (0x4B400000u + 64u));
+                dym = max(dym, by[j] - (0x4B400000u + 64u));
+            }
+            // "deep interior": 2 <= ix <= W-3 and 2 <= iy <= H-3 for all four pixels.  Then both taps in x and
+            // y are inside the frame, the 8-byte loads stay inside the row, and no crop flag can be set
+            // (u >= 2 - 1/64 and u < W - 2, same for v).
+            const bool deep = dxm <= (uint32_t)(32 * (W - 3) + 31 - 64) && dym <= (uint32_t)(32 * (H - 3) + 31 - 64);
+            fast = __ballot(active && !deep) == 0;
         }
-        // "deep interior": 2 <= ix <= W-3 and 2 <= iy <= H-3 for all four pixels.  Then both taps in x and
-        // y are inside the frame, the 8-byte loads stay inside the row, and no crop flag can be set
-        // (u >= 2 - 1/64 and u < W - 2, same for v).
-        const bool deep = dxm <= (uint32_t)(32 * (W - 3) + 31 - 64) && dym <= (uint32_t)(32 * (H - 3) + 31 - 64);
-        uint32_t px[4];
+        uint3 d;                                                        // the lane's 12 output bytes
         if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the region has landed in LDS
-        if (__ballot(active && !deep) == 0) {
+        if (fast) {
             // fast path (wave-uniform): every pixel of the footprint samples the deep interior
             if (!active) continue;
             uint2 a[4], b[4];
@@ -459,6 +472,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                     __builtin_memcpy(&b[j], src1 + o, 8);
                 }
             }
+            uint32_t oB[4], oG[4], oR[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // a[j].x = B0 G0 R0 B1, a[j].y = G1 R1 . .   (pixel ix, pixel ix+1 of row iy; b: row iy+1)
@@ -475,15 +489,20 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 const uint32_t hRa = __builtin_amdgcn_udot4(pa, wr, 0u, false), hRb = __builtin_amdgcn_udot4(pb, wr, 0u, false);
                 // vertical lerp scaled by 64 so that ((sum + 512) >> 10) lands in byte 2:  (sum + 512) * 64 < 2^24
                 const uint32_t fy6 = (by[j] << 6) & 0x7C0u, wy6 = 2048u - fy6;
-                const uint32_t oB = umad24(wy6, hBa, umad24(fy6, hBb, 32768u));
-                const uint32_t oG = umad24(wy6, hGa, umad24(fy6, hGb, 32768u));
-                const uint32_t oR = umad24(wy6, hRa, umad24(fy6, hRb, 32768u));
-                const uint32_t bg = __builtin_amdgcn_perm(oG, oB, 0x0C0C0602u);           // B | G << 8
-                px[j] = __builtin_amdgcn_perm(oR, bg, 0x0C060100u);                       // | R << 16
+                oB[j] = umad24(wy6, hBa, umad24(fy6, hBb, 32768u));
+                oG[j] = umad24(wy6, hGa, umad24(fy6, hGb, 32768u));
+                oR[j] = umad24(wy6, hRa, umad24(fy6, hRb, 32768u));
             }
+            // the 12 result bytes sit in byte 2 of the 12 sums: 9 v_perm_b32 gather them into B0 G0 R0 B1 | G1 R1 B2 G2 |
+            // R2 B3 G3 R3  (pair = byte 2 of `lo` then byte 2 of `hi`; join = two low bytes of each pair)
+            const uint32_t pair = 0x0C0C0602u, join = 0x05040100u;
+            d.x = __builtin_amdgcn_perm(__builtin_amdgcn_perm(oB[1], oR[0], pair), __builtin_amdgcn_perm(oG[0], oB[0], pair), join);
+            d.y = __builtin_amdgcn_perm(__builtin_amdgcn_perm(oG[2], oB[2], pair), __builtin_amdgcn_perm(oR[1], oG[1], pair), join);
+            d.z = __builtin_amdgcn_perm(__builtin_amdgcn_perm(oR[3], oG[3], pair), __builtin_amdgcn_perm(oB[3], oR[2], pair), join);
         } else {
             // generic path: frame borders, uncovered pixels, crop flags, out-of-range coordinates
             if (!active) continue;
+            uint32_t px[4];
 #pragma unroll 1
             for (int j = 0; j < 4; ++j) {
                 const float uu = j == 0 ? u[0] : j == 1 ? u[1] : j == 2 ? u[2] : u[3];
@@ -517,22 +536,19 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 }
                 if (j == 0) px[0] = r; else if (j == 1) px[1] = r; else if (j == 2) px[2] = r; else px[3] = r;
             }
-        }
-        const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
-        if (fast_store && x0 + 3 < W) {
-            uint3 d;
             d.x = px[0] | (px[1] << 24);
             d.y = (px[1] >> 8) | (px[2] << 16);
             d.z = (px[2] >> 16) | (px[3] << 8);
+        }
+        const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
+        if (fast_store && x0 + 3 < W) {
             *reinterpret_cast<uint3*>(dst + o) = d;
         } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (x0 + j < W) {
-                    dst[o + 3 * j + 0] = (uint8_t)(px[j]);
-                    dst[o + 3 * j + 1] = (uint8_t)(px[j] >> 8);
-                    dst[o + 3 * j + 2] = (uint8_t)(px[j] >> 16);
-                }
+            const int nb = 3 * min(4, W - x0);                       // W % 4 != 0: byte by byte, up to the row end
+            for (int k = 0; k < nb; ++k) {
+                const uint32_t word = k < 4 ? d.x : k < 8 ? d.y : d.z;
+                dst[o + k] = (uint8_t)(word >> (8 * (k & 3)));
+            }
         }
     }
 
