@@ -318,7 +318,8 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     while (r_lo < R - 1 && s_gy[r_lo + 1] < ya - ryhi) ++r_lo;
     while (r_hi > 0 && s_gy[r_hi] > yb + rylo) --r_hi;
     FootPlan p;
-    for (int i = 0; i < 8; ++i) p.e[i] = 0;
+    uint16_t codes[8];
+    for (int i = 0; i < 8; ++i) { p.e[i] = 0; codes[i] = 0; }
     int cnt = 0;
     bool overflow = false, closed = false;
     const float cxs[2] = { (float)xa, (float)xb }, cys[2] = { (float)ya, (float)yb };
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
             const int k = r * C + c;
             const float* __restrict__ ed = fedge + (size_t)k * MF_EDGE_FLOATS;
             bool all_in = true, any_out = false;
+            int uncertain = 0, which = 0;
             for (int e = 0; e < 4; ++e) {
                 // extrema of the affine function a x + b y + c over the footprint rectangle sit on its corners:
                 // min = c + min(a xa, a xb) + min(b ya, b yb), max likewise (NaN coefficients fail both tests)
@@ -340,9 +342,11 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
                 const float gmax = (fmaxf(ax0, ax1) + fmaxf(by0, by1)) + ed[3 * e + 2];
                 all_in = all_in && gmin > 1.0f;
                 any_out = any_out || gmax < -1.0f;
+                if (!(gmin > 1.0f)) { ++uncertain; which = e; }
             }
             if (any_out) continue;
             if (cnt == 8) { overflow = true; break; }
+            codes[cnt] = (uint16_t)(MF_PLAN_CODES | (uncertain == 1 ? which : 4));
             p.e[cnt++] = (uint16_t)(k | MF_PLAN_VALID | (all_in ? MF_PLAN_IN : 0u));
             if (all_in) closed = true;
             const double* __restrict__ hi = frec + (size_t)k * MF_CELL_DOUBLES + MF_CELL_OFF_HI;
@@ -356,6 +360,8 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
                 vmin = fmin(vmin, v); vmax = fmax(vmax, v);
             }
         }
+    if (!overflow && cnt <= 4)
+        for (int i = 0; i < cnt; ++i) p.e[4 + i] = codes[i];      // short list: room for the per-entry edge codes
     if (overflow) {
         // more than 8 candidates: hand the whole range to the warp kernel instead
         p.e[0] = (uint16_t)r_lo; p.e[1] = (uint16_t)r_hi; p.e[2] = (uint16_t)c_lo; p.e[3] = (uint16_t)c_hi;

@@ -349,16 +349,29 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 uint32_t pass = unowned;                                   // IN: every unowned pixel passes
                 if (!(e & MF_PLAN_IN)) {
                     const float* __restrict__ ed = fedge + k * MF_EDGE_FLOATS;
-                    const float r0 = __builtin_fmaf(ed[1], yf, ed[2]), r1 = __builtin_fmaf(ed[4], yf, ed[5]);
-                    const float r2 = __builtin_fmaf(ed[7], yf, ed[8]), r3 = __builtin_fmaf(ed[10], yf, ed[11]);
+                    // short lists carry an edge code: only one of the four edge functions can fail in this footprint
+                    const uint32_t code = ne <= 4 ? (((i < 2 ? pv.z : pv.w) >> (16 * (i & 1))) & 7u) : 4u;
                     uint32_t ok = 0, amb = 0;
+                    if (code < 4u) {
+                        const float* __restrict__ e1 = ed + 3u * code;
+                        const float rr = __builtin_fmaf(e1[1], yf, e1[2]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float xf = xf0 + (float)j;
-                        const float g = fminf(fminf(__builtin_fmaf(ed[0], xf, r0), __builtin_fmaf(ed[3], xf, r1)),
-                                              fminf(__builtin_fmaf(ed[6], xf, r2), __builtin_fmaf(ed[9], xf, r3)));
-                        ok |= g > 0.5f ? (1u << j) : 0u;
-                        amb |= ((g > 0.5f) | (g < -0.5f)) ? 0u : (1u << j);     // NaN (irregular cell) -> ambiguous
+                        for (int j = 0; j < 4; ++j) {
+                            const float g = __builtin_fmaf(e1[0], xf0 + (float)j, rr);
+                            ok |= g > 0.5f ? (1u << j) : 0u;
+                            amb |= ((g > 0.5f) | (g < -0.5f)) ? 0u : (1u << j);
+                        }
+                    } else {
+                        const float r0 = __builtin_fmaf(ed[1], yf, ed[2]), r1 = __builtin_fmaf(ed[4], yf, ed[5]);
+                        const float r2 = __builtin_fmaf(ed[7], yf, ed[8]), r3 = __builtin_fmaf(ed[10], yf, ed[11]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xf = xf0 + (float)j;
+                            const float g = fminf(fminf(__builtin_fmaf(ed[0], xf, r0), __builtin_fmaf(ed[3], xf, r1)),
+                                                  fminf(__builtin_fmaf(ed[6], xf, r2), __builtin_fmaf(ed[9], xf, r3)));
+                            ok |= g > 0.5f ? (1u << j) : 0u;
+                            amb |= ((g > 0.5f) | (g < -0.5f)) ? 0u : (1u << j);     // NaN (irregular cell) -> ambiguous
+                        }
                     }
                     amb &= unowned;
                     if (__ballot(amb != 0) != 0)
