@@ -26,7 +26,7 @@
 //      cell's Hi comes in through scalar loads and the four coordinates are straight-line float64 code with
 //      an IEEE-exact reciprocal trimmed for 0.5 <= |w| < 2.
 //   3. Several cells: their Hi go to LDS; ownership is resolved last cell first with a float32 evaluation
-//      of the cell's four affine edge functions, which decides unless the pixel is within 1/64 px of the
+//      of the cell's four affine edge functions, which decides unless the pixel is within the float32 error band of the
 //      mask edge -- then a division-free float64 comparison, and OpenCV's exact arithmetic (division, rint)
 //      only within 1e-6 of the edge; every pixel then computes its coordinates once with its owner's Hi
 //      read from LDS.  More than 8 candidates: every cell of the recorded index range is tested.
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                                                    const double* __restrict__ records,
                                                    const float* __restrict__ edges,
                                                    const FootPlan* __restrict__ plan, const uint32_t* __restrict__ regions,
-                                                   int stage_ok, int n, int W, int H, int R, int C,
+                                                   int stage_ok, float edge_margin, int n, int W, int H, int R, int C,
                                                    uint32_t border, int32_t* __restrict__ crop)
 {
     // inverse homographies of a footprint's candidate cells, per wavefront: [entry][Hi0..Hi8, pad] (80-byte rows)
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
         } else {
             // Several cells share the footprint.  (a) their inverse homographies go to LDS; (b) ownership is
             // resolved per pixel, last cell first: a float32 evaluation of the cell's four edge functions
-            // decides unless the pixel is within 1/64 px of a mask edge, then the float64 test; (c) every
+            // decides unless the pixel is within the float32 error band of a mask edge, then the float64 test; (c) every
             // pixel computes its coordinates ONCE with its owner's matrix read from LDS.
             int ne = 0;
 #pragma unroll
@@ -332,14 +332,34 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                     s_hi[wave][e][dd] = frec[k * MF_CELL_DOUBLES + MF_CELL_OFF_HI + dd];
                 }
             }
-            uint32_t unowned = 0;
             int own[4];
+            const float yf = (float)y, xf0 = (float)x0;
+            // The common shape -- exactly two cells, each with ONE mask edge crossing the footprint (a footprint on the
+            // border between two cells): one fma per pixel and cell decides, straight-line.
+            const uint32_t cd0 = pv.z & 7u, cd1 = (pv.z >> 16) & 7u;
+            bool general = !(ne == 2 && !(pv.x & MF_PLAN_IN) && !((pv.x >> 16) & MF_PLAN_IN) && cd0 < 4u && cd1 < 4u);
+            if (!general) {
+                const float* __restrict__ eb = fedge + (pv.x & 0xFFFu) * MF_EDGE_FLOATS + 3u * cd0;            // later cell: wins
+                const float* __restrict__ ea = fedge + ((pv.x >> 16) & 0xFFFu) * MF_EDGE_FLOATS + 3u * cd1;
+                const float rb = __builtin_fmaf(eb[1], yf, eb[2]), ra = __builtin_fmaf(ea[1], yf, ea[2]);
+                float near = 1e30f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xf = xf0 + (float)j;
+                    const float gb = __builtin_fmaf(eb[0], xf, rb), ga = __builtin_fmaf(ea[0], xf, ra);
+                    own[j] = gb > edge_margin ? 0 : (ga > edge_margin ? 1 : -1);
+                    near = fminf(near, fminf(fabsf(gb), fabsf(ga)));
+                }
+                // a pixel inside the float32 error band of a mask edge (or NaN coefficients): the general path decides exactly
+                general = __ballot(!(near > edge_margin) && y < H && x0 < W) != 0;
+            }
+            if (general) {
+            uint32_t unowned = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 own[j] = -1;
                 if (x0 + j < W && y < H) unowned |= 1u << j;
             }
-            const float yf = (float)y, xf0 = (float)x0;
             bool done = __ballot(unowned != 0) == 0;
 #pragma unroll 1
             for (int i = 0; i < ne && !done; ++i) {
@@ -358,8 +378,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float g = __builtin_fmaf(e1[0], xf0 + (float)j, rr);
-                            ok |= g > 0.5f ? (1u << j) : 0u;
-                            amb |= ((g > 0.5f) | (g < -0.5f)) ? 0u : (1u << j);
+                            ok |= g > edge_margin ? (1u << j) : 0u;
+                            amb |= ((g > edge_margin) | (g < -edge_margin)) ? 0u : (1u << j);
                         }
                     } else {
                         const float r0 = __builtin_fmaf(ed[1], yf, ed[2]), r1 = __builtin_fmaf(ed[4], yf, ed[5]);
@@ -369,8 +389,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                             const float xf = xf0 + (float)j;
                             const float g = fminf(fminf(__builtin_fmaf(ed[0], xf, r0), __builtin_fmaf(ed[3], xf, r1)),
                                                   fminf(__builtin_fmaf(ed[6], xf, r2), __builtin_fmaf(ed[9], xf, r3)));
-                            ok |= g > 0.5f ? (1u << j) : 0u;
-                            amb |= ((g > 0.5f) | (g < -0.5f)) ? 0u : (1u << j);     // NaN (irregular cell) -> ambiguous
+                            ok |= g > edge_margin ? (1u << j) : 0u;
+                            amb |= ((g > edge_margin) | (g < -edge_margin)) ? 0u : (1u << j);     // NaN (irregular cell) -> ambiguous
                         }
                     }
                     amb &= unowned;
@@ -382,6 +402,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 for (int j = 0; j < 4; ++j) own[j] = ((pass >> j) & 1u) ? i : own[j];
                 unowned &= ~pass;
                 done = __ballot(unowned != 0) == 0;
+            }
             }
             // (c) coordinates, once per pixel, owner's matrix from LDS (same wavefront wrote it: in order)
             double w4[4], nx[4], ny[4];
@@ -623,7 +644,11 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
     const dim3 grid((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H, n);
     // staging reads dword-aligned 16-byte chunks: needs a 4-byte aligned clip (W % 4 == 0 is checked by the plan)
     const int stage_ok = ((uintptr_t)frames & 3u) == 0 ? 1 : 0;
-    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, tv.records, tv.edges, tv.plan, tv.regions, stage_ok, n, W, H, R, C, border,
+    // float32 edge functions (cell_table.hip) reach |g| <= V = 32 max(W, H) (1/32-px units); two fmas and three rounded
+    // coefficients put the evaluation within 2.5 V 2^-23 of the exact value.  The kernel trusts the float32 sign only
+    // beyond six times that, max(W, H) 2^-14 (0.12 at 1080p), and decides in float64 inside the band.
+    const float edge_margin = (float)(W > H ? W : H) * (1.0f / 16384.0f);
+    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, tv.records, tv.edges, tv.plan, tv.regions, stage_ok, edge_margin, n, W, H, R, C, border,
                        crop);
     return hip_fail(hipGetLastError(), "warp_kernel launch");
 }

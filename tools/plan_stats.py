@@ -1,0 +1,38 @@
+"""Footprint-plan statistics of a workload: how many footprints are single-owner, staged, certified interior."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from meshflow_amd import ops, synthetic, _lib
+from meshflow_amd.stabilizer import MeshFlowStabilizer
+H, W, F, R, C, omega, iters = 1080, 1920, 300, 16, 16, 10, 100
+if len(sys.argv) > 1 and sys.argv[1] == 'cfg3':
+    F, R, C, omega, iters = 600, 32, 32, 30, 200
+dev = torch.device('cuda:0')
+disp, hom = synthetic.motion(F, R, C, seed=0)
+s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=omega, optimization_num_iterations=iters)
+d_disp = torch.from_numpy(disp).to(dev)
+d_stab = s._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
+n = 60
+table = ops.cell_table(d_disp[:n], d_stab[:n], W, H, R, C)
+torch.cuda.synchronize()
+buf = table.buf.cpu().numpy()
+nrec = n * R * C
+plan_off = (nrec * (32 * 8 + 8 + 12 * 4) + 15) & ~15
+nfx, nfy = (W + 31) // 32, (H + 7) // 8
+npl = n * nfx * nfy
+plan = buf[plan_off:plan_off + npl * 16].view(np.uint16).reshape(npl, 8)
+reg_off = plan_off + npl * 16 + n * 16 + (R + C + 2) * 4
+regions = buf[reg_off:reg_off + npl * 4].view(np.uint32)
+valid = (plan & 0x4000) != 0
+overflow = plan[:, 7] == 0xFFFF
+ne = np.where(overflow, 9, valid[:, :4].sum(1) + np.where(valid[:, :4].all(1), valid[:, 4:].sum(1), 0))
+single = (ne == 1) & ((plan[:, 0] & 0x8000) != 0)
+print(f'{npl} footprints: single-owner {single.mean():.3f}; candidates histogram', {int(k): round(float((ne == k).mean()), 4) for k in np.unique(ne)})
+codes = plan[:, 4:8]
+short = (ne >= 2) & (ne <= 4)
+mixed_entries = 0; single_edge = 0
+for i in range(4):
+    m = short & (i < ne) & ((plan[:, i] & 0x8000) == 0)
+    mixed_entries += m.sum(); single_edge += (m & ((codes[:, i] & 7) < 4)).sum()
+print(f'MIXED entries in short lists: {mixed_entries}, of which single-edge: {single_edge} ({single_edge / max(mixed_entries, 1):.3f})')
+print(f'staged {((regions >> 31) & 1).mean():.4f}  certified interior {((regions >> 30) & 1).mean():.4f}')
