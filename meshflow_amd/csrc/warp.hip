@@ -216,11 +216,32 @@ __device__ __forceinline__ uint32_t cell_mask_test(const double* __restrict__ re
     return ok & unowned;
 }
 
+// n / d for n < 2^31 as (n * m) >> (32 + s), m = ceil(2^(31 + ceil(log2 d)) / d): exact because the excess m d - 2^p is below
+// d <= 2^(p - 31).  d == 1 is passed through.
+struct FastDiv {
+    uint32_t d, m, s;
+    __device__ __forceinline__ uint32_t quotient(uint32_t n) const { return d == 1u ? n : (__umulhi(n, m) >> s); }
+};
+inline FastDiv make_fast_div(uint32_t d)
+{
+    FastDiv f;
+    f.d = d; f.m = 0; f.s = 0;
+    if (d > 1u) {
+        uint32_t l = 0;
+        while ((1ull << l) < d) ++l;                       // ceil(log2 d) >= 1
+        const unsigned p = 31u + l;
+        f.m = (uint32_t)(((1ull << p) + d - 1) / d);
+        f.s = l - 1u;
+    }
+    return f;
+}
+struct TileOrder { uint32_t tiles, per_xcd; FastDiv by_frame, by_row; };
+
 __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out,
                                                    const double* __restrict__ records,
                                                    const float* __restrict__ edges,
                                                    const FootPlan* __restrict__ plan, const uint32_t* __restrict__ regions,
-                                                   int stage_ok, float edge_margin, int n, int W, int H, int R, int C,
+                                                   int stage_ok, float edge_margin, TileOrder order, int n, int W, int H, int R, int C,
                                                    uint32_t border, int32_t* __restrict__ crop)
 {
     // inverse homographies of a footprint's candidate cells, per wavefront: [entry][Hi0..Hi8, pad] (80-byte rows)
@@ -228,10 +249,20 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
     // source region of the footprint, per wavefront: MF_STAGE_ROWS rows of MF_STAGE_PITCH bytes (+ slack for the
     // third dword of the last tap)
     __shared__ __attribute__((aligned(16))) uint8_t s_src[4][MF_STAGE_CHUNKS * 16 + 64];
-    const int f = blockIdx.z;
+    // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2: with the
+    // natural order the four neighbours of a tile -- whose staged source windows overlap this tile's by 60 % -- would
+    // all run on other XCDs and each L2 would fetch the shared rows again.  Workgroup L therefore takes tile
+    // (L % 8) * ceil(T / 8) + L / 8: every XCD sweeps one contiguous eighth of the clip in raster order.
+    // (divisions by multiply-high with host-made constants: everything stays on the scalar unit)
+    const uint32_t tile = (blockIdx.x & 7u) * order.per_xcd + (blockIdx.x >> 3);
+    if (tile >= order.tiles) return;
+    const int f = (int)order.by_frame.quotient(tile);
+    const uint32_t tile_in_frame = tile - (uint32_t)f * order.by_frame.d;
+    const int tile_y = (int)order.by_row.quotient(tile_in_frame);
+    const int tile_x = (int)(tile_in_frame - (uint32_t)tile_y * order.by_row.d);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps plan/record loads scalar
     const int lane = threadIdx.x & 63;
-    const int xa = blockIdx.x * TILE_W + wave * FOOT_W;                  // footprint x range starts here
+    const int xa = tile_x * TILE_W + wave * FOOT_W;                  // footprint x range starts here
     if (xa >= W) return;                                                 // whole wave outside the frame
     const int x0 = xa + (lane & 7) * 4;                                  // first of this lane's 4 pixels
     const int ncell = R * C;
@@ -243,8 +274,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
     const size_t limit = (size_t)(n - f) * frame_bytes;
     const double* __restrict__ frec = records + (size_t)f * ncell * MF_CELL_DOUBLES;
     const float* __restrict__ fedge = edges + (size_t)f * ncell * MF_EDGE_FLOATS;
-    const uint4* __restrict__ fplan = reinterpret_cast<const uint4*>(plan) + ((size_t)f * nfy * nfx + (blockIdx.x * (TILE_W / FOOT_W) + wave));
-    const uint32_t* __restrict__ fregion = regions + ((size_t)f * nfy * nfx + (blockIdx.x * (TILE_W / FOOT_W) + wave));
+    const uint4* __restrict__ fplan = reinterpret_cast<const uint4*>(plan) + ((size_t)f * nfy * nfx + (tile_x * (TILE_W / FOOT_W) + wave));
+    const uint32_t* __restrict__ fregion = regions + ((size_t)f * nfy * nfx + (tile_x * (TILE_W / FOOT_W) + wave));
 
     int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
     const float fWm1 = (float)(W - 1), fHm1 = (float)(H - 1);
@@ -253,12 +284,12 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
 
 #pragma unroll 1
     for (int q = 0; q < FOOTS; ++q) {
-        const int ya = blockIdx.y * TILE_H + q * FOOT_H;
+        const int ya = tile_y * TILE_H + q * FOOT_H;
         if (ya >= H) break;
         const int y = ya + (lane >> 3);
         const double yy = (double)y;
-        const uint4 pv = fplan[(size_t)(blockIdx.y * FOOTS + q) * nfx];   // wave-uniform: scalar load
-        const uint32_t rg = fregion[(size_t)(blockIdx.y * FOOTS + q) * nfx];
+        const uint4 pv = fplan[(size_t)(tile_y * FOOTS + q) * nfx];   // wave-uniform: scalar load
+        const uint32_t rg = fregion[(size_t)(tile_y * FOOTS + q) * nfx];
         // Source region -> LDS, asynchronously (global_load_lds: no VGPRs, no ds_write): lane i fetches the i-th and
         // (64+i)-th 16-byte chunk of the window (10 chunks = 160 bytes per row), which land at LDS offsets 16 i and
         // 1024 + 16 i.
@@ -641,14 +672,21 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
         set_error("mf_warp_u8c3: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
         return MF_ERR_INVALID_ARG;
     }
-    const dim3 grid((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H, n);
+    const long long tiles = (long long)((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H) * n;
+    if ((tiles + 7) / 8 * 8 > 0x7FFFFFFFll) { set_error("mf_warp_u8c3: too many tiles (%lld)", tiles); return MF_ERR_INVALID_ARG; }
+    const dim3 grid((unsigned)((tiles + 7) / 8 * 8));             // one workgroup per 128 x 8 tile, XCD-swizzled in the kernel
+    TileOrder order;
+    order.tiles = (uint32_t)tiles;
+    order.per_xcd = (uint32_t)((tiles + 7) / 8);
+    order.by_frame = make_fast_div((uint32_t)(tiles / n));
+    order.by_row = make_fast_div((uint32_t)((W + TILE_W - 1) / TILE_W));
     // staging reads dword-aligned 16-byte chunks: needs a 4-byte aligned clip (W % 4 == 0 is checked by the plan)
     const int stage_ok = ((uintptr_t)frames & 3u) == 0 ? 1 : 0;
     // float32 edge functions (cell_table.hip) reach |g| <= V = 32 max(W, H) (1/32-px units); two fmas and three rounded
     // coefficients put the evaluation within 2.5 V 2^-23 of the exact value.  The kernel trusts the float32 sign only
     // beyond six times that, max(W, H) 2^-14 (0.12 at 1080p), and decides in float64 inside the band.
     const float edge_margin = (float)(W > H ? W : H) * (1.0f / 16384.0f);
-    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, tv.records, tv.edges, tv.plan, tv.regions, stage_ok, edge_margin, n, W, H, R, C, border,
+    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, tv.records, tv.edges, tv.plan, tv.regions, stage_ok, edge_margin, order, n, W, H, R, C, border,
                        crop);
     return hip_fail(hipGetLastError(), "warp_kernel launch");
 }
