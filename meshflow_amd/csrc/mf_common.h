@@ -89,6 +89,55 @@ inline TableView table_view(void* blob, int n, int W, int H, int R, int C)
     return v;
 }
 
+// n / d for n < 2^31 as (n * m) >> (32 + s), m = ceil(2^(31 + ceil(log2 d)) / d): exact because the excess m d - 2^p is below
+// d <= 2^(p - 31).  d == 1 is passed through.
+struct FastDiv {
+    uint32_t d, m, s;
+    __device__ __forceinline__ uint32_t quotient(uint32_t n) const { return d == 1u ? n : (__umulhi(n, m) >> s); }
+};
+inline FastDiv make_fast_div(uint32_t d)
+{
+    FastDiv f;
+    f.d = d; f.m = 0; f.s = 0;
+    if (d > 1u) {
+        uint32_t l = 0;
+        while ((1ull << l) < d) ++l;                       // ceil(log2 d) >= 1
+        const unsigned p = 31u + l;
+        f.m = (uint32_t)(((1ull << p) + d - 1) / d);
+        f.s = l - 1u;
+    }
+    return f;
+}
+// XCD-aware tile order (workgroups go to the 8 XCDs round-robin by linear id, each XCD has its own L2): workgroup L of a
+// 1-D grid of 8 * per_xcd takes tile (L % 8) * per_xcd + L / 8, so every XCD sweeps one contiguous eighth of the tiles
+// in raster order and rows shared by neighbouring tiles are fetched once per L2.  tile -> (frame, tile row, tile col).
+struct TileOrder {
+    uint32_t tiles, per_xcd;
+    FastDiv by_frame, by_row;
+    __device__ __forceinline__ bool decode(uint32_t block, int& f, int& ty, int& tx) const
+    {
+        const uint32_t tile = (block & 7u) * per_xcd + (block >> 3);
+        if (tile >= tiles) return false;
+        f = (int)by_frame.quotient(tile);
+        const uint32_t in_frame = tile - (uint32_t)f * by_frame.d;
+        ty = (int)by_row.quotient(in_frame);
+        tx = (int)(in_frame - (uint32_t)ty * by_row.d);
+        return true;
+    }
+};
+inline bool make_tile_order(int tiles_x, int tiles_y, int n, TileOrder& o)
+{
+    const long long tiles = (long long)tiles_x * tiles_y * n;
+    if ((tiles + 7) / 8 * 8 > 0x7FFFFFFFll) return false;
+    o.tiles = (uint32_t)tiles;
+    o.per_xcd = (uint32_t)((tiles + 7) / 8);
+    o.by_frame = make_fast_div((uint32_t)(tiles_x * tiles_y));
+    o.by_row = make_fast_div((uint32_t)tiles_x);
+    return true;
+}
+
+
+
 // Launchers (defined next to their kernels).
 int launch_jacobi(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
                   int F, int S, int omega, int iters, hipStream_t st);

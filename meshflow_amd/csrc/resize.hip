@@ -11,13 +11,14 @@
 //   vertical    out = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2
 // resize_tables_kernel builds the per-column / per-row tables (W + H entries) on the device in the same
 // float / double operations; resize_kernel applies them: a lane owns 4 consecutive output pixels (one
-// 12-byte store), two unaligned 8-byte tap loads per pixel, v_dot2_u32_u16 for the horizontal pass.  Memory-bound
-// in principle (2*H*W*3 bytes per frame); VALU-bound in practice like the warp kernel.
+// 12-byte store), the two source rows of an output row staged in LDS, v_dot2_u32_u16 for the horizontal pass.
+// Memory-bound in principle (2*H*W*3 bytes per frame).
 #include "mf_common.h"
 
 namespace mf {
 
-struct ResizeTab { int32_t ofs; uint32_t w; };     // x: ofs = sx, w = a0 | a1 << 16;  y: ofs = sy0 | sy1 << 16, w = b0 | b1 << 16
+// x: ofs = sx, w = 16 a0 | 16 a1 << 16 (pre-scaled, see resize_kernel);  y: ofs = sy0 | sy1 << 16, w = b0 | b1 << 16
+struct ResizeTab { int32_t ofs; uint32_t w; };
 
 __device__ __forceinline__ int cv_round_pos(float v) { return (int)rintf(v); }
 
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void resize_tables_kernel(int cw, int ch, int 
         if (sx >= cw - 1) { fx = 0.0f; sx = cw - 1; }
         const int a0 = cv_round_pos((1.0f - fx) * 2048.0f), a1 = cv_round_pos(fx * 2048.0f);
         xtab[i].ofs = sx;
-        xtab[i].w = (uint32_t)a0 | ((uint32_t)a1 << 16);
+        xtab[i].w = ((uint32_t)a0 << 4) | ((uint32_t)a1 << 20);
     }
     if (i < H) {
         float fy = (float)(((double)i + 0.5) * scale_y - 0.5);
@@ -67,50 +68,109 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
     return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b), c, false);
 }
 
+constexpr int kRowPitch = 800;        // bytes of one staged source row in LDS: 50 chunks of 16 bytes (256 output px + slack)
+
+// Workgroup = 4 output rows x 256 pixels; wavefront = one row; lane = 4 consecutive pixels (one 12-byte store).
+// The two source rows of an output row are shared by all its pixels: the wavefront copies the span it needs of both
+// (<= 800 bytes each, from the dword holding the first tap) into LDS with two global->LDS 16-byte loads per lane and
+// takes the taps from there (three dword reads per pixel and row + v_alignbyte for the 3-byte-pixel misalignment).
+// That replaces eight unaligned 8-byte loads per lane, whose instruction count -- not bytes -- bounded the first version.
+// High 32 bits of the product of two 24-bit values (v_mul_hi_u32_u24).
+__device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b)
+{
+    return (uint32_t)(((unsigned long long)(a & 0xFFFFFFu) * (unsigned long long)(b & 0xFFFFFFu)) >> 32);
+}
+
 __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out, int n,
                                                      int W, int H, int left, int top, int cw,
                                                      const ResizeTab* __restrict__ xtab,
-                                                     const ResizeTab* __restrict__ ytab)
+                                                     const ResizeTab* __restrict__ ytab, TileOrder order)
 {
-    const int f = blockIdx.z;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    if (y >= H || x0 >= W) return;
+    __shared__ __attribute__((aligned(16))) uint8_t s_rows[4][2 * kRowPitch + 64];
+    int f, tile_y, tile_x;
+    if (!order.decode(blockIdx.x, f, tile_y, tile_x)) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int y = tile_y * 4 + wave;
+    const int xw = tile_x * 256, x0 = xw + lane * 4;
+    if (y >= H) return;
     const size_t frame_bytes = (size_t)W * H * 3;
     const uint8_t* __restrict__ src = frames + (size_t)f * frame_bytes;
     uint8_t* __restrict__ dst = out + (size_t)f * frame_bytes;
     const size_t limit = (size_t)(n - f) * frame_bytes;
     const ResizeTab yt = ytab[y];
     const uint32_t b0 = yt.w & 0xFFFFu, b1 = yt.w >> 16;
+    const uint32_t b0s = b0 << 8, b1s = b1 << 8;
     const uint32_t row0 = (uint32_t)(top + (yt.ofs & 0xFFFF)) * (uint32_t)W + (uint32_t)left;
     const uint32_t row1 = (uint32_t)(top + (yt.ofs >> 16)) * (uint32_t)W + (uint32_t)left;
+
+    // span of source columns this wavefront touches: taps sx .. sx+1 for its first .. last pixel (the tables are
+    // monotone); staged when it fits the LDS rows and the 16-byte chunks stay inside the frame stack
+    const uint32_t sx_first = (uint32_t)xtab[xw].ofs, sx_last = (uint32_t)xtab[min(xw + 255, W - 1)].ofs;
+    const size_t g0 = (size_t)(row0 + sx_first) * 3u, g1 = (size_t)(row1 + sx_first) * 3u;      // byte offsets in the frame
+    const size_t base = (size_t)(uintptr_t)src;
+    const uint32_t s0 = (uint32_t)((base + g0) & 3u), s1 = (uint32_t)((base + g1) & 3u);         // misalignment of each row
+    const uint32_t span = 3u * (sx_last + 2u - sx_first);
+    const bool staged = span + 3u + 12u <= (uint32_t)kRowPitch && (g0 > g1 ? g0 : g1) - 3u + (size_t)kRowPitch <= limit &&
+                        g0 >= 3u && g1 >= 3u;
+    if (staged) {
+        if (lane < kRowPitch / 16) {
+            uint32_t o = (uint32_t)lane << 4;
+            asm("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (g0 - s0) + o),
+                                             (__attribute__((address_space(3))) void*)&s_rows[wave][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (g1 - s1) + o),
+                                             (__attribute__((address_space(3))) void*)&s_rows[wave][kRowPitch], 16, 0, 0);
+        }
+    }
+    if (x0 >= W) {
+        if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     uint32_t px[4];
-    // Fast path: the lane's four pixels are inside the frame and every 8-byte tap load (pixels sx, sx+1 and two
-    // bytes more) stays inside the frame stack.  Where sx is the last column of the crop the second weight is 0,
-    // so whatever lies right of it may be read.
+    // Fast path: the lane's four pixels are inside the frame and every tap load stays inside the frame stack.
+    // Where sx is the last column of the crop the second weight is 0, so whatever lies right of it may be read.
     const bool whole = x0 + 3 < W && ((size_t)(max(row0, row1) + (uint32_t)cw) * 3u + 8u <= limit);
-    if (whole) {
+    if (staged || whole) {
         ResizeTab xt[4];
         uint2 a[4], b[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            xt[j] = xtab[x0 + j];
-            __builtin_memcpy(&a[j], src + (row0 + (uint32_t)xt[j].ofs) * 3u, 8);
-            __builtin_memcpy(&b[j], src + (row1 + (uint32_t)xt[j].ofs) * 3u, 8);
+        for (int j = 0; j < 4; ++j) xt[j] = xtab[min(x0 + j, W - 1)];
+        if (staged) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t rel = 3u * ((uint32_t)xt[j].ofs - sx_first);
+                const uint32_t at0 = rel + s0, at1 = rel + s1;
+                const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(&s_rows[wave][at0 & ~3u]);
+                const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(&s_rows[wave][kRowPitch + (at1 & ~3u)]);
+                const uint32_t t0 = p[0], t1 = p[1], t2 = p[2], u0 = q[0], u1 = q[1], u2 = q[2];
+                a[j].x = __builtin_amdgcn_alignbyte(t1, t0, at0);
+                a[j].y = __builtin_amdgcn_alignbyte(t2, t1, at0);
+                b[j].x = __builtin_amdgcn_alignbyte(u1, u0, at1);
+                b[j].y = __builtin_amdgcn_alignbyte(u2, u1, at1);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __builtin_memcpy(&a[j], src + (row0 + (uint32_t)xt[j].ofs) * 3u, 8);
+                __builtin_memcpy(&b[j], src + (row1 + (uint32_t)xt[j].ofs) * 3u, 8);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            // bytes: B0 G0 R0 B1 | G1 R1 . .  -> (S[sx], S[sx+1]) as two uint16 per channel, then v_dot2_u32_u16
-            const uint32_t w = xt[j].w;                                        // a0 | a1 << 16
+            // bytes: B0 G0 R0 B1 | G1 R1 . .  -> (S[sx], S[sx+1]) as two uint16 per channel, then v_dot2_u32_u16 with the
+            // weights pre-scaled by 16: T = 16 t < 2^24, T & ~255 = 256 (t >> 4), and (b * (t >> 4)) >> 16 is the high
+            // half of the 24 x 24-bit product (256 b) * (256 (t >> 4)): one v_and + one v_mul_hi_u32_u24 per term
+            const uint32_t w = xt[j].w;                                        // 16 a0 | 16 a1 << 16
             const uint32_t tB0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C030C00u), w, 0u);
             const uint32_t tG0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C040C01u), w, 0u);
             const uint32_t tR0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C050C02u), w, 0u);
             const uint32_t tB1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C030C00u), w, 0u);
             const uint32_t tG1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C040C01u), w, 0u);
             const uint32_t tR1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C050C02u), w, 0u);
-            const uint32_t vB = ((__umul24(b0, tB0 >> 4) >> 16) + (__umul24(b1, tB1 >> 4) >> 16) + 2u) >> 2;
-            const uint32_t vG = ((__umul24(b0, tG0 >> 4) >> 16) + (__umul24(b1, tG1 >> 4) >> 16) + 2u) >> 2;
-            const uint32_t vR = ((__umul24(b0, tR0 >> 4) >> 16) + (__umul24(b1, tR1 >> 4) >> 16) + 2u) >> 2;
+            const uint32_t vB = (mulhi_u24(b0s, tB0 & ~255u) + mulhi_u24(b1s, tB1 & ~255u) + 2u) >> 2;
+            const uint32_t vG = (mulhi_u24(b0s, tG0 & ~255u) + mulhi_u24(b1s, tG1 & ~255u) + 2u) >> 2;
+            const uint32_t vR = (mulhi_u24(b0s, tR0 & ~255u) + mulhi_u24(b1s, tR1 & ~255u) + 2u) >> 2;
             px[j] = min(vB, 255u) | (min(vG, 255u) << 8) | (min(vR, 255u) << 16);
         }
     } else {
@@ -119,7 +179,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
             px[j] = 0;
             if (x0 + j >= W) continue;
             const ResizeTab xt = xtab[x0 + j];
-            const uint32_t a0 = xt.w & 0xFFFFu, a1 = xt.w >> 16;
+            const uint32_t a0 = (xt.w & 0xFFFFu) >> 4, a1 = xt.w >> 20;
             const uint32_t sx = (uint32_t)xt.ofs, sx1 = min(sx + 1u, (uint32_t)(cw - 1));     // a1 == 0 where sx == cw-1
             const uint32_t p00 = load_bgr(src, (row0 + sx) * 3u, limit), p01 = load_bgr(src, (row0 + sx1) * 3u, limit);
             const uint32_t p10 = load_bgr(src, (row1 + sx) * 3u, limit), p11 = load_bgr(src, (row1 + sx1) * 3u, limit);
@@ -174,8 +234,13 @@ int launch_crop_resize(const uint8_t* frames, uint8_t* out, int n, int W, int H,
     hipLaunchKernelGGL(resize_tables_kernel, dim3((m + 255) / 256), dim3(256), 0, st, cw, ch, W, H, scale_x, scale_y, xtab, ytab);
     int rc = hip_fail(hipGetLastError(), "resize_tables_kernel launch");
     if (rc != MF_OK) return rc;
-    const dim3 grid((W + 255) / 256, (H + 3) / 4, n);
-    hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, st, frames, out, n, W, H, left, top, cw, xtab, ytab);
+    TileOrder order;
+    if (!make_tile_order((W + 255) / 256, (H + 3) / 4, n, order)) {
+        set_error("mf_crop_resize_u8c3: too many tiles");
+        return MF_ERR_INVALID_ARG;
+    }
+    hipLaunchKernelGGL(resize_kernel, dim3(order.per_xcd * 8u), dim3(256), 0, st, frames, out, n, W, H, left, top, cw, xtab, ytab,
+                       order);
     return hip_fail(hipGetLastError(), "resize_kernel launch");
 }
 

@@ -216,27 +216,6 @@ __device__ __forceinline__ uint32_t cell_mask_test(const double* __restrict__ re
     return ok & unowned;
 }
 
-// n / d for n < 2^31 as (n * m) >> (32 + s), m = ceil(2^(31 + ceil(log2 d)) / d): exact because the excess m d - 2^p is below
-// d <= 2^(p - 31).  d == 1 is passed through.
-struct FastDiv {
-    uint32_t d, m, s;
-    __device__ __forceinline__ uint32_t quotient(uint32_t n) const { return d == 1u ? n : (__umulhi(n, m) >> s); }
-};
-inline FastDiv make_fast_div(uint32_t d)
-{
-    FastDiv f;
-    f.d = d; f.m = 0; f.s = 0;
-    if (d > 1u) {
-        uint32_t l = 0;
-        while ((1ull << l) < d) ++l;                       // ceil(log2 d) >= 1
-        const unsigned p = 31u + l;
-        f.m = (uint32_t)(((1ull << p) + d - 1) / d);
-        f.s = l - 1u;
-    }
-    return f;
-}
-struct TileOrder { uint32_t tiles, per_xcd; FastDiv by_frame, by_row; };
-
 __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out,
                                                    const double* __restrict__ records,
                                                    const float* __restrict__ edges,
@@ -254,12 +233,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
     // all run on other XCDs and each L2 would fetch the shared rows again.  Workgroup L therefore takes tile
     // (L % 8) * ceil(T / 8) + L / 8: every XCD sweeps one contiguous eighth of the clip in raster order.
     // (divisions by multiply-high with host-made constants: everything stays on the scalar unit)
-    const uint32_t tile = (blockIdx.x & 7u) * order.per_xcd + (blockIdx.x >> 3);
-    if (tile >= order.tiles) return;
-    const int f = (int)order.by_frame.quotient(tile);
-    const uint32_t tile_in_frame = tile - (uint32_t)f * order.by_frame.d;
-    const int tile_y = (int)order.by_row.quotient(tile_in_frame);
-    const int tile_x = (int)(tile_in_frame - (uint32_t)tile_y * order.by_row.d);
+    int f, tile_y, tile_x;
+    if (!order.decode(blockIdx.x, f, tile_y, tile_x)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps plan/record loads scalar
     const int lane = threadIdx.x & 63;
     const int xa = tile_x * TILE_W + wave * FOOT_W;                  // footprint x range starts here
@@ -672,14 +647,12 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
         set_error("mf_warp_u8c3: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
         return MF_ERR_INVALID_ARG;
     }
-    const long long tiles = (long long)((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H) * n;
-    if ((tiles + 7) / 8 * 8 > 0x7FFFFFFFll) { set_error("mf_warp_u8c3: too many tiles (%lld)", tiles); return MF_ERR_INVALID_ARG; }
-    const dim3 grid((unsigned)((tiles + 7) / 8 * 8));             // one workgroup per 128 x 8 tile, XCD-swizzled in the kernel
     TileOrder order;
-    order.tiles = (uint32_t)tiles;
-    order.per_xcd = (uint32_t)((tiles + 7) / 8);
-    order.by_frame = make_fast_div((uint32_t)(tiles / n));
-    order.by_row = make_fast_div((uint32_t)((W + TILE_W - 1) / TILE_W));
+    if (!make_tile_order((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H, n, order)) {
+        set_error("mf_warp_u8c3: too many tiles");
+        return MF_ERR_INVALID_ARG;
+    }
+    const dim3 grid(order.per_xcd * 8u);                          // one workgroup per 128 x 8 tile, XCD-swizzled in the kernel
     // staging reads dword-aligned 16-byte chunks: needs a 4-byte aligned clip (W % 4 == 0 is checked by the plan)
     const int stage_ok = ((uintptr_t)frames & 3u) == 0 ? 1 : 0;
     // float32 edge functions (cell_table.hip) reach |g| <= V = 32 max(W, H) (1/32-px units); two fmas and three rounded
