@@ -70,7 +70,8 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
 
 constexpr int kRowPitch = 800;        // bytes of one staged source row in LDS: 50 chunks of 16 bytes (256 output px + slack)
 
-// Workgroup = 4 output rows x 256 pixels; wavefront = one row; lane = 4 consecutive pixels (one 12-byte store).
+// Workgroup = 8 output rows x 256 pixels; wavefront = kRows consecutive rows; lane = 4 consecutive pixels per row (one
+// 12-byte store each).
 // The two source rows of an output row are shared by all its pixels: the wavefront copies the span it needs of both
 // (<= 800 bytes each, from the dword holding the first tap) into LDS with two global->LDS 16-byte loads per lane and
 // takes the taps from there (three dword reads per pixel and row + v_alignbyte for the 3-byte-pixel misalignment).
@@ -81,134 +82,145 @@ __device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b)
     return (uint32_t)(((unsigned long long)(a & 0xFFFFFFu) * (unsigned long long)(b & 0xFFFFFFu)) >> 32);
 }
 
+constexpr int kRows = 2;              // output rows per wavefront (amortises the scalar set-up and the column table)
+
 __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out, int n,
                                                      int W, int H, int left, int top, int cw,
                                                      const ResizeTab* __restrict__ xtab,
                                                      const ResizeTab* __restrict__ ytab, TileOrder order)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_rows[4][2 * kRowPitch + 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_rows[4][kRows][2 * kRowPitch + 64];
     int f, tile_y, tile_x;
     if (!order.decode(blockIdx.x, f, tile_y, tile_x)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int y = tile_y * 4 + wave;
+    const int ya = (tile_y * 4 + wave) * kRows;
     const int xw = tile_x * 256, x0 = xw + lane * 4;
-    if (y >= H) return;
+    if (ya >= H) return;
     const size_t frame_bytes = (size_t)W * H * 3;
     const uint8_t* __restrict__ src = frames + (size_t)f * frame_bytes;
     uint8_t* __restrict__ dst = out + (size_t)f * frame_bytes;
     const size_t limit = (size_t)(n - f) * frame_bytes;
-    const ResizeTab yt = ytab[y];
-    const uint32_t b0 = yt.w & 0xFFFFu, b1 = yt.w >> 16;
-    const uint32_t b0s = b0 << 8, b1s = b1 << 8;
-    const uint32_t row0 = (uint32_t)(top + (yt.ofs & 0xFFFF)) * (uint32_t)W + (uint32_t)left;
-    const uint32_t row1 = (uint32_t)(top + (yt.ofs >> 16)) * (uint32_t)W + (uint32_t)left;
+    const size_t base = (size_t)(uintptr_t)src;
 
     // span of source columns this wavefront touches: taps sx .. sx+1 for its first .. last pixel (the tables are
-    // monotone); staged when it fits the LDS rows and the 16-byte chunks stay inside the frame stack
+    // monotone); a row is staged when the span fits the LDS row and the 16-byte chunks stay inside the frame stack
     const uint32_t sx_first = (uint32_t)xtab[xw].ofs, sx_last = (uint32_t)xtab[min(xw + 255, W - 1)].ofs;
-    const size_t g0 = (size_t)(row0 + sx_first) * 3u, g1 = (size_t)(row1 + sx_first) * 3u;      // byte offsets in the frame
-    const size_t base = (size_t)(uintptr_t)src;
-    const uint32_t s0 = (uint32_t)((base + g0) & 3u), s1 = (uint32_t)((base + g1) & 3u);         // misalignment of each row
     const uint32_t span = 3u * (sx_last + 2u - sx_first);
-    const bool staged = span + 3u + 12u <= (uint32_t)kRowPitch && (g0 > g1 ? g0 : g1) - 3u + (size_t)kRowPitch <= limit &&
-                        g0 >= 3u && g1 >= 3u;
-    if (staged) {
-        if (lane < kRowPitch / 16) {
+    uint32_t row0[kRows], row1[kRows], b0s[kRows], b1s[kRows], s0[kRows], s1[kRows];
+    bool staged[kRows];
+#pragma unroll
+    for (int q = 0; q < kRows; ++q) {
+        const ResizeTab yt = ytab[min(ya + q, H - 1)];
+        b0s[q] = (yt.w & 0xFFFFu) << 8;
+        b1s[q] = (yt.w >> 16) << 8;
+        row0[q] = (uint32_t)(top + (yt.ofs & 0xFFFF)) * (uint32_t)W + (uint32_t)left;
+        row1[q] = (uint32_t)(top + (yt.ofs >> 16)) * (uint32_t)W + (uint32_t)left;
+        const size_t g0 = (size_t)(row0[q] + sx_first) * 3u, g1 = (size_t)(row1[q] + sx_first) * 3u;     // byte offsets in the frame
+        s0[q] = (uint32_t)((base + g0) & 3u);                                                          // misalignment of each row
+        s1[q] = (uint32_t)((base + g1) & 3u);
+        staged[q] = ya + q < H && span + 3u + 12u <= (uint32_t)kRowPitch && g0 >= 3u && g1 >= 3u &&
+                    (g0 > g1 ? g0 : g1) - 3u + (size_t)kRowPitch <= limit;
+        if (staged[q] && lane < kRowPitch / 16) {
             uint32_t o = (uint32_t)lane << 4;
             asm("" : "+v"(o));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (g0 - s0) + o),
-                                             (__attribute__((address_space(3))) void*)&s_rows[wave][0], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (g1 - s1) + o),
-                                             (__attribute__((address_space(3))) void*)&s_rows[wave][kRowPitch], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (g0 - s0[q]) + o),
+                                             (__attribute__((address_space(3))) void*)&s_rows[wave][q][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (g1 - s1[q]) + o),
+                                             (__attribute__((address_space(3))) void*)&s_rows[wave][q][kRowPitch], 16, 0, 0);
         }
     }
-    if (x0 >= W) {
-        if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
-    uint32_t px[4];
-    // Fast path: the lane's four pixels are inside the frame and every tap load stays inside the frame stack.
-    // Where sx is the last column of the crop the second weight is 0, so whatever lies right of it may be read.
-    const bool whole = x0 + 3 < W && ((size_t)(max(row0, row1) + (uint32_t)cw) * 3u + 8u <= limit);
-    if (staged || whole) {
-        ResizeTab xt[4];
-        uint2 a[4], b[4];
+    ResizeTab xt[4];
+    if (x0 < W) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) xt[j] = xtab[min(x0 + j, W - 1)];
-        if (staged) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // staged rows (and the column table) have landed
+    if (x0 >= W) return;
+
+#pragma unroll
+    for (int q = 0; q < kRows; ++q) {
+        const int y = ya + q;
+        if (y >= H) break;
+        uint32_t px[4];
+        // Fast path: the lane's four pixels are inside the frame and every tap load stays inside the frame stack.
+        // Where sx is the last column of the crop the second weight is 0, so whatever lies right of it may be read.
+        const bool whole = x0 + 3 < W && ((size_t)(max(row0[q], row1[q]) + (uint32_t)cw) * 3u + 8u <= limit);
+        if (staged[q] || whole) {
+            uint2 a[4], b[4];
+            if (staged[q]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t rel = 3u * ((uint32_t)xt[j].ofs - sx_first);
+                    const uint32_t at0 = rel + s0[q], at1 = rel + s1[q];
+                    const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(&s_rows[wave][q][at0 & ~3u]);
+                    const uint32_t* __restrict__ r = reinterpret_cast<const uint32_t*>(&s_rows[wave][q][kRowPitch + (at1 & ~3u)]);
+                    const uint32_t t0 = p[0], t1 = p[1], t2 = p[2], u0 = r[0], u1 = r[1], u2 = r[2];
+                    a[j].x = __builtin_amdgcn_alignbyte(t1, t0, at0);
+                    a[j].y = __builtin_amdgcn_alignbyte(t2, t1, at0);
+                    b[j].x = __builtin_amdgcn_alignbyte(u1, u0, at1);
+                    b[j].y = __builtin_amdgcn_alignbyte(u2, u1, at1);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    __builtin_memcpy(&a[j], src + (row0[q] + (uint32_t)xt[j].ofs) * 3u, 8);
+                    __builtin_memcpy(&b[j], src + (row1[q] + (uint32_t)xt[j].ofs) * 3u, 8);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t rel = 3u * ((uint32_t)xt[j].ofs - sx_first);
-                const uint32_t at0 = rel + s0, at1 = rel + s1;
-                const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(&s_rows[wave][at0 & ~3u]);
-                const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(&s_rows[wave][kRowPitch + (at1 & ~3u)]);
-                const uint32_t t0 = p[0], t1 = p[1], t2 = p[2], u0 = q[0], u1 = q[1], u2 = q[2];
-                a[j].x = __builtin_amdgcn_alignbyte(t1, t0, at0);
-                a[j].y = __builtin_amdgcn_alignbyte(t2, t1, at0);
-                b[j].x = __builtin_amdgcn_alignbyte(u1, u0, at1);
-                b[j].y = __builtin_amdgcn_alignbyte(u2, u1, at1);
+                // bytes: B0 G0 R0 B1 | G1 R1 . .  -> (S[sx], S[sx+1]) as two uint16 per channel, then v_dot2_u32_u16 with
+                // the weights pre-scaled by 16: T = 16 t < 2^24, T & ~255 = 256 (t >> 4), and (b * (t >> 4)) >> 16 is the
+                // high half of the 24 x 24-bit product (256 b) * (256 (t >> 4)): one v_and + one v_mul_hi_u32_u24 per term
+                const uint32_t w = xt[j].w;                                        // 16 a0 | 16 a1 << 16
+                const uint32_t tB0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C030C00u), w, 0u);
+                const uint32_t tG0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C040C01u), w, 0u);
+                const uint32_t tR0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C050C02u), w, 0u);
+                const uint32_t tB1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C030C00u), w, 0u);
+                const uint32_t tG1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C040C01u), w, 0u);
+                const uint32_t tR1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C050C02u), w, 0u);
+                const uint32_t vB = (mulhi_u24(b0s[q], tB0 & ~255u) + mulhi_u24(b1s[q], tB1 & ~255u) + 2u) >> 2;
+                const uint32_t vG = (mulhi_u24(b0s[q], tG0 & ~255u) + mulhi_u24(b1s[q], tG1 & ~255u) + 2u) >> 2;
+                const uint32_t vR = (mulhi_u24(b0s[q], tR0 & ~255u) + mulhi_u24(b1s[q], tR1 & ~255u) + 2u) >> 2;
+                px[j] = min(vB, 255u) | (min(vG, 255u) << 8) | (min(vR, 255u) << 16);
             }
         } else {
+            const uint32_t b0 = b0s[q] >> 8, b1 = b1s[q] >> 8;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                __builtin_memcpy(&a[j], src + (row0 + (uint32_t)xt[j].ofs) * 3u, 8);
-                __builtin_memcpy(&b[j], src + (row1 + (uint32_t)xt[j].ofs) * 3u, 8);
+                px[j] = 0;
+                if (x0 + j >= W) continue;
+                const uint32_t a0 = (xt[j].w & 0xFFFFu) >> 4, a1 = xt[j].w >> 20;
+                const uint32_t sx = (uint32_t)xt[j].ofs, sx1 = min(sx + 1u, (uint32_t)(cw - 1));     // a1 == 0 where sx == cw-1
+                const uint32_t p00 = load_bgr(src, (row0[q] + sx) * 3u, limit), p01 = load_bgr(src, (row0[q] + sx1) * 3u, limit);
+                const uint32_t p10 = load_bgr(src, (row1[q] + sx) * 3u, limit), p11 = load_bgr(src, (row1[q] + sx1) * 3u, limit);
+                uint32_t r = 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t t0 = ((p00 >> (8 * c)) & 255u) * a0 + ((p01 >> (8 * c)) & 255u) * a1;
+                    const uint32_t t1 = ((p10 >> (8 * c)) & 255u) * a0 + ((p11 >> (8 * c)) & 255u) * a1;
+                    const uint32_t v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2u) >> 2;
+                    r |= min(v, 255u) << (8 * c);
+                }
+                px[j] = r;
             }
         }
+        const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
+        if ((W & 3) == 0 && x0 + 3 < W) {
+            uint3 d;
+            d.x = px[0] | (px[1] << 24);
+            d.y = (px[1] >> 8) | (px[2] << 16);
+            d.z = (px[2] >> 16) | (px[3] << 8);
+            *reinterpret_cast<uint3*>(dst + o) = d;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // bytes: B0 G0 R0 B1 | G1 R1 . .  -> (S[sx], S[sx+1]) as two uint16 per channel, then v_dot2_u32_u16 with the
-            // weights pre-scaled by 16: T = 16 t < 2^24, T & ~255 = 256 (t >> 4), and (b * (t >> 4)) >> 16 is the high
-            // half of the 24 x 24-bit product (256 b) * (256 (t >> 4)): one v_and + one v_mul_hi_u32_u24 per term
-            const uint32_t w = xt[j].w;                                        // 16 a0 | 16 a1 << 16
-            const uint32_t tB0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C030C00u), w, 0u);
-            const uint32_t tG0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C040C01u), w, 0u);
-            const uint32_t tR0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C050C02u), w, 0u);
-            const uint32_t tB1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C030C00u), w, 0u);
-            const uint32_t tG1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C040C01u), w, 0u);
-            const uint32_t tR1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C050C02u), w, 0u);
-            const uint32_t vB = (mulhi_u24(b0s, tB0 & ~255u) + mulhi_u24(b1s, tB1 & ~255u) + 2u) >> 2;
-            const uint32_t vG = (mulhi_u24(b0s, tG0 & ~255u) + mulhi_u24(b1s, tG1 & ~255u) + 2u) >> 2;
-            const uint32_t vR = (mulhi_u24(b0s, tR0 & ~255u) + mulhi_u24(b1s, tR1 & ~255u) + 2u) >> 2;
-            px[j] = min(vB, 255u) | (min(vG, 255u) << 8) | (min(vR, 255u) << 16);
+            for (int j = 0; j < 4; ++j)
+                if (x0 + j < W) {
+                    dst[o + 3 * j + 0] = (uint8_t)(px[j]);
+                    dst[o + 3 * j + 1] = (uint8_t)(px[j] >> 8);
+                    dst[o + 3 * j + 2] = (uint8_t)(px[j] >> 16);
+                }
         }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            px[j] = 0;
-            if (x0 + j >= W) continue;
-            const ResizeTab xt = xtab[x0 + j];
-            const uint32_t a0 = (xt.w & 0xFFFFu) >> 4, a1 = xt.w >> 20;
-            const uint32_t sx = (uint32_t)xt.ofs, sx1 = min(sx + 1u, (uint32_t)(cw - 1));     // a1 == 0 where sx == cw-1
-            const uint32_t p00 = load_bgr(src, (row0 + sx) * 3u, limit), p01 = load_bgr(src, (row0 + sx1) * 3u, limit);
-            const uint32_t p10 = load_bgr(src, (row1 + sx) * 3u, limit), p11 = load_bgr(src, (row1 + sx1) * 3u, limit);
-            uint32_t r = 0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const uint32_t t0 = ((p00 >> (8 * c)) & 255u) * a0 + ((p01 >> (8 * c)) & 255u) * a1;
-                const uint32_t t1 = ((p10 >> (8 * c)) & 255u) * a0 + ((p11 >> (8 * c)) & 255u) * a1;
-                const uint32_t v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2u) >> 2;
-                r |= min(v, 255u) << (8 * c);
-            }
-            px[j] = r;
-        }
-    }
-    const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
-    if ((W & 3) == 0 && x0 + 3 < W) {
-        uint3 d;
-        d.x = px[0] | (px[1] << 24);
-        d.y = (px[1] >> 8) | (px[2] << 16);
-        d.z = (px[2] >> 16) | (px[3] << 8);
-        *reinterpret_cast<uint3*>(dst + o) = d;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (x0 + j < W) {
-                dst[o + 3 * j + 0] = (uint8_t)(px[j]);
-                dst[o + 3 * j + 1] = (uint8_t)(px[j] >> 8);
-                dst[o + 3 * j + 2] = (uint8_t)(px[j] >> 16);
-            }
     }
 }
 
@@ -235,7 +247,7 @@ int launch_crop_resize(const uint8_t* frames, uint8_t* out, int n, int W, int H,
     int rc = hip_fail(hipGetLastError(), "resize_tables_kernel launch");
     if (rc != MF_OK) return rc;
     TileOrder order;
-    if (!make_tile_order((W + 255) / 256, (H + 3) / 4, n, order)) {
+    if (!make_tile_order((W + 255) / 256, (H + 4 * kRows - 1) / (4 * kRows), n, order)) {
         set_error("mf_crop_resize_u8c3: too many tiles");
         return MF_ERR_INVALID_ARG;
     }

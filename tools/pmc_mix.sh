@@ -6,5 +6,5 @@ for set in "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_V
   i=$((i+1))
   rm -rf /tmp/pp$i
   timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pp$i -o r -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-frames 0 > $O/prof/pmc_$1_$i.log 2>&1
-  grep "warp_kernel" /tmp/pp$i/r_counter_collection.csv | tail -8 | awk -F',' '{n=NF; print $(n-3), $(n-2), $(n)-$(n-1)}'
+  grep "${KERNEL:-warp_kernel}" /tmp/pp$i/r_counter_collection.csv | tail -8 | awk -F',' '{n=NF; print $(n-3), $(n-2), $(n)-$(n-1)}'
 done
