@@ -16,28 +16,31 @@
 // oracle (oracle/warp_oracle.c).
 //
 // Mapping (gfx950).  A 256-thread workgroup owns a 128 x 8 pixel tile of one frame (tile rows start on a
-// 128-byte boundary of the 3-byte-per-pixel output when W % 128 == 0: 1080p, 4K).  Each wavefront owns a
-// 32 x 8 pixel "footprint" of the tile; a lane owns 4 consecutive pixels
-// of one row (12 contiguous output bytes -> one global_store_dwordx3).  Per footprint:
-//   1. The candidate cells come from the footprint PLAN written by footprint_plan_kernel (cell_table.hip):
-//      up to 8 cells in descending order, each IN (all 256 pixels pass its mask test) or MIXED, cells that
-//      cannot own a pixel already dropped.  The plan is wave-uniform: one scalar load.
-//   2. One IN cell (the common case, ~65 % of footprints at config-2 geometry): no per-pixel test; the
-//      cell's Hi comes in through scalar loads and the four coordinates are straight-line float64 code with
-//      an IEEE-exact reciprocal trimmed for 0.5 <= |w| < 2.
-//   3. Several cells: their Hi go to LDS; ownership is resolved last cell first with a float32 evaluation
-//      of the cell's four affine edge functions, which decides unless the pixel is within the float32 error band of the
-//      mask edge -- then a division-free float64 comparison, and OpenCV's exact arithmetic (division, rint)
-//      only within 1e-6 of the edge; every pixel then computes its coordinates once with its owner's Hi
-//      read from LDS.  More than 8 candidates: every cell of the recorded index range is tested.
-//   4. cv2.remap: sx = rint(32u) via one fma against 1.5*2^23; if every tap of the wave lies at least two
-//      pixels inside the frame (one max-reduction per lane, one ballot) two unaligned 8-byte loads per
-//      pixel fetch the 2x2 taps, the horizontal lerps are v_dot4_u32_u8, the vertical lerp two chained
-//      v_mad_u32_u24 scaled so that the rounded byte lands in byte 2, v_perm_b32 packs B,G,R; otherwise a
-//      per-tap path handles frame borders, uncovered pixels and the crop flags.
+// 128-byte boundary of the 3-byte-per-pixel output when W % 128 == 0: 1080p, 4K); tiles are handed out XCD-aware
+// (mf_common.h TileOrder).  Each wavefront owns a 32 x 8 pixel "footprint" of the tile; a lane owns 4 consecutive
+// pixels of one row (12 contiguous output bytes -> one global_store_dwordx3).  Per footprint:
+//   1. footprint_plan_kernel (cell_table.hip) wrote the wave-uniform PLAN (one scalar load): up to 8 candidate cells
+//      in descending order, each IN (all 256 pixels pass its mask test) or MIXED, with -- for short lists -- the one
+//      mask edge that can fail; and the footprint's SOURCE REGION, the window of the source frame that holds every
+//      bilinear tap of every pixel.
+//   2. The window goes to LDS asynchronously: two global_load_lds_dwordx4 per lane, issued first, awaited after the
+//      coordinate arithmetic.
+//   3. One IN cell (~66 % of footprints at config-2 geometry): no per-pixel test; the cell's Hi comes in through
+//      scalar loads and the four coordinates are straight-line float64 code with an IEEE-exact reciprocal trimmed
+//      for 0.5 <= |w| < 2.
+//   4. Two cells with one uncertain edge each (~27 %): one float32 fma per pixel and cell decides ownership.
+//      Otherwise the general last-cell-first loop.  A pixel inside the float32 error band of an edge is decided by a
+//      division-free float64 comparison, and by OpenCV's exact arithmetic (division, rint) only within 1e-6 of the
+//      edge.  Every pixel then computes its coordinates once with its owner's Hi read from LDS.  More than 8
+//      candidates: every cell of the recorded index range is tested.
+//   5. cv2.remap: sx = rint(32u) via one fma against 1.5*2^23; taps = three dword LDS reads per pixel and row +
+//      v_alignbyte_b32, horizontal lerps v_dot4_u32_u8, vertical lerp two chained v_mad_u32_u24 scaled so that the
+//      rounded byte lands in byte 2, nine v_perm_b32 gather the lane's 12 output bytes.  Footprints the plan could
+//      not certify (frame border, uncovered pixels, oversized or unaligned windows) check per pixel and use either
+//      two unaligned 8-byte global loads per pixel or the per-tap path with border colour and crop flags.
 // Algorithmic HBM traffic: 2*H*W*3 bytes per frame (each source byte read once, each output byte written
-// once); cell table + plan add < 2 %.  No dense contraction: no MFMA.  The kernel is VALU-issue bound (exact
-// float64 coordinates), not HBM bound: DESIGN.md section 4.3, profiles/.
+// once); measured 1.02x that.  No dense contraction: no MFMA.  The kernel is VALU-issue bound (exact float64
+// coordinates + integer blend), not HBM bound: DESIGN.md section 4.3, profiles/.
 #include "mf_common.h"
 
 namespace mf {

@@ -19,6 +19,8 @@ def run(cases=200, seed0=0, only=-1, big=False):
         kind = g.choice(['warp', 'warp', 'warp', 'jacobi', 'resize'])
         if kind == 'warp':
             W = int(g.integers(8, 2100 if big else 420)); H = int(g.integers(8, 1200 if big else 300))
+            if g.random() < 0.6:
+                W = max(8, W & ~3)                               # the LDS-staged tap path needs W % 4 == 0
             R = int(g.integers(1, min(64 if big else 24, H // 2) + 1)); C = int(g.integers(1, min(64 if big else 24, W // 2) + 1))
             n = int(g.integers(1, 3 if big else 4))
             sigma = float(g.choice([0.2, 1.0, 3.0, 8.0, 25.0])) * min(1.0, min(W / C, H / R) / 20.0 + 0.05)
