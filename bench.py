@@ -11,7 +11,7 @@ once, before the closing barrier.  N = 1 runs
 BASELINE.json configs[1] (1080p, 300 frames, 16x16 mesh, 100 Jacobi sweeps, ORIGINAL weights).
 N > 1 (launched by torch.distributed.run, one rank per GPU) shards ONE clip of 300*N frames by contiguous
 frame range: Jacobi replicated, each rank warps its own 300 frames, one 16-byte all-reduce of the crop
-bounds (weak scaling; no frame gather inside the timed region -- see DESIGN.md).
+bounds (weak scaling); the RCCL gather of all frames to rank 0 is timed once after the timed region.
 
 Rank 0 prints ONE JSON line (fields: see the task's bench contract) including
   roofline:     warp kernel, algorithmic bytes 2*H*W*3 per frame over its HIP-event time, vs 8 TB/s HBM
@@ -96,7 +96,8 @@ def main():
     ap.add_argument('--frames-kind', default='pattern', choices=['pattern', 'noise'])
     ap.add_argument('--cpu-frames', type=int, default=300, help='frames warped by the CPU baseline (0 = skip)')
     # default: the whole clip, ~5-10 s of host time
-    ap.add_argument('--gather', action='store_true', help='also time one RCCL gather of all frames to rank 0')
+    ap.add_argument('--gather', action='store_true', help='(default for N > 1 in shard mode; kept for compatibility)')
+    ap.add_argument('--no-gather', action='store_true', help='N > 1: skip the RCCL gather of all frames to rank 0 after the timed region')
     ap.add_argument('--mode', default='shard', choices=['shard', 'clips'],
                     help='N > 1: "shard" = ONE clip of N x frames sharded by frame range (Jacobi replicated, 16-byte crop '
                          'all-reduce); "clips" = N independent clips, one per GPU, no collective (BASELINE config 5)')
@@ -217,13 +218,20 @@ def main():
             clib.vertex_motion(W, H, R, C, stab.feature_ellipse_row_count, stab.feature_ellipse_col_count, feats, hom, openmp=True)
             motion_row['cpu_port_pairs_per_s'] = (F - 1) / (time.perf_counter() - t1)
             motion_row['cpu_port_threads'] = threads
-    gather_ms = None
-    if args.gather and world > 1:
-        barrier()
-        t1 = time.perf_counter()
-        mfdist.gather_frames(d_out, F)
-        barrier()
-        gather_ms = (time.perf_counter() - t1) * 1e3
+    # north_star's "single RCCL gather over xGMI at the end": timed once, after the timed region (it is 7 x 1.87 GB into
+    # one GPU -- an order of magnitude above a step -- and a consumer in host memory is better served by every rank
+    # draining its own shard over its own PCIe link).  --no-gather skips it.
+    gather_ms, gather_error = None, None
+    if world > 1 and not clips_mode and not args.no_gather:
+        try:
+            barrier()
+            t1 = time.perf_counter()
+            gathered = mfdist.gather_frames(d_out, F)
+            barrier()
+            gather_ms = (time.perf_counter() - t1) * 1e3
+            del gathered
+        except Exception as e:                      # never let the optional collective take the measurement down
+            gather_error = f'{type(e).__name__}: {e}'
 
     if rank == 0:
         algo_bytes = 2.0 * H * W * 3 * (hi - lo)
@@ -247,7 +255,7 @@ def main():
                                        f'frame-range shards x{world}, Jacobi replicated, 16-byte crop all-reduce')},
             'roofline': {'kernel': 'warp_kernel', 'bound': 'hbm', 'achieved': achieved / 1e9,
                          'peak': HBM_PEAK_BYTES_PER_S / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_BYTES_PER_S,
-                         'traffic': traffic, 'traffic_source': 'profiles/traffic.json (PMC FETCH_SIZE/WRITE_SIZE, calibrated)'
+                         'traffic': traffic, 'traffic_source': 'profiles/traffic.json (PMC: size-resolved TCC_EA0_RDREQ read requests + WRITE_SIZE)'
                          if traffic else None,
                          'algorithmic_bytes_per_launch': algo_bytes, 'avg_launch_ms': warp_ms,
                          'note': 'VALU-issue bound (float64 coordinate arithmetic), not HBM bound: see DESIGN.md'},
@@ -267,6 +275,9 @@ def main():
             result.setdefault('next_rows', {})['vertex_motion'] = motion_row
         if gather_ms is not None:
             result['gather_to_rank0_ms'] = gather_ms
+            result['gather_note'] = 'one RCCL gather of every rank\'s stabilized frames to rank 0, after the timed region'
+        if gather_error is not None:
+            result['gather_error'] = gather_error
         if world == 1 and args.cpu_frames > 0:
             result['cpu_baseline'] = cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, args.cpu_frames)
         else:
