@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     const float cxs[2] = { (float)xa, (float)xb }, cys[2] = { (float)ya, (float)yb };
     const float* __restrict__ fedge = edges + (size_t)f * R * C * MF_EDGE_FLOATS;
     const double* __restrict__ frec = records + (size_t)f * R * C * MF_CELL_DOUBLES;
-    double umin = 1e30, umax = -1e30, vmin = 1e30, vmax = -1e30;
+    float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
     bool sane = true;
     for (int r = r_hi; r >= r_lo && !closed && !overflow; --r)
         for (int c = c_hi; c >= c_lo && !closed && !overflow; --c) {
@@ -349,15 +349,19 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
             codes[cnt] = (uint16_t)(MF_PLAN_CODES | (uncertain == 1 ? which : 4));
             p.e[cnt++] = (uint16_t)(k | MF_PLAN_VALID | (all_in ? MF_PLAN_IN : 0u));
             if (all_in) closed = true;
+            // source position of the four footprint corners under this cell's inverse homography (float32 is ample:
+            // the window keeps a pixel of slack, the float32 error at coordinates below 32768 is below 0.01)
             const double* __restrict__ hi = frec + (size_t)k * MF_CELL_DOUBLES + MF_CELL_OFF_HI;
+            const float h0 = (float)hi[0], h1 = (float)hi[1], h2 = (float)hi[2], h3 = (float)hi[3], h4 = (float)hi[4];
+            const float h5 = (float)hi[5], h6 = (float)hi[6], h7 = (float)hi[7], h8 = (float)hi[8];
             for (int q = 0; q < 4; ++q) {
-                const double cx = (double)cxs[q & 1], cy = (double)cys[q >> 1];
-                const double w = hi[6] * cx + hi[7] * cy + hi[8];
-                sane = sane && w > 0.25 && w < 4.0;                       // (NaN fails)
-                const double iw = 1.0 / w;
-                const double u = (hi[0] * cx + hi[1] * cy + hi[2]) * iw, v = (hi[3] * cx + hi[4] * cy + hi[5]) * iw;
-                umin = fmin(umin, u); umax = fmax(umax, u);
-                vmin = fmin(vmin, v); vmax = fmax(vmax, v);
+                const float cx = cxs[q & 1], cy = cys[q >> 1];
+                const float w = h6 * cx + h7 * cy + h8;
+                sane = sane && w > 0.25f && w < 4.0f;                     // (NaN fails)
+                const float iw = 1.0f / w;
+                const float u = (h0 * cx + h1 * cy + h2) * iw, v = (h3 * cx + h4 * cy + h5) * iw;
+                umin = fminf(umin, u); umax = fmaxf(umax, u);
+                vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
             }
         }
     if (!overflow && cnt <= 4)
@@ -370,10 +374,10 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     plan[gid] = p;
     uint32_t region = 0;
     if (sane && cnt > 0 && !overflow && (W & 3) == 0 && 3 * W >= MF_STAGE_PITCH && H > MF_STAGE_ROWS &&
-        umin > -4.0 && vmin > -4.0 && umax < 40000.0 && vmax < 40000.0) {
+        umin > -4.0f && vmin > -4.0f && umax < 40000.0f && vmax < 40000.0f) {
         // taps of a pixel at (u, v): columns floor(u) .. floor(u)+1 up to 1/64 px of rounding -> one pixel of slack
-        const int ix_lo = (int)floor(umin) - 1, ix_hi = (int)floor(umax) + 2;
-        const int iy_lo = (int)floor(vmin) - 1, iy_hi = (int)floor(vmax) + 2;
+        const int ix_lo = (int)floorf(umin) - 1, ix_hi = (int)floorf(umax) + 2;
+        const int iy_lo = (int)floorf(vmin) - 1, iy_hi = (int)floorf(vmax) + 2;
         const int sx0 = min(max(ix_lo, 0), (3 * W - MF_STAGE_PITCH) / 3), sy0 = min(max(iy_lo, 0), H - MF_STAGE_ROWS - 1);
         if (ix_lo >= sx0 && ix_hi <= sx0 + MF_STAGE_COLS - 1 && iy_lo >= sy0 && iy_hi <= sy0 + MF_STAGE_ROWS - 1)
             region = MF_REGION_STAGED | ((uint32_t)sy0 << 15) | (uint32_t)sx0 |

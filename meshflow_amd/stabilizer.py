@@ -351,12 +351,30 @@ class MeshFlowStabilizer:
 
     def _jacobi_coefficients_device(self, num_frames, frame_width, frame_height, adaptive_weights_definition,
                                     homographies, device):
+        """Band coefficients (host, O(F): mfs.py:713-841 restated in host.py) -> device.  The upload goes through a
+        small ring of pinned buffers with a non-blocking copy: a pageable copy would wait for everything already
+        queued on the stream, i.e. serialise this host work with the previous clip's kernels."""
         import torch
         taps, lam, inv_on = host.jacobi_band_coefficients(
             num_frames, frame_width, frame_height, adaptive_weights_definition,
             np.asarray(homographies, dtype=np.float64), self.temporal_smoothing_radius)
-        packed = torch.from_numpy(np.concatenate([taps, lam, inv_on])).to(device)
         nt = taps.size
+        total = nt + 2 * num_frames
+        ring = getattr(self, '_coef_ring', None)
+        if ring is None or ring['size'] != total or ring['device'] != device:
+            ring = {'size': total, 'device': device, 'next': 0,
+                    'slots': [(torch.empty(total, dtype=torch.float64).pin_memory(), torch.cuda.Event()) for _ in range(4)]}
+            self._coef_ring = ring
+        staging, done = ring['slots'][ring['next']]
+        ring['next'] = (ring['next'] + 1) % len(ring['slots'])
+        done.synchronize()                                   # the copy that last used this slot (long finished)
+        view = staging.numpy()
+        view[:nt] = taps
+        view[nt:nt + num_frames] = lam
+        view[nt + num_frames:] = inv_on
+        packed = torch.empty(total, dtype=torch.float64, device=device)
+        packed.copy_(staging, non_blocking=True)
+        done.record(torch.cuda.current_stream(device))
         return packed[:nt], packed[nt:nt + num_frames], packed[nt + num_frames:]
 
     def _stabilized_vertex_displacements_device(self, d_disp, frame_width, frame_height,

@@ -20,3 +20,10 @@ for F, R, C, om, it in ((300,16,16,10,100),(600,16,16,10,100),(1200,16,16,10,100
     ms = t(lambda: ops.jacobi(b, *tt, om, it, out=out))
     flops = it * F * b.shape[1] * (2 * (2 * om + 1) + 3)
     print(f'F={F} mesh={R}x{C} omega={om} iters={it}: {ms:.3f} ms  {flops/ms/1e9:.2f} TFLOP/s')
+import time
+for F in (300, 2400):
+    disp, hom = synthetic.motion(F, 16, 16, seed=0)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        host.jacobi_band_coefficients(F, 1920, 1080, 0, hom, 10)
+    print(f'host coefficient set-up F={F}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms')
