@@ -4,24 +4,27 @@
 // iterated `iters` times from x = b.  float64 throughout: after N sweeps the reference is far from
 // converged, so the iteration itself is replicated, and an fp32 state misses the 1e-4 bar.
 //
-// Mapping (gfx950): one 64-lane wavefront per series.  Lane l owns K consecutive frames
+// Mapping (gfx950): one workgroup of WAVES wavefronts per series.  Thread l owns K consecutive frames
 // [l*K, l*K+K); the state x lives in LDS (double-buffered, OMEGA zero-halo entries on both sides);
-// each sweep a lane pulls its K+2*OMEGA window into registers with ds_read_b64, forms K dot products
+// each sweep a thread pulls its K+2*OMEGA window into registers with ds_read_b64, forms K dot products
 // of 2*OMEGA+1 taps with v_fma_f64 (taps are wave-uniform -> scalar registers), and writes K values
-// back.  A 64-thread workgroup needs no cross-wave barrier; everything stays on chip for all sweeps:
-// HBM traffic is one read of b and one write of x.  This kernel is FP64-VALU / LDS bound, not HBM bound.
+// back; one barrier per sweep.  Everything stays on chip for all sweeps: HBM traffic is one read of b and
+// one write of x.  This kernel is FP64-VALU / LDS bound, not HBM bound.  WAVES = 1 (no cross-wave barrier)
+// when there are enough series to fill the 1024 SIMDs; long clips of small meshes (fewer series than SIMDs,
+// e.g. the replicated sweep of a multi-GPU run) spread each series over up to 8 wavefronts instead.
 #include "mf_common.h"
 
 namespace mf {
 
-template <int OMEGA, int K>
-__global__ __launch_bounds__(64) void jacobi_wave_kernel(const double* __restrict__ b, double* __restrict__ x_out,
+template <int OMEGA, int K, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* __restrict__ b, double* __restrict__ x_out,
                                                          const double* __restrict__ taps,
                                                          const double* __restrict__ lam,
                                                          const double* __restrict__ inv_on, int F, int S, int iters)
 {
     constexpr int NT = 2 * OMEGA + 1;
-    constexpr int LEN = 64 * K + 2 * OMEGA;
+    constexpr int NTHR = 64 * WAVES;
+    constexpr int LEN = NTHR * K + 2 * OMEGA;
     __shared__ double xs[2][LEN];
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(64) void jacobi_wave_kernel(const double* __restric
         two_lam[k] = in ? 2.0 * lam[t] : 0.0;
         inv[k] = in ? inv_on[t] : 0.0;            // frames past the end stay exactly 0 = the zero halo
     }
-    for (int i = lane; i < LEN; i += 64) { xs[0][i] = 0.0; xs[1][i] = 0.0; }
+    for (int i = lane; i < LEN; i += NTHR) { xs[0][i] = 0.0; xs[1][i] = 0.0; }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; ++k) xs[0][OMEGA + lane * K + k] = bt[k];   // x_start = b
@@ -107,11 +110,12 @@ __global__ __launch_bounds__(256) void jacobi_generic_kernel(const double* __res
     for (int t = threadIdx.x; t < F; t += blockDim.x) x_out[(size_t)t * S + s] = cur[omega + t];
 }
 
-template <int OMEGA, int K>
+template <int OMEGA, int K, int WAVES>
 static int launch_wave(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
                        int F, int S, int iters, hipStream_t st)
 {
-    hipLaunchKernelGGL((jacobi_wave_kernel<OMEGA, K>), dim3(S), dim3(64), 0, st, b, x, taps, lam, inv_on, F, S, iters);
+    hipLaunchKernelGGL((jacobi_wave_kernel<OMEGA, K, WAVES>), dim3(S), dim3(64 * WAVES), 0, st, b, x, taps, lam, inv_on, F, S,
+                       iters);
     return hip_fail(hipGetLastError(), "jacobi_wave_kernel launch");
 }
 
@@ -122,16 +126,34 @@ int launch_jacobi(const double* b, double* x, const double* taps, const double* 
         set_error("mf_jacobi_f64: bad sizes F=%d S=%d omega=%d iters=%d", F, S, omega, iters);
         return MF_ERR_INVALID_ARG;
     }
+    // enough series to give every SIMD a wavefront of its own: one wavefront per series, more frames per lane;
+    // otherwise the fewest frames per lane, i.e. as many wavefronts per series as the clip length needs
+    const bool many = S >= 1024;
+#define MF_JACOBI(O, K, WV) return launch_wave<O, K, WV>(b, x, taps, lam, inv_on, F, S, iters, st)
     if (omega == 10) {
-        if (F <= 64 * 5) return launch_wave<10, 5>(b, x, taps, lam, inv_on, F, S, iters, st);
-        if (F <= 64 * 10) return launch_wave<10, 10>(b, x, taps, lam, inv_on, F, S, iters, st);
-        if (F <= 64 * 19) return launch_wave<10, 19>(b, x, taps, lam, inv_on, F, S, iters, st);
-        if (F <= 64 * 38) return launch_wave<10, 38>(b, x, taps, lam, inv_on, F, S, iters, st);
+        if (F <= 64 * 5) MF_JACOBI(10, 5, 1);
+        if (many) {
+            if (F <= 64 * 10) MF_JACOBI(10, 10, 1);
+            if (F <= 64 * 19) MF_JACOBI(10, 19, 1);
+            if (F <= 64 * 38) MF_JACOBI(10, 38, 1);
+        }
+        if (F <= 128 * 5) MF_JACOBI(10, 5, 2);
+        if (F <= 256 * 5) MF_JACOBI(10, 5, 4);
+        if (F <= 512 * 5) MF_JACOBI(10, 5, 8);
+        if (F <= 512 * 10) MF_JACOBI(10, 10, 8);
+        if (F <= 512 * 19) MF_JACOBI(10, 19, 8);
     } else if (omega == 30) {
-        if (F <= 64 * 10) return launch_wave<30, 10>(b, x, taps, lam, inv_on, F, S, iters, st);
-        if (F <= 64 * 19) return launch_wave<30, 19>(b, x, taps, lam, inv_on, F, S, iters, st);
-        if (F <= 64 * 38) return launch_wave<30, 38>(b, x, taps, lam, inv_on, F, S, iters, st);
+        if (F <= 64 * 10) MF_JACOBI(30, 10, 1);
+        if (many) {
+            if (F <= 64 * 19) MF_JACOBI(30, 19, 1);
+            if (F <= 64 * 38) MF_JACOBI(30, 38, 1);
+        }
+        if (F <= 128 * 10) MF_JACOBI(30, 10, 2);
+        if (F <= 256 * 10) MF_JACOBI(30, 10, 4);
+        if (F <= 512 * 10) MF_JACOBI(30, 10, 8);
+        if (F <= 512 * 19) MF_JACOBI(30, 19, 8);
     }
+#undef MF_JACOBI
     const size_t lds = ((size_t)2 * (F + 2 * omega) + 2 * omega + 1) * sizeof(double);
     if (lds > 160 * 1024) {
         set_error("mf_jacobi_f64: F=%d omega=%d needs %zu bytes of LDS (> 160 KiB)", F, omega, lds);

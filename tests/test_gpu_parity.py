@@ -38,6 +38,24 @@ def _hip_jacobi(dev, b, taps, lam, inv_on, omega, iters):
 
 # ---------------------------------------------------------------------------------------------- Jacobi
 
+@pytest.mark.parametrize('F,S,omega', [(641, 6, 10), (1280, 5, 10), (2400, 7, 10), (2561, 3, 10), (5120, 2, 10), (9000, 2, 10),
+                                       (700, 4, 30), (2400, 3, 30), (5000, 2, 30), (9728, 1, 30), (10100, 1, 30),
+                                       (1300, 1100, 10)])
+def test_jacobi_long_clips_every_variant_vs_c_oracle(dev, F, S, omega):
+    """Few series + long clips spread a series over 2-8 wavefronts (the replicated sweep of a multi-GPU run); many series
+    keep one wavefront per series; beyond the specialised sizes the generic kernel takes over.  All bit-identical."""
+    from meshflow_amd import synthetic
+    from oracle import clib
+    iters = 6
+    b = np.cumsum(2.0 * synthetic.normal(np.arange(F * S).reshape(F, S), seed=F + omega), axis=0)
+    taps = np.exp(-np.square((3 / omega) * np.arange(-omega, omega + 1)))
+    lam = 0.95 * synthetic.uniform01(np.arange(F), seed=3)
+    inv_on = 1.0 / (1 + 2 * lam * taps.sum())
+    want = clib.jacobi_banded(b, taps, lam, inv_on, omega, iters, openmp=True)
+    got = _hip_jacobi(dev, b, taps, lam, inv_on, omega, iters)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize('definition', [0, 1, 2, 3])
 def test_jacobi_small_vs_reference_golden(dev, golden_dir, definition):
     from meshflow_amd.stabilizer import MeshFlowStabilizer
