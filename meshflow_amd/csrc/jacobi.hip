@@ -9,9 +9,8 @@
 // each sweep a thread pulls its K+2*OMEGA window into registers with ds_read_b64, forms K dot products
 // of 2*OMEGA+1 taps with v_fma_f64 (taps are wave-uniform -> scalar registers), and writes K values
 // back; one barrier per sweep.  Everything stays on chip for all sweeps: HBM traffic is one read of b and
-// one write of x.  This kernel is FP64-VALU / LDS bound, not HBM bound.  WAVES = 1 (no cross-wave barrier)
-// when there are enough series to fill the 1024 SIMDs; long clips of small meshes (fewer series than SIMDs,
-// e.g. the replicated sweep of a multi-GPU run) spread each series over up to 8 wavefronts instead.
+// one write of x.  This kernel is FP64-VALU / LDS bound, not HBM bound.  K is kept minimal (5 frames per thread at
+// OMEGA = 10, 10 at OMEGA = 30); clips longer than 64 K frames spread each series over 2-8 wavefronts.
 #include "mf_common.h"
 
 namespace mf {
@@ -126,17 +125,11 @@ int launch_jacobi(const double* b, double* x, const double* taps, const double* 
         set_error("mf_jacobi_f64: bad sizes F=%d S=%d omega=%d iters=%d", F, S, omega, iters);
         return MF_ERR_INVALID_ARG;
     }
-    // enough series to give every SIMD a wavefront of its own: one wavefront per series, more frames per lane;
-    // otherwise the fewest frames per lane, i.e. as many wavefronts per series as the clip length needs
-    const bool many = S >= 1024;
+    // the fewest frames per thread that covers the clip: a long clip spreads each series over up to 8 wavefronts
+    // (measured faster than more frames per lane even when there are more series than SIMDs: tools/time_jacobi.py)
 #define MF_JACOBI(O, K, WV) return launch_wave<O, K, WV>(b, x, taps, lam, inv_on, F, S, iters, st)
     if (omega == 10) {
         if (F <= 64 * 5) MF_JACOBI(10, 5, 1);
-        if (many) {
-            if (F <= 64 * 10) MF_JACOBI(10, 10, 1);
-            if (F <= 64 * 19) MF_JACOBI(10, 19, 1);
-            if (F <= 64 * 38) MF_JACOBI(10, 38, 1);
-        }
         if (F <= 128 * 5) MF_JACOBI(10, 5, 2);
         if (F <= 256 * 5) MF_JACOBI(10, 5, 4);
         if (F <= 512 * 5) MF_JACOBI(10, 5, 8);
@@ -144,10 +137,6 @@ int launch_jacobi(const double* b, double* x, const double* taps, const double* 
         if (F <= 512 * 19) MF_JACOBI(10, 19, 8);
     } else if (omega == 30) {
         if (F <= 64 * 10) MF_JACOBI(30, 10, 1);
-        if (many) {
-            if (F <= 64 * 19) MF_JACOBI(30, 19, 1);
-            if (F <= 64 * 38) MF_JACOBI(30, 38, 1);
-        }
         if (F <= 128 * 10) MF_JACOBI(30, 10, 2);
         if (F <= 256 * 10) MF_JACOBI(30, 10, 4);
         if (F <= 512 * 10) MF_JACOBI(30, 10, 8);

@@ -11,7 +11,7 @@ def t(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for F, R, C, om, it in ((300,16,16,10,100),(600,16,16,10,100),(1200,16,16,10,100),(2400,16,16,10,100),(600,32,32,30,200),(1200,32,32,30,200)):
+for F, R, C, om, it in ((600,32,32,10,100),(1200,32,32,10,100),(2400,32,32,10,100),(300,16,16,10,100),(600,16,16,10,100),(1200,16,16,10,100),(2400,16,16,10,100),(600,32,32,30,200),(1200,32,32,30,200)):
     disp, hom = synthetic.motion(F, R, C, seed=0)
     taps, lam, inv_on = host.jacobi_band_coefficients(F, 1920, 1080, 0, hom, om)
     b = torch.from_numpy(disp.reshape(F, -1)).to(dev)
