@@ -1,0 +1,27 @@
+import sys; sys.path.insert(0,'/root/repo')
+import numpy as np, torch
+from meshflow_amd import synthetic
+from meshflow_amd.stabilizer import MeshFlowStabilizer
+from oracle import clib, meshflow_oracle as mo
+def run(F,H,W,R,C,omega=3,iters=5,seed=0,**kw):
+    frames,disp,hom=synthetic.clip(F,H,W,R,C,seed=seed,kind='noise',**kw)
+    s=MeshFlowStabilizer(mesh_row_count=R,mesh_col_count=C,temporal_smoothing_radius=omega,optimization_num_iterations=iters)
+    try:
+        out,bounds,stab,score=s.stabilize_clip(list(frames),disp,hom)
+    except Exception as e:
+        print((F,H,W,R,C),'raised',type(e).__name__,str(e)[:100]); return
+    want,crop,bad=clib.warp_clip(frames,R,C,disp,stab)
+    ok=np.array_equal(np.stack(out),want) and tuple(int(b) for b in bounds)==(crop[:,0].max(),crop[:,1].max(),crop[:,2].min(),crop[:,3].min())
+    print((F,H,W,R,C),'ok' if ok else 'MISMATCH','bounds',tuple(int(b) for b in bounds),'score',score)
+run(1,32,32,2,2)
+run(2,32,32,2,2)
+run(3,2,2,1,1)
+run(3,5,7,1,1)
+run(4,16,16,8,8)
+run(4,64,64,64,64)
+run(3,40,2000,1,16)
+run(3,2000,40,16,1)
+run(5,100,100,3,3,translation_sigma=40.0)
+run(5,100,100,3,3,field_sigma=30.0)
+run(6,1080,1920,16,16,omega=10,iters=3,translation_sigma=60.0)
+run(4,1080,1920,16,16,omega=10,iters=3,field_sigma=15.0,jitter_sigma=4.0)
