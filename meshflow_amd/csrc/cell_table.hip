@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
             const int k = r * C + c;
             const float* __restrict__ ed = fedge + (size_t)k * MF_EDGE_FLOATS;
             bool all_in = true, any_out = false;
-            int uncertain = 0, which = 0;
+            int uncertain = 0, which = 0, which2 = 0;
             for (int e = 0; e < 4; ++e) {
                 // extrema of the affine function a x + b y + c over the footprint rectangle sit on its corners:
                 // min = c + min(a xa, a xb) + min(b ya, b yb), max likewise (NaN coefficients fail both tests)
@@ -342,11 +342,11 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
                 const float gmax = (fmaxf(ax0, ax1) + fmaxf(by0, by1)) + ed[3 * e + 2];
                 all_in = all_in && gmin > 1.0f;
                 any_out = any_out || gmax < -1.0f;
-                if (!(gmin > 1.0f)) { ++uncertain; which = e; }
+                if (!(gmin > 1.0f)) { ++uncertain; which2 = which; which = e; }
             }
             if (any_out) continue;
             if (cnt == 8) { overflow = true; break; }
-            codes[cnt] = (uint16_t)(MF_PLAN_CODES | (uncertain == 1 ? which : 4));
+            codes[cnt] = (uint16_t)(MF_PLAN_CODES | (uncertain == 1 ? which : uncertain == 2 ? (8 | which2 | (which << 4)) : 4));
             p.e[cnt++] = (uint16_t)(k | MF_PLAN_VALID | (all_in ? MF_PLAN_IN : 0u));
             if (all_in) closed = true;
             // source position of the four footprint corners under this cell's inverse homography (float32 is ample:

@@ -37,9 +37,9 @@ inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 // passes the cell's mask test).  Up to 8 entries in descending cell order; the list ends at the first IN
 // entry or the first invalid one.  Entry 7 == 0xFFFF: too many candidates -- entries 0-3 then hold the
 // cell range r_lo, r_hi, c_lo, c_hi and the warp kernel tests every cell of the range.
-// Lists of at most 4 entries carry an edge code per entry in e[4 + i] (bit 15 set, bit 14 clear): 0-3 = of the cell's
-// four mask-edge functions only this one can fail inside the footprint (the others are > +1 at all four corners),
-// 4 = test all four.
+// Lists of at most 4 entries carry an edge code per entry in e[4 + i] (bit 15 set, bit 14 clear), bits 0-5: 0-3 = of the
+// cell's four mask-edge functions only this one can fail inside the footprint (the others are > +1 at all four
+// corners); 4 = test all four; 8 | a | b << 4 = only edges a and b can fail (a < b).
 #define MF_PLAN_CODES 0x8000u
 #define MF_PLAN_VALID 0x4000u
 #define MF_PLAN_IN 0x8000u

@@ -345,9 +345,35 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
             const float yf = (float)y, xf0 = (float)x0;
             // The common shape -- exactly two cells, each with ONE mask edge crossing the footprint (a footprint on the
             // border between two cells): one fma per pixel and cell decides, straight-line.
-            const uint32_t cd0 = pv.z & 7u, cd1 = (pv.z >> 16) & 7u;
-            bool general = !(ne == 2 && !(pv.x & MF_PLAN_IN) && !((pv.x >> 16) & MF_PLAN_IN) && cd0 < 4u && cd1 < 4u);
-            if (!general) {
+            const uint32_t cd0 = pv.z & 0x3Fu, cd1 = (pv.z >> 16) & 0x3Fu, cd2 = pv.w & 0x3Fu, cd3 = (pv.w >> 16) & 0x3Fu;
+            const bool pair = ne == 2 && !(pv.x & MF_PLAN_IN) && !((pv.x >> 16) & MF_PLAN_IN) && cd0 < 4u && cd1 < 4u;
+            // four cells around a mesh vertex, each with the two edges that meet there uncertain
+            const bool quad = ne == 4 && !((pv.x | (pv.x >> 16) | pv.y | (pv.y >> 16)) & MF_PLAN_IN) &&
+                              (cd0 & cd1 & cd2 & cd3 & 8u) != 0;
+            bool general = !(pair || quad);
+            if (quad) {
+                float near = 1e30f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) own[j] = -1;
+#pragma unroll
+                for (int i = 3; i >= 0; --i) {                  // first entry last: it wins
+                    const uint32_t ent = (i < 2 ? pv.x : pv.y) >> (16 * (i & 1));
+                    const uint32_t cd = i == 0 ? cd0 : i == 1 ? cd1 : i == 2 ? cd2 : cd3;
+                    const float* __restrict__ ed = fedge + (ent & 0xFFFu) * MF_EDGE_FLOATS;
+                    const float* __restrict__ e1 = ed + 3u * (cd & 3u);
+                    const float* __restrict__ e2 = ed + 3u * ((cd >> 4) & 3u);
+                    const float r1 = __builtin_fmaf(e1[1], yf, e1[2]), r2 = __builtin_fmaf(e2[1], yf, e2[2]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xf = xf0 + (float)j;
+                        const float g = fminf(__builtin_fmaf(e1[0], xf, r1), __builtin_fmaf(e2[0], xf, r2));
+                        own[j] = g > edge_margin ? i : own[j];
+                        near = fminf(near, fabsf(g));
+                    }
+                }
+                general = __ballot(!(near > edge_margin) && y < H && x0 < W) != 0;
+            }
+            if (pair) {
                 const float* __restrict__ eb = fedge + (pv.x & 0xFFFu) * MF_EDGE_FLOATS + 3u * cd0;            // later cell: wins
                 const float* __restrict__ ea = fedge + ((pv.x >> 16) & 0xFFFu) * MF_EDGE_FLOATS + 3u * cd1;
                 const float rb = __builtin_fmaf(eb[1], yf, eb[2]), ra = __builtin_fmaf(ea[1], yf, ea[2]);
@@ -379,7 +405,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 if (!(e & MF_PLAN_IN)) {
                     const float* __restrict__ ed = fedge + k * MF_EDGE_FLOATS;
                     // short lists carry an edge code: only one of the four edge functions can fail in this footprint
-                    const uint32_t code = ne <= 4 ? (((i < 2 ? pv.z : pv.w) >> (16 * (i & 1))) & 7u) : 4u;
+                    const uint32_t code = ne <= 4 ? (((i < 2 ? pv.z : pv.w) >> (16 * (i & 1))) & 0x3Fu) : 4u;
                     uint32_t ok = 0, amb = 0;
                     if (code < 4u) {
                         const float* __restrict__ e1 = ed + 3u * code;
