@@ -143,3 +143,41 @@ def test_randomised_motion_campaign(dev):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     import fuzz_motion
     assert fuzz_motion.run(150, 7) == 0
+
+
+def test_raw_c_abi_as_in_integration_md(dev, golden_dir):
+    """The device-pointer ABI driven with nothing but ctypes (mf_malloc / mf_memcpy_* / mf_vertex_motion_f64), the way
+    INTEGRATION.md shows a maintainer of the reference would bind it."""
+    import ctypes
+    from meshflow_amd import _lib
+    lib = _lib.lib
+    g, feats = _load_case(golden_dir, 'motion_small')
+    early = np.ascontiguousarray(np.concatenate([e.reshape(-1, 2) for e, _ in feats]), np.float64)
+    late = np.ascontiguousarray(np.concatenate([l.reshape(-1, 2) for _, l in feats]), np.float64)
+    counts = [len(e) for e, _ in feats]
+    offsets = np.cumsum([0] + counts).astype(np.int32)
+    P, K, R, C = len(counts), len(early), int(g['R']), int(g['C'])
+    hom = np.ascontiguousarray(g['hom'][:P], np.float64)
+    vel = np.empty((P, R + 1, C + 1, 2), np.float32)
+    disp = np.empty((P + 1, R + 1, C + 1, 2), np.float64)
+    status = np.zeros(1, np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    arrays = dict(early=early, late=late, offsets=offsets, hom=hom, vel=vel, disp=disp, status=status)
+    d = {}
+    for name, arr in arrays.items():
+        d[name] = ctypes.c_void_p()
+        _lib.check(lib.mf_malloc(ctypes.byref(d[name]), arr.nbytes))
+    work = ctypes.c_void_p()
+    _lib.check(lib.mf_malloc(ctypes.byref(work), lib.mf_vertex_motion_workspace_bytes(K, max(counts), P, R, C)))
+    for name in ('early', 'late', 'offsets', 'hom', 'status'):
+        _lib.check(lib.mf_memcpy_h2d(d[name], p(arrays[name]), arrays[name].nbytes, None))
+    _lib.check(lib.mf_vertex_motion_f64(d['early'], d['late'], d['offsets'], d['hom'], P, K, max(counts), int(g['width']),
+                                        int(g['height']), R, C, int(g['ell_rows']), int(g['ell_cols']), d['vel'], d['disp'],
+                                        work, d['status'], None))
+    for name in ('vel', 'disp', 'status'):
+        _lib.check(lib.mf_memcpy_d2h(p(arrays[name]), d[name], arrays[name].nbytes, None))
+    _lib.check(lib.mf_stream_synchronize(None))
+    for ptr in list(d.values()) + [work]:
+        _lib.check(lib.mf_free(ptr))
+    assert status[0] == 0
+    assert np.array_equal(vel, g['velocities']) and np.array_equal(disp, g['displacements'])
