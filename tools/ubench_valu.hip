@@ -11,6 +11,8 @@ __global__ __launch_bounds__(64) void k(double* out, const double* in, long long
 {
     double a[8]; float fa[8]; uint32_t ia[8];
     for (int i = 0; i < 8; ++i) { a[i] = in[i + threadIdx.x % 3]; fa[i] = (float)a[i]; ia[i] = (uint32_t)(a[i] * 1000) + threadIdx.x; }
+    double b[8];
+    for (int i = 0; i < 8; ++i) b[i] = in[(i + threadIdx.x) % 7] * 1e-3;
     double c = in[9], d = in[10]; float fc = (float)c; uint32_t ic = (uint32_t)(c * 77), id = (uint32_t)(d * 55);
     long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
@@ -35,10 +37,12 @@ __global__ __launch_bounds__(64) void k(double* out, const double* in, long long
             if (OP == 15) ia[i] = (uint32_t)((int)rintf(fa[i])) + ia[i];         // rndne+cvt_i32_f32+add
             if (OP == 16) a[i] = (double)ia[i] + a[i];                          // cvt_f64_u32 + add_f64
             if (OP == 17) ia[i] = __builtin_amdgcn_perm(ia[i], ic, 0x02010007);
+            if (OP == 18) a[i] = __builtin_fma(c, b[i], a[i]);                  // v_fmac_f64 acc, sgpr, vgpr (the Jacobi inner op)
+            if (OP == 19) a[i] = __builtin_fma(b[(i + 1) & 7], b[i], a[i]);     // v_fmac_f64 acc, vgpr, vgpr
         }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
-    double s = 0; for (int i = 0; i < 8; ++i) s += a[i] + fa[i] + ia[i];
+    double s = 0; for (int i = 0; i < 8; ++i) s += a[i] + fa[i] + ia[i] + b[i];
     out[blockIdx.x * 64 + threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
@@ -71,6 +75,7 @@ int main()
         run<10>("v_mul_f32", 1, w); run<11>("rndne_f32+add_f32", 2, w); run<12>("v_alignbit", 1, w);
         run<13>("v_bfe_u32", 1, w); run<14>("v_min_f64", 1, w); run<15>("rndne+cvt_i32_f32+add", 3, w);
         run<16>("cvt_f64_u32+add_f64", 2, w); run<17>("v_perm_b32", 1, w);
+        run<18>("v_fmac_f64 acc,sgpr,vgpr", 1, w); run<19>("v_fmac_f64 acc,vgpr,vgpr", 1, w);
     }
     return 0;
 }
