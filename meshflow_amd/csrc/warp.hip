@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
     const uint32_t* __restrict__ fregion = regions + ((size_t)f * nfy * nfx + (tile_x * (TILE_W / FOOT_W) + wave));
 
     int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
+    bool scanned = false;                     // (wave-uniform) the crop-flag scan ran for some footprint of this wavefront
     const float fWm1 = (float)(W - 1), fHm1 = (float)(H - 1);
     const bool fast_store = (W & 3) == 0;
     const double xs0 = (double)x0;
@@ -570,6 +571,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
             d.z = __builtin_amdgcn_perm(__builtin_amdgcn_perm(oR[3], oG[3], pair), __builtin_amdgcn_perm(oB[3], oR[2], pair), join);
         } else {
             // generic path: frame borders, uncovered pixels, crop flags, out-of-range coordinates
+            scanned = true;
             if (!active) continue;
             uint32_t px[4];
 #pragma unroll 1
@@ -621,7 +623,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
         }
     }
 
-    // Crop bounds: wave reduction, then at most one atomic per bound per wave (most waves have none).
+    // Crop bounds: only the generic path can have set one.  Wave reduction, then at most one atomic per bound per wave.
+    if (!scanned) return;
     const bool any = c_left != 0 || c_top != 0 || c_right != W - 1 || c_bottom != H - 1;
     if (__ballot(any) != 0) {
 #pragma unroll
