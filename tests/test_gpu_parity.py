@@ -391,3 +391,38 @@ def test_randomised_parity_campaign(dev):
     spec.loader.exec_module(mod)
     bad, stats = mod.run(300, 1)
     assert bad == 0 and stats['warp'] > 100 and stats['jacobi'] > 30 and stats['resize'] > 30
+
+
+def test_methods_borrowed_by_a_foreign_class(dev):
+    """a class that only has the reference's attributes borrows the drop-in methods."""
+    from meshflow_amd import synthetic
+    import meshflow_amd as amd
+    from oracle import clib
+
+    class RefLike:                       # stands in for meshflowstabilizer.MeshFlowStabilizer (attributes of mfs.py:87-97)
+        def __init__(self):
+            self.mesh_row_count = self.mesh_col_count = 4
+            self.temporal_smoothing_radius, self.optimization_num_iterations = 3, 8
+            self.color_outside_image_area_bgr = (0, 0, 255)
+
+    class Stabilizer(RefLike):
+        _get_stabilized_vertex_displacements = amd.MeshFlowStabilizer._get_stabilized_vertex_displacements
+        _get_stabilized_frames_and_crop_boundaries = amd.MeshFlowStabilizer._get_stabilized_frames_and_crop_boundaries
+        _check_mesh_shape = amd.MeshFlowStabilizer._check_mesh_shape
+        _torch_device = amd.MeshFlowStabilizer._torch_device
+        _jacobi_coefficients_device = amd.MeshFlowStabilizer._jacobi_coefficients_device
+        _stabilized_vertex_displacements_device = amd.MeshFlowStabilizer._stabilized_vertex_displacements_device
+        _start_upload = amd.MeshFlowStabilizer._start_upload
+        _warp_staged = amd.MeshFlowStabilizer._warp_staged
+        _crop_frames = amd.MeshFlowStabilizer._crop_frames
+        device = None
+
+    F, H, W = 10, 64, 96
+    frames, disp, hom = synthetic.clip(F, H, W, 4, 4, seed=6)
+    s = Stabilizer()
+    stab = s._get_stabilized_vertex_displacements(F, list(frames), 0, disp, hom)
+    out, bounds = s._get_stabilized_frames_and_crop_boundaries(F, list(frames), disp, stab)
+    want, crop, _ = clib.warp_clip(frames, 4, 4, disp, stab)
+    np.testing.assert_array_equal(np.stack(out), want)
+    cropped = s._crop_frames(out, bounds)
+    assert len(cropped) == F and cropped[0].shape == (H, W, 3)
