@@ -193,9 +193,10 @@ def main():
     motion_row = None
     if rank == 0:
         from meshflow_amd import host as mfhost
-        feats = synthetic.features(F, H, W, hom, seed=seed, per_pair=(1500, 2500))
+        Fm = min(F, per_gpu)                          # one GPU's worth of frame pairs, whatever N is
+        feats = synthetic.features(Fm, H, W, hom[:Fm], seed=seed, per_pair=(1500, 2500))
         early, late, offsets, kmax = mfhost.pack_features(feats)
-        d_in = [torch.from_numpy(a).to(device) for a in (early, late, offsets, np.ascontiguousarray(hom[:-1]))]
+        d_in = [torch.from_numpy(a).to(device) for a in (early, late, offsets, np.ascontiguousarray(hom[:Fm - 1]))]
         ops.vertex_motion(*d_in, kmax, W, H, R, C, stab.feature_ellipse_row_count, stab.feature_ellipse_col_count)
         m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         m0.record()
@@ -207,16 +208,16 @@ def main():
         ops.vertex_motion_check(status)
         motion_ms = m0.elapsed_time(m1) / 3
         motion_row = {'kernels': 'feature_prep + bitonic sort + vertex_median + median_blur + accumulate',
-                      'avg_ms': motion_ms, 'frame_pairs': F - 1, 'features': int(early.shape[0]),
-                      'pairs_per_s': (F - 1) / (motion_ms * 1e-3),
+                      'avg_ms': motion_ms, 'frame_pairs': Fm - 1, 'features': int(early.shape[0]),
+                      'pairs_per_s': (Fm - 1) / (motion_ms * 1e-3),
                       'note': 'outside the timed region; latency/ALU bound (no meaningful HBM roofline: 14 MB of features)'}
         del d_in
         if world == 1 and args.cpu_frames > 0:
             from oracle import clib
             threads = clib.set_threads(min(usable_cpus(), 32))
             t1 = time.perf_counter()
-            clib.vertex_motion(W, H, R, C, stab.feature_ellipse_row_count, stab.feature_ellipse_col_count, feats, hom, openmp=True)
-            motion_row['cpu_port_pairs_per_s'] = (F - 1) / (time.perf_counter() - t1)
+            clib.vertex_motion(W, H, R, C, stab.feature_ellipse_row_count, stab.feature_ellipse_col_count, feats, hom[:Fm], openmp=True)
+            motion_row['cpu_port_pairs_per_s'] = (Fm - 1) / (time.perf_counter() - t1)
             motion_row['cpu_port_threads'] = threads
     # north_star's "single RCCL gather over xGMI at the end": timed once, after the timed region (it is 7 x 1.87 GB into
     # one GPU -- an order of magnitude above a step -- and a consumer in host memory is better served by every rank
