@@ -63,7 +63,7 @@ def cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, budget_frames):
     linearly to F frames).  The oracle is only the thing timed here, never part of the product path."""
     from meshflow_amd import synthetic
     from oracle import clib, meshflow_oracle as mo
-    # more than 32 threads did not help on the 256-thread hosts measured (tools/cpu_threads.py: 16 -> 60 frames/s,
+    # more than 32 threads did not help on the 256-thread hosts measured (tests/cpu_threads.py: 16 -> 60 frames/s,
     # 32 -> 61, 64 -> 53, 256 -> 35), so the baseline is capped there
     threads = min(usable_cpus(), 32, max(budget_frames, 1))
     threads = clib.set_threads(threads)      # the environment may pin OMP_NUM_THREADS (torchrun sets it to 1)

@@ -1,4 +1,6 @@
-import sys; sys.path.insert(0,'/root/repo')
+"""Edge-case geometries through the public API against the C oracle (run by hand on a GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from meshflow_amd import synthetic
 from meshflow_amd.stabilizer import MeshFlowStabilizer

@@ -1,5 +1,5 @@
 """Randomised parity campaign: HIP kernels vs the C oracle on random geometries (bit-exact or bust).
-Usage: python tools/fuzz_parity.py [cases] [seed]"""
+Usage: python tests/fuzz_parity.py [cases] [seed]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

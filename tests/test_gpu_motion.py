@@ -137,10 +137,10 @@ def test_features_to_stabilized_frames_end_to_end(dev):
 
 
 def test_randomised_motion_campaign(dev):
-    """tools/fuzz_motion.py: random frame sizes, meshes up to 39x39, ellipses up to 3x the mesh, 0-5000 features per
+    """tests/fuzz_motion.py: random frame sizes, meshes up to 39x39, ellipses up to 3x the mesh, 0-5000 features per
     pair incl. points outside the frame, points exactly on vertices / ellipse extremes, repeated residuals."""
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import fuzz_motion
     assert fuzz_motion.run(150, 7) == 0
 

@@ -386,7 +386,7 @@ def test_randomised_parity_campaign(dev):
     crop + resize) against the C / NumPy oracles, bit for bit.  Seed 1 contains the case that exposed the
     crop-flag bug for pixels beyond the right frame edge."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_parity.py'))
+    spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'fuzz_parity.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     bad, stats = mod.run(300, 1)
