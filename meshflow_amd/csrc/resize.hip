@@ -182,7 +182,10 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
                 const uint32_t vB = (mulhi_u24(b0s[q], tB0 & ~255u) + mulhi_u24(b1s[q], tB1 & ~255u) + 2u) >> 2;
                 const uint32_t vG = (mulhi_u24(b0s[q], tG0 & ~255u) + mulhi_u24(b1s[q], tG1 & ~255u) + 2u) >> 2;
                 const uint32_t vR = (mulhi_u24(b0s[q], tR0 & ~255u) + mulhi_u24(b1s[q], tR1 & ~255u) + 2u) >> 2;
-                px[j] = min(vB, 255u) | (min(vG, 255u) << 8) | (min(vR, 255u) << 16);
+                // no saturation needed: each weight pair sums to 2048 +- 1 (two cvRound of complementary fractions), so
+                // t <= 255 * 2049, t >> 4 <= 32655 and the two high halves sum to at most 2049 * 32655 / 65536 < 1021,
+                // i.e. (sum + 2) >> 2 <= 255 -- cv2's saturate_cast never triggers either
+                px[j] = vB | (vG << 8) | (vR << 16);
             }
         } else {
             const uint32_t b0 = b0s[q] >> 8, b1 = b1s[q] >> 8;
