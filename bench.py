@@ -173,6 +173,19 @@ def main():
 
     warp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     jac_ms = float(np.mean([a.elapsed_time(b) for a, b in jev]))
+    # Jacobi kernel alone (the per-step figure above includes the host-side coefficient set-up), outside the timed region
+    taps_d, lam_d, inv_on_d = stab._jacobi_coefficients_device(F, W, H, 0, hom, device)
+    b2d = d_disp.reshape(F, -1)
+    x2d = torch.empty_like(b2d)
+    ops.jacobi(b2d, taps_d, lam_d, inv_on_d, omega, iters, out=x2d)
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record()
+    for _ in range(5):
+        ops.jacobi(b2d, taps_d, lam_d, inv_on_d, omega, iters, out=x2d)
+    k1.record()
+    torch.cuda.synchronize()
+    jac_kernel_ms = k0.elapsed_time(k1) / 5
+    jac_flops = float(iters) * F * b2d.shape[1] * (2 * (2 * omega + 1) + 3)
     # Next row on the path, measured outside the timed region: crop to the clip-level bounds and
     # resize back, device-resident (mfs.py:1111-1157).
     resize_ms = None
@@ -260,7 +273,9 @@ def main():
                          if traffic else None,
                          'algorithmic_bytes_per_launch': algo_bytes, 'avg_launch_ms': warp_ms,
                          'note': 'VALU-issue bound (float64 coordinate arithmetic), not HBM bound: see DESIGN.md'},
-            'jacobi': {'avg_ms_incl_host_setup': jac_ms, 'series': int(d_disp[0].numel()), 'frames': F},
+            'jacobi': {'avg_ms_incl_host_setup': jac_ms, 'kernel_ms': jac_kernel_ms, 'series': int(d_disp[0].numel()), 'frames': F,
+                       'bound': 'fp64 vector ALU + LDS (the state never leaves the chip)', 'achieved': jac_flops / (jac_kernel_ms * 1e-3) / 1e12,
+                       'peak': 78.6, 'unit': 'TFLOP/s', 'frac': jac_flops / (jac_kernel_ms * 1e-3) / 78.6e12},
             'crop_bounds': [int(v) for v in bounds.tolist()],
         }
         if resize_ms is not None:
