@@ -85,6 +85,24 @@ def test_vs_c_oracle(dev, geometry):
     assert np.array_equal(got_d, want_d)
 
 
+def test_full_cfg2_sized_clip_vs_c_oracle(dev):
+    """299 frame pairs of a 1080p / 16x16 clip, 1500-2500 features each (590 k in all): bit-identical to the C oracle, and
+    the running sum is the sum (property: displacement[t] - displacement[t-1] == float64(velocity[t-1]) exactly)."""
+    from oracle import clib
+    from meshflow_amd import synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    W, H, R, C, F = 1920, 1080, 16, 16, 300
+    _, hom = synthetic.motion(F, R, C, seed=0)
+    hom[:-1, :2, :2] = np.identity(2) + 0.2 * (hom[:-1, :2, :2] - np.identity(2))
+    feats = synthetic.features(F, H, W, hom, seed=0, per_pair=(1500, 2500))
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C)
+    disp, vel = s._vertex_motion_from_features(F, W, H, feats, hom)
+    want_d, want_v = clib.vertex_motion(W, H, R, C, 10, 10, feats, hom, openmp=True)
+    assert np.array_equal(vel, want_v) and np.array_equal(disp, want_d)
+    assert np.array_equal(np.diff(disp, axis=0), vel.astype(np.float64)) or np.abs(np.diff(disp, axis=0) - vel).max() < 1e-9
+    assert not disp[0].any()
+
+
 def test_duplicate_values_and_even_counts(dev):
     """Ties: many features with identical residuals, even list lengths (mean of the two middle values)."""
     from oracle import clib

@@ -252,6 +252,60 @@ def test_warp_1080p_vs_c_oracle_and_identity(dev):
     np.testing.assert_array_equal(crop, [[0, 0, W - 1, H - 1]] * 2)
 
 
+def test_warp_full_cfg2_clip_properties(dev):
+    """BASELINE config 2 at full size (300 frames of 1920x1080, 16x16 mesh), device-resident, through properties that do
+    not need the oracle on all 300 frames: an integer global shift moves every interior pixel by exactly that shift and
+    paints the uncovered band in the border colour; the real smoothed motion is deterministic (two launches, same bytes)
+    and a sample of frames is bit-identical to the C oracle; the clip-level bounds follow mfs.py:1103-1106."""
+    from meshflow_amd import ops, synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    from oracle import clib
+    F, H, W, R, C = 300, 1080, 1920, 16, 16
+    d_frames = synthetic.frames_torch(F, H, W, dev, seed=0, kind='pattern')
+    disp, hom = synthetic.motion(F, R, C, seed=0)
+    d_disp = torch.from_numpy(disp).to(dev)
+    # (a) integer shift: stabilized = unstabilized + (dx, dy) on every vertex of every frame
+    dx, dy = 7, -5
+    d_shift = d_disp + torch.tensor([dx, dy], dtype=torch.float64, device=dev)
+    table = ops.cell_table(d_disp, d_shift, W, H, R, C)
+    out = ops.warp(d_frames, table, (9, 8, 7))
+    table.check()
+    assert torch.equal(out[:, :H + dy, dx:], d_frames[:, -dy:, :W - dx])          # content moved by (+7, -5)
+    border = torch.tensor([9, 8, 7], dtype=torch.uint8, device=dev)
+    assert bool((out[:, :, :dx - 1] == border).all()) and bool((out[:, H + dy + 1:] == border).all())
+    bounds = ops.crop_reduce(table.crop, W, H).tolist()
+    assert bounds == [dx, 0, W - 1, H - 1 + dy]
+    del out, table
+    # (b) the smoothed motion of the config
+    s = MeshFlowStabilizer(device=str(dev))
+    d_stab = s._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
+    out1, crop1 = s._stabilized_frames_device(d_frames, d_disp, d_stab)
+    out1, crop1 = out1.clone(), crop1.clone()
+    out2, crop2 = s._stabilized_frames_device(d_frames, d_disp, d_stab)
+    assert torch.equal(out1, out2) and torch.equal(crop1, crop2)
+    sel = [0, 149, 299]
+    stab = d_stab.cpu().numpy()
+    want, want_crop, bad = clib.warp_clip(d_frames[sel].cpu().numpy(), R, C, disp[sel], stab[sel], use_bbox=True, openmp=True)
+    assert bad == 0
+    assert np.array_equal(out1[sel].cpu().numpy(), want)
+    np.testing.assert_array_equal(crop1[sel].cpu().numpy(), want_crop)
+    crop_h = crop1.cpu().numpy()
+    assert ops.crop_reduce(crop1, W, H).tolist() == [crop_h[:, 0].max(), crop_h[:, 1].max(), crop_h[:, 2].min(), crop_h[:, 3].min()]
+
+
+def test_warp_4k_frames_vs_c_oracle(dev):
+    """BASELINE config 4 geometry (3840x2160, 16x16 mesh): two frames of a shard, bit-identical to the C oracle."""
+    from oracle import clib
+    H, W, R, C = 2160, 3840, 16, 16
+    frames, disp, stab = _clip(6, H, W, R, C, seed=4, kind='pattern', omega=10, iters=50)
+    sel = [2, 5]
+    out, crop, _ = _hip_warp(dev, frames[sel], R, C, disp[sel], stab[sel])
+    want, want_crop, bad = clib.warp_clip(frames[sel], R, C, disp[sel], stab[sel], use_bbox=True, openmp=True)
+    assert bad == 0
+    np.testing.assert_array_equal(crop, want_crop)
+    assert np.array_equal(out, want), f'{(out != want).sum()} bytes differ'
+
+
 def test_trimmed_reciprocal_matches_ieee_division(dev):
     from meshflow_amd import _lib
     bad = ctypes.c_uint64(123)
@@ -379,6 +433,22 @@ def test_crop_resize_1080p_and_errors(dev):
     np.testing.assert_array_equal(np.stack(got), np.stack(want))
     with pytest.raises(ValueError):
         ops.crop_resize(torch.from_numpy(frames[:1]).to(dev), (50, 10, 40, 100))       # right < left: empty crop
+
+
+def test_crop_resize_full_cfg2_clip_properties(dev):
+    """300 frames of 1920x1080 on the device: the full-frame rectangle is the identity (weights (2048, 0) both ways), a
+    real crop is deterministic and a sample of frames matches the oracle."""
+    from meshflow_amd import ops, synthetic
+    from oracle import meshflow_oracle as mo
+    F, H, W = 300, 1080, 1920
+    d_frames = synthetic.frames_torch(F, H, W, dev, seed=3, kind='noise')
+    assert torch.equal(ops.crop_resize(d_frames, (0, 0, W - 1, H - 1)), d_frames)
+    rect = (13, 11, 1909, 1068)
+    out = ops.crop_resize(d_frames, rect)
+    assert torch.equal(out, ops.crop_resize(d_frames, rect))
+    sel = [0, 150, 299]
+    want = np.stack(mo.crop_frames(list(d_frames[sel].cpu().numpy()), rect))
+    assert np.array_equal(out[sel].cpu().numpy(), want)
 
 
 def test_randomised_parity_campaign(dev):
