@@ -1,8 +1,12 @@
 """Optional cross-check of the oracle's OpenCV restatements against a real OpenCV.
 
 OpenCV is not installed in the build image nor on the GPU box, so these tests normally SKIP; wherever `cv2`
-is importable they pin the four restated calls of the warp path (and cv2.resize) against the real thing.
+is importable they pin the restated calls of the warp path, cv2.resize and the two calls of the vertex-motion row
+(perspectiveTransform on float64 points, medianBlur) against the real thing.
 Ties (a coordinate within ~1e-9 of a 1/32-pixel rounding boundary) may differ, hence the small allowances."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -81,3 +85,43 @@ def test_whole_warp_against_reference_loop():
                     cv2.INTER_LINEAR, borderValue=(0, 0, 255))
     diff = np.abs(got.astype(int) - ref.astype(int))
     assert (diff > 0).mean() < 1e-3           # only rounding ties of the two homography solvers may differ
+
+
+def test_perspective_transform_float64_points():
+    """The CV_64F flavour the reference's feature arrays take (mfs.py:420, promoted at mfs.py:578)."""
+    from oracle import motion_oracle as mt
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(0, 1900, (500, 1, 2))
+    H = np.identity(3) + rng.normal(0, 0.01, (3, 3))
+    H[2, :2] = rng.normal(0, 1e-6, 2)
+    H[2, 2] = 1.0
+    assert np.array_equal(cv2.perspectiveTransform(pts, H), mt.perspective_transform_f64(pts, H))
+
+
+def test_median_blur_3x3_float32():
+    """cv2.medianBlur on the (R+1) x (C+1) float32 velocity planes (mfs.py:359-360): replicated borders."""
+    from oracle import motion_oracle as mt
+    rng = np.random.default_rng(6)
+    for shape in ((17, 17), (33, 33), (4, 6), (2, 2)):
+        img = rng.normal(0, 3, shape).astype(np.float32)
+        assert np.array_equal(cv2.medianBlur(img, 3), mt.median_blur3_f32(img))
+
+
+def test_vertex_velocities_against_reference_code_with_real_cv2():
+    """The reference's own _get_unstabilized_vertex_velocities with the real cv2 (needs /root/reference importable)."""
+    ref_dir = os.environ.get('MESHFLOW_REFERENCE_DIR', '/root/reference')
+    if not os.path.exists(os.path.join(ref_dir, 'meshflowstabilizer.py')):
+        pytest.skip('reference not present')
+    sys.path.insert(0, ref_dir)
+    import meshflowstabilizer as mfs
+    from oracle import gen_golden, motion_oracle as mt
+    W, H, R, C, er, ec = 640, 360, 8, 8, 5, 5
+    feats, hom = gen_golden.motion_inputs(W, H, R, C, 4, (120, 180), 3)
+    s = mfs.MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, feature_ellipse_row_count=er, feature_ellipse_col_count=ec)
+    frames = [np.zeros((H, W, 3), np.uint8) for _ in range(4)]
+    index = {id(f): i for i, f in enumerate(frames)}
+    s._get_matched_features_and_homography = lambda a, b: (*feats[index[id(a)]], hom[index[id(a)]])
+    for t in range(3):
+        want = s._get_unstabilized_vertex_velocities(frames[t], frames[t + 1])[0]
+        got = mt.unstabilized_vertex_velocities(W, H, R, C, er, ec, feats[t][0], feats[t][1], hom[t])
+        assert np.array_equal(want, got)
