@@ -126,6 +126,13 @@ int mf_vertex_motion_f64(const double* d_early, const double* d_late, const int3
                          int ellipse_rows, int ellipse_cols, float* d_velocities, double* d_displacements,
                          void* d_work, int32_t* d_status, void* stream);
 
+/* ---- stability score (mfs.py:1216-1259) of device-resident vertex paths ----
+ * d_stab: [F][S] float64 as for mf_jacobi_f64 (S = V*2: x and y of every vertex interleaved).  Per series the fraction of
+ * the velocity profile's spectral energy that sits in DFT bins 1..5 (five direct sums + Parseval for the total);
+ * d_series: [S] float64 receives those fractions, d_score: [1] float64 the clip-level score
+ * (mean over x series + mean over y series) / 2.  Needs F >= 7.  Agrees with np.fft to float64 rounding. */
+int mf_stability_score_f64(const double* d_stab, int F, int S, double* d_series, double* d_score, void* stream);
+
 /* Device self-test: sqrt() on (0, 0.25] (the ellipse half-width, mfs.py:444) must be correctly rounded; *mismatches
  * receives the number of inputs where it is not (must be 0).  Synchronous. */
 int mf_selftest_sqrt(uint64_t n, uint64_t seed, uint64_t* mismatches);

@@ -41,6 +41,7 @@ SIGNATURES = {
     'mf_crop_resize_u8c3': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'mf_vertex_motion_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'mf_vertex_motion_f64': (_i, [_vp, _vp, _vp, _vp] + [_i] * 9 + [_vp, _vp, _vp, _vp, _vp]),
+    'mf_stability_score_f64': (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     'mf_selftest_sqrt': (_i, [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     'mf_selftest_recip': (_i, [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     'mf_jacobi_f64_host': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_float)]),

@@ -143,6 +143,12 @@ int mf_vertex_motion_f64(const double* d_early, const double* d_late, const int3
                                 ellipse_rows, ellipse_cols, d_velocities, d_displacements, d_work, d_status, (hipStream_t)stream);
 }
 
+int mf_stability_score_f64(const double* d_stab, int F, int S, double* d_series, double* d_score, void* stream)
+{
+    if (!d_stab || !d_series || !d_score) { set_error("mf_stability_score_f64: null pointer"); return MF_ERR_INVALID_ARG; }
+    return launch_stability_score(d_stab, F, S, d_series, d_score, (hipStream_t)stream);
+}
+
 static int run_selftest(int (*launch)(unsigned long long, unsigned long long, unsigned long long*, hipStream_t),
                         uint64_t n, uint64_t seed, uint64_t* mismatches)
 {

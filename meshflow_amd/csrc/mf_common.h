@@ -154,6 +154,7 @@ int launch_vertex_motion(const double* early, const double* late, const int32_t*
                          int total_features, int max_per_pair, int W, int H, int R, int C, int ell_rows, int ell_cols,
                          float* vel, double* disp, void* work, int32_t* status, hipStream_t st);
 int launch_selftest_sqrt(unsigned long long n, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t st);
+int launch_stability_score(const double* stab, int F, int S, double* ratio, double* score, hipStream_t st);
 int launch_crop_reduce(const int32_t* crop, int n, int W, int H, int32_t* bounds, hipStream_t st);
 
 }  // namespace mf

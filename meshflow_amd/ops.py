@@ -153,3 +153,15 @@ def vertex_motion(early, late, offsets, homographies, max_per_pair, W, H, R, C, 
 def vertex_motion_check(status):
     if int(status.item()):
         raise ValueError('math domain error')          # what math.sqrt raises at mfs.py:444
+
+
+def stability_score(stab):
+    """Stability score (mfs.py:1216-1259) of device-resident paths: (F, R+1, C+1, 2) or (F, S) float64 tensor ->
+    (score (1,) float64 tensor, per-series fractions (S,))."""
+    _need(stab, torch.float64, 'stab')
+    F = stab.shape[0]
+    S = stab.numel() // F
+    series = torch.empty(S, dtype=torch.float64, device=stab.device)
+    score = torch.empty(1, dtype=torch.float64, device=stab.device)
+    _lib.check(_lib_.mf_stability_score_f64(_ptr(stab), F, S, _ptr(series), _ptr(score), _stream()))
+    return score, series

@@ -336,6 +336,13 @@ class MeshFlowStabilizer:
         """mfs.py:1216-1259."""
         return host.stability_score(np.asarray(vertex_stabilized_displacements_by_frame_index))
 
+    def _compute_stability_score_device(self, d_stab):
+        """mfs.py:1216-1259 on device-resident paths (five direct DFT bins + Parseval; float64 rounding apart from
+        `_compute_stability_score`, which stays the bit-for-bit restatement of the reference's np.fft formulation)."""
+        from . import ops
+        score, _ = ops.stability_score(d_stab)
+        return float(score.item())
+
     def _get_vertex_x_y(self, frame_width, frame_height):
         """mfs.py:881-906."""
         return host.vertex_x_y(frame_width, frame_height, self.mesh_row_count, self.mesh_col_count)
