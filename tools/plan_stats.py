@@ -35,4 +35,14 @@ for i in range(4):
     m = short & (i < ne) & ((plan[:, i] & 0x8000) == 0)
     mixed_entries += m.sum(); single_edge += (m & ((codes[:, i] & 7) < 4)).sum()
 print(f'MIXED entries in short lists: {mixed_entries}, of which single-edge: {single_edge} ({single_edge / max(mixed_entries, 1):.3f})')
+inn = (plan & 0x8000) != 0
+cd = codes & 0x3F
+pair = (ne == 2) & ~inn[:, 0] & ~inn[:, 1] & (cd[:, 0] < 4) & (cd[:, 1] < 4)
+quad = (ne == 4) & ~inn[:, :4].any(1) & ((cd[:, 0] & cd[:, 1] & cd[:, 2] & cd[:, 3] & 8) != 0)
+general = ~single & ~pair & ~quad
+print(f'paths: single IN {single.mean():.4f}  pair {pair.mean():.4f}  quad {quad.mean():.4f}  general {general.mean():.4f}')
+g2 = general & (ne == 2)
+print(f'general by shape: ne=1 {(general & (ne == 1)).mean():.4f}  ne=2 {g2.mean():.4f} (of which closed by an IN cell {(g2 & inn[:, 1]).mean():.4f}, '
+      f'two-edge codes {(g2 & ~inn[:, 1] & (((cd[:, 0] | cd[:, 1]) & 8) != 0)).mean():.4f})  ne=3 {(general & (ne == 3)).mean():.4f}  '
+      f'ne=4 {(general & (ne == 4)).mean():.4f}  ne>4 {(general & (ne > 4)).mean():.4f}')
 print(f'staged {((regions >> 31) & 1).mean():.4f}  certified interior {((regions >> 30) & 1).mean():.4f}')
