@@ -6,9 +6,11 @@
  *   _get_stabilized_vertex_displacements        mfs.py:632-710   -> mf_jacobi_f64
  *   _get_stabilized_frames_and_crop_boundaries  mfs.py:909-1108  -> mf_cell_table_f64 + mf_warp_u8c3
  *
- * and the step that follows them:
+ * and the steps either side of them:
  *
  *   _crop_frames                                mfs.py:1111-1157 -> mf_crop_resize_u8c3
+ *   vertex-motion accumulation after the tracker  mfs.py:268-282, 316-362, 365-452 -> mf_vertex_motion_f64
+ *   _compute_stability_score                    mfs.py:1216-1259 -> mf_stability_score_f64
  *
  * Every entry point takes plain pointers and sizes.  Pointers named d_* are DEVICE pointers
  * (hipMalloc / torch tensors' data_ptr()); `stream` is a hipStream_t passed as void* (NULL = the
@@ -46,7 +48,8 @@ extern "C" {
  *   [26]     status: 0 ok, 1 degenerate
  *   [27..31] reserved
  * The table blob of n frames (mf_cell_table_bytes) holds n*R*C records followed by private acceleration
- * data of the warp kernel (compact boxes, edge functions, per-footprint candidate plan, per-frame reach, vertex grid). */
+ * data of the warp kernel (compact boxes, edge functions, per-footprint candidate plan and source region, per-frame
+ * reach, vertex grid). */
 #define MF_CELL_DOUBLES 32
 #define MF_CELL_OFF_M 0
 #define MF_CELL_OFF_HI 9
