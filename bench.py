@@ -90,8 +90,8 @@ def cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, budget_frames):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
     ap.add_argument('--frames-kind', default='pattern', choices=['pattern', 'noise'])
     ap.add_argument('--cpu-frames', type=int, default=300, help='frames warped by the CPU baseline (0 = skip)')
