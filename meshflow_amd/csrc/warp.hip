@@ -440,8 +440,9 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 done = __ballot(unowned != 0) == 0;
             }
             }
-            // (c) coordinates, once per pixel, owner's matrix from LDS (same wavefront wrote it: in order)
-            double w4[4], nx[4], ny[4];
+            // (c) coordinates, once per pixel, owner's matrix from LDS (same wavefront wrote it: in order).  Optimistic: the
+            // trimmed reciprocal is applied straight away (keeps one pixel's intermediates live instead of four) and the
+            // rare footprint with a denominator outside [0.5, 2) is redone with the generic division.
             uint32_t eor = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -450,30 +451,33 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 const double2 h45 = *reinterpret_cast<const double2*>(hp + 4), h67 = *reinterpret_cast<const double2*>(hp + 6);
                 const double h8 = hp[8];
                 const double xs = xs0 + (double)j;
-                w4[j] = (xs * h67.x + yy * h67.y) + h8;
-                nx[j] = (xs * h01.x + yy * h01.y) + h23.x;
-                ny[j] = (xs * h23.y + yy * h45.x) + h45.y;
-                eor |= own[j] < 0 ? 0u : (uint32_t)__builtin_amdgcn_frexp_exp(w4[j]);
+                const double w = (xs * h67.x + yy * h67.y) + h8;
+                const double nx = (xs * h01.x + yy * h01.y) + h23.x;
+                const double ny = (xs * h23.y + yy * h45.x) + h45.y;
+                eor |= own[j] < 0 ? 0u : (uint32_t)__builtin_amdgcn_frexp_exp(w);
+                const double iw = recip_unit_range(w);
+                const float un = (float)(nx * iw), vn = (float)(ny * iw);
+                u[j] = own[j] < 0 ? (float)(W + 1) : un;
+                v[j] = own[j] < 0 ? (float)(H + 1) : vn;
             }
-            if (__ballot(eor > 1u) == 0) {
-#pragma unroll
+            if (__ballot(eor > 1u) != 0) {                             // far-from-affine cell: generic division
+#pragma unroll 1
                 for (int j = 0; j < 4; ++j) {
-                    const double iw = recip_unit_range(w4[j]);
-                    const float un = (float)(nx[j] * iw), vn = (float)(ny[j] * iw);
-                    u[j] = own[j] < 0 ? (float)(W + 1) : un;
-                    v[j] = own[j] < 0 ? (float)(H + 1) : vn;
-                }
-            } else {                                                   // far-from-affine cell: generic division
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                    const int oj = j == 0 ? own[0] : j == 1 ? own[1] : j == 2 ? own[2] : own[3];
+                    const double* hp = &s_hi[wave][oj < 0 ? 0 : oj][0];
+                    const double xs = xs0 + (double)j;
+                    const double w = (xs * hp[6] + yy * hp[7]) + hp[8];
                     float un = 0.0f, vn = 0.0f;
-                    if (fabs(w4[j]) > 1.1920928955078125e-07) {
-                        const double iw = 1.0 / w4[j];
-                        un = (float)(nx[j] * iw);
-                        vn = (float)(ny[j] * iw);
+                    if (fabs(w) > 1.1920928955078125e-07) {
+                        const double iw = 1.0 / w;
+                        un = (float)(((xs * hp[0] + yy * hp[1]) + hp[2]) * iw);
+                        vn = (float)(((xs * hp[3] + yy * hp[4]) + hp[5]) * iw);
                     }
-                    u[j] = own[j] < 0 ? (float)(W + 1) : un;
-                    v[j] = own[j] < 0 ? (float)(H + 1) : vn;
+                    if (oj < 0) { un = (float)(W + 1); vn = (float)(H + 1); }
+                    if (j == 0) { u[0] = un; v[0] = vn; }
+                    else if (j == 1) { u[1] = un; v[1] = vn; }
+                    else if (j == 2) { u[2] = un; v[2] = vn; }
+                    else { u[3] = un; v[3] = vn; }
                 }
             }
         }
