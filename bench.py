@@ -15,6 +15,7 @@ bounds (weak scaling); the RCCL gather of all frames to rank 0 is timed once aft
 
 Rank 0 prints ONE JSON line (fields: see the task's bench contract) including
   roofline:     warp kernel, algorithmic bytes 2*H*W*3 per frame over its HIP-event time, vs 8 TB/s HBM
+  end_to_end:   stabilize_clip() from host frames to host frames (PCIe both ways), N = 1 only; never `value`
   cpu_baseline: the C oracle (oracle/warp_oracle.c, OpenMP) timed on this box's host cores on a bounded
                 sample of the same workload (N = 1 only).
 """
@@ -87,6 +88,22 @@ def cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, budget_frames):
     }
 
 
+def end_to_end(stab, d_frames, disp, hom, F):
+    """BASELINE.json's other figure: frames/s of stabilize_clip() from a Python list of NumPy frames in host memory to a list
+    of stabilized frames + crop bounds + paths + stability score back in host memory (PCIe both ways, pageable buffers, as
+    the reference passes them).  Never `value`.  Best of three."""
+    frames = [f.copy() for f in d_frames.cpu().numpy()]           # separate allocations, like a decoder's output
+    best = float('inf')
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = stab.stabilize_clip(frames, disp, hom)
+        best = min(best, time.perf_counter() - t0)
+        del out
+    return {'value': F / best, 'unit': 'frames/s', 'ms_per_clip': best * 1e3,
+            'what': 'stabilize_clip(list of F host frames) -> list of F host frames + crop bounds + paths + score; '
+                    'chunked, overlapped PCIe staging (meshflow_amd/pipeline.py); best of 3'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -101,6 +118,7 @@ def main():
     ap.add_argument('--mode', default='shard', choices=['shard', 'clips'],
                     help='N > 1: "shard" = ONE clip of N x frames sharded by frame range (Jacobi replicated, 16-byte crop '
                          'all-reduce); "clips" = N independent clips, one per GPU, no collective (BASELINE config 5)')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the host-buffers-in / host-buffers-out measurement (N = 1 only)')
     ap.add_argument('--as-rank-of', type=int, default=0, metavar='N',
                     help='single process only: do the work rank 0 of an N-GPU "shard" run does (clip of N x frames, own '
                          'frame range, replicated Jacobi) without the collective -- predicts weak scaling on one GPU')
@@ -294,6 +312,8 @@ def main():
             result['gather_note'] = 'one RCCL gather of every rank\'s stabilized frames to rank 0, after the timed region'
         if gather_error is not None:
             result['gather_error'] = gather_error
+        if world == 1 and not args.no_e2e and args.as_rank_of <= 1:
+            result['end_to_end'] = end_to_end(stab, d_frames, disp, hom, F)
         if world == 1 and args.cpu_frames > 0:
             result['cpu_baseline'] = cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, args.cpu_frames)
         else:
