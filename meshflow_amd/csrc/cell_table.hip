@@ -285,25 +285,13 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
 // maps the footprint rectangle onto a convex quadrilateral (w > 0 at the four corners), so the bounding box of the
 // mapped corners, widened by the bilinear footprint and a pixel of slack, holds every tap of every pixel whichever
 // listed cell owns it.  If that box fits the staging window and the frame, the warp kernel fetches it once.
-__global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __restrict__ edges,
-                                                             const double* __restrict__ records,
-                                                             const int32_t* __restrict__ reach,
-                                                             const int32_t* __restrict__ grid, int n, int W, int H, int R,
-                                                             int C, FootPlan* __restrict__ plan, uint32_t* __restrict__ regions)
+// Classification + source region of ONE footprint.  `edge_of(k)` yields the 12 float32 edge coefficients of cell k of this
+// frame, `hi_of(k, out9)` its inverse homography as float32: from LDS when the workgroup staged its cell rows, else global.
+template <typename EdgeOf, typename HiOf>
+__device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, const int* s_gx, const int* s_gy, int xa, int xb,
+                                                   int ya, int yb, int rxlo, int rylo, int rxhi, int ryhi, int W, int H, int R,
+                                                   int C, FootPlan& p, uint32_t& region)
 {
-    __shared__ int s_gx[66], s_gy[66];
-    if ((int)threadIdx.x <= C) s_gx[threadIdx.x] = grid[threadIdx.x];
-    if ((int)threadIdx.x <= R) s_gy[threadIdx.x] = grid[C + 1 + threadIdx.x];
-    __syncthreads();
-    const int nfx = (W + MF_FOOT_W - 1) / MF_FOOT_W, nfy = (H + MF_FOOT_H - 1) / MF_FOOT_H;
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)n * nfy * nfx) return;
-    const int f = (int)(gid / (nfy * nfx));
-    const int rem = (int)(gid % (nfy * nfx));
-    const int fy = rem / nfx, fx = rem % nfx;
-    const int xa = fx * MF_FOOT_W, xb = min(xa + MF_FOOT_W - 1, W - 1);
-    const int ya = fy * MF_FOOT_H, yb = min(ya + MF_FOOT_H - 1, H - 1);
-    const int rxlo = reach[4 * f + 0], rylo = reach[4 * f + 1], rxhi = reach[4 * f + 2], ryhi = reach[4 * f + 3];
     // cells whose grid rect, widened by the frame's reach, meets the footprint (contiguous index ranges)
     // (start from the uniform-grid estimate, then walk the exact vertex coordinates: a step or two)
     const float cs = (float)C / (float)(W - 1), rs = (float)R / (float)(H - 1);
@@ -317,20 +305,17 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     while (c_hi > 0 && s_gx[c_hi] > xb + rxlo) --c_hi;
     while (r_lo < R - 1 && s_gy[r_lo + 1] < ya - ryhi) ++r_lo;
     while (r_hi > 0 && s_gy[r_hi] > yb + rylo) --r_hi;
-    FootPlan p;
     uint16_t codes[8];
     for (int i = 0; i < 8; ++i) { p.e[i] = 0; codes[i] = 0; }
     int cnt = 0;
     bool overflow = false, closed = false;
     const float cxs[2] = { (float)xa, (float)xb }, cys[2] = { (float)ya, (float)yb };
-    const float* __restrict__ fedge = edges + (size_t)f * R * C * MF_EDGE_FLOATS;
-    const double* __restrict__ frec = records + (size_t)f * R * C * MF_CELL_DOUBLES;
     float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
     bool sane = true;
     for (int r = r_hi; r >= r_lo && !closed && !overflow; --r)
         for (int c = c_hi; c >= c_lo && !closed && !overflow; --c) {
             const int k = r * C + c;
-            const float* __restrict__ ed = fedge + (size_t)k * MF_EDGE_FLOATS;
+            const float* ed = edge_of(k);
             bool all_in = true, any_out = false;
             int uncertain = 0, which = 0, which2 = 0;
             for (int e = 0; e < 4; ++e) {
@@ -351,15 +336,14 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
             if (all_in) closed = true;
             // source position of the four footprint corners under this cell's inverse homography (float32 is ample:
             // the window keeps a pixel of slack, the float32 error at coordinates below 32768 is below 0.01)
-            const double* __restrict__ hi = frec + (size_t)k * MF_CELL_DOUBLES + MF_CELL_OFF_HI;
-            const float h0 = (float)hi[0], h1 = (float)hi[1], h2 = (float)hi[2], h3 = (float)hi[3], h4 = (float)hi[4];
-            const float h5 = (float)hi[5], h6 = (float)hi[6], h7 = (float)hi[7], h8 = (float)hi[8];
+            float h[9];
+            hi_of(k, h);
             for (int q = 0; q < 4; ++q) {
                 const float cx = cxs[q & 1], cy = cys[q >> 1];
-                const float w = h6 * cx + h7 * cy + h8;
+                const float w = h[6] * cx + h[7] * cy + h[8];
                 sane = sane && w > 0.25f && w < 4.0f;                     // (NaN fails)
                 const float iw = 1.0f / w;
-                const float u = (h0 * cx + h1 * cy + h2) * iw, v = (h3 * cx + h4 * cy + h5) * iw;
+                const float u = (h[0] * cx + h[1] * cy + h[2]) * iw, v = (h[3] * cx + h[4] * cy + h[5]) * iw;
                 umin = fminf(umin, u); umax = fmaxf(umax, u);
                 vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
             }
@@ -371,8 +355,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
         p.e[0] = (uint16_t)r_lo; p.e[1] = (uint16_t)r_hi; p.e[2] = (uint16_t)c_lo; p.e[3] = (uint16_t)c_hi;
         p.e[4] = p.e[5] = p.e[6] = 0; p.e[7] = (uint16_t)MF_PLAN_OVERFLOW;
     }
-    plan[gid] = p;
-    uint32_t region = 0;
+    region = 0;
     if (sane && cnt > 0 && !overflow && (W & 3) == 0 && 3 * W >= MF_STAGE_PITCH && H > MF_STAGE_ROWS &&
         umin > -4.0f && vmin > -4.0f && umax < 40000.0f && vmax < 40000.0f) {
         // taps of a pixel at (u, v): columns floor(u) .. floor(u)+1 up to 1/64 px of rounding -> one pixel of slack
@@ -383,6 +366,71 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
             region = MF_REGION_STAGED | ((uint32_t)sy0 << 15) | (uint32_t)sx0 |
                      (closed && ix_lo >= 2 && ix_hi <= W - 3 && iy_lo >= 2 && iy_hi <= H - 3 ? MF_REGION_DEEP : 0u);
     }
+}
+
+constexpr int kPlanStageCells = 256;          // cells (whole mesh rows) a workgroup keeps in LDS: 21 KB
+
+// grid = n * ceil(footprints per frame / 256): a workgroup handles 256 consecutive footprints of ONE frame -- a few rows of
+// footprints, which only meet a few mesh rows.  Those rows' edge functions and inverse homographies are staged in LDS once
+// (the per-footprint loops then run on LDS latency instead of dependent L2 round trips); when they do not fit, from global.
+__global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __restrict__ edges,
+                                                             const double* __restrict__ records,
+                                                             const int32_t* __restrict__ reach,
+                                                             const int32_t* __restrict__ grid, int n, int W, int H, int R,
+                                                             int C, FootPlan* __restrict__ plan, uint32_t* __restrict__ regions)
+{
+    __shared__ int s_gx[66], s_gy[66];
+    __shared__ float s_edge[kPlanStageCells * MF_EDGE_FLOATS];
+    __shared__ float s_hi[kPlanStageCells * 9];
+    if ((int)threadIdx.x <= C) s_gx[threadIdx.x] = grid[threadIdx.x];
+    if ((int)threadIdx.x <= R) s_gy[threadIdx.x] = grid[C + 1 + threadIdx.x];
+    __syncthreads();
+    const int nfx = (W + MF_FOOT_W - 1) / MF_FOOT_W, nfy = (H + MF_FOOT_H - 1) / MF_FOOT_H, per_frame = nfx * nfy;
+    const int blocks_per_frame = (per_frame + 255) / 256;
+    const int f = (int)(blockIdx.x / (unsigned)blocks_per_frame);
+    if (f >= n) return;
+    const int rem0 = ((int)blockIdx.x - f * blocks_per_frame) * 256, rem = rem0 + (int)threadIdx.x;
+    const int rxlo = reach[4 * f + 0], rylo = reach[4 * f + 1], rxhi = reach[4 * f + 2], ryhi = reach[4 * f + 3];
+    const float* __restrict__ fedge = edges + (size_t)f * R * C * MF_EDGE_FLOATS;
+    const double* __restrict__ frec = records + (size_t)f * R * C * MF_CELL_DOUBLES;
+
+    // mesh rows the workgroup's footprints can meet (same widening by the frame's reach as per footprint)
+    const int ya0 = (rem0 / nfx) * MF_FOOT_H, yb1 = min((min(rem0 + 255, per_frame - 1) / nfx) * MF_FOOT_H + MF_FOOT_H - 1, H - 1);
+    int rb_lo = 0, rb_hi = R - 1;
+    while (rb_lo < R - 1 && s_gy[rb_lo + 1] < ya0 - ryhi) ++rb_lo;
+    while (rb_hi > 0 && s_gy[rb_hi] > yb1 + rylo) --rb_hi;
+    const int staged_cells = (rb_hi - rb_lo + 1) * C;
+    const bool staged = rb_hi >= rb_lo && staged_cells <= kPlanStageCells;          // (workgroup-uniform)
+    if (staged) {
+        const int k0 = rb_lo * C;
+        for (int i = threadIdx.x; i < staged_cells * MF_EDGE_FLOATS; i += 256) s_edge[i] = fedge[(size_t)k0 * MF_EDGE_FLOATS + i];
+        for (int i = threadIdx.x; i < staged_cells * 9; i += 256) {
+            const int cell = i / 9, j = i - 9 * cell;
+            s_hi[i] = (float)frec[(size_t)(k0 + cell) * MF_CELL_DOUBLES + MF_CELL_OFF_HI + j];
+        }
+    }
+    __syncthreads();
+    if (rem >= per_frame) return;
+    const int fy = rem / nfx, fx = rem - fy * nfx;
+    const int xa = fx * MF_FOOT_W, xb = min(xa + MF_FOOT_W - 1, W - 1);
+    const int ya = fy * MF_FOOT_H, yb = min(ya + MF_FOOT_H - 1, H - 1);
+    FootPlan p;
+    uint32_t region;
+    if (staged) {
+        const int k0 = rb_lo * C;
+        plan_one_footprint([&](int k) { return (const float*)&s_edge[(k - k0) * MF_EDGE_FLOATS]; },
+                           [&](int k, float (&h)[9]) { for (int j = 0; j < 9; ++j) h[j] = s_hi[(k - k0) * 9 + j]; },
+                           s_gx, s_gy, xa, xb, ya, yb, rxlo, rylo, rxhi, ryhi, W, H, R, C, p, region);
+    } else {
+        plan_one_footprint([&](int k) { return fedge + (size_t)k * MF_EDGE_FLOATS; },
+                           [&](int k, float (&h)[9]) {
+                               const double* __restrict__ hi = frec + (size_t)k * MF_CELL_DOUBLES + MF_CELL_OFF_HI;
+                               for (int j = 0; j < 9; ++j) h[j] = (float)hi[j];
+                           },
+                           s_gx, s_gy, xa, xb, ya, yb, rxlo, rylo, rxhi, ryhi, W, H, R, C, p, region);
+    }
+    const size_t gid = (size_t)f * per_frame + rem;
+    plan[gid] = p;
     regions[gid] = region;
 }
 
@@ -403,8 +451,8 @@ int launch_cell_table(const double* unstab, const double* stab, int n, int W, in
                        tv.edges, tv.reach, tv.grid, crop, status);
     int rc = hip_fail(hipGetLastError(), "cell_table_kernel launch");
     if (rc != MF_OK) return rc;
-    const size_t nplan = plan_count(n, W, H);
-    hipLaunchKernelGGL(footprint_plan_kernel, dim3((unsigned)((nplan + 255) / 256)), dim3(256), 0, st, tv.edges, tv.records,
+    const size_t per_frame = plan_count(1, W, H);
+    hipLaunchKernelGGL(footprint_plan_kernel, dim3((unsigned)(((per_frame + 255) / 256) * (size_t)n)), dim3(256), 0, st, tv.edges, tv.records,
                        tv.reach, tv.grid, n, W, H, R, C, tv.plan, tv.regions);
     return hip_fail(hipGetLastError(), "footprint_plan_kernel launch");
 }
