@@ -204,6 +204,19 @@ def test_warp_stress_geometries_bit_exact(dev, H, W, R, C, sigma, seed):
     np.testing.assert_array_equal(crop, want_crop)
 
 
+@pytest.mark.parametrize('H,W,R,C', [(24, 32764, 1, 64), (40, 16384, 2, 64), (16388, 32, 64, 1), (20, 8196, 1, 3)])
+def test_warp_extreme_aspect_ratios_bit_exact(dev, H, W, R, C):
+    """Frames at the size limits (coordinates up to 32767: staging offsets, float32 edge margins that scale with the frame,
+    15-bit region fields), very wide and very tall."""
+    from oracle import clib
+    frames, disp, stab = _clip(2, H, W, R, C, seed=H + W, kind='noise', jitter_sigma=0.6, translation_sigma=2.0)
+    out, crop, rec = _hip_warp(dev, frames, R, C, disp, stab)
+    want, want_crop, bad = clib.warp_clip(frames, R, C, disp, stab, use_bbox=True, openmp=True)
+    assert bad == 0
+    np.testing.assert_array_equal(crop, want_crop)
+    assert np.array_equal(out, want), f'{(out != want).sum()} bytes differ'
+
+
 def test_warp_matches_numpy_oracle_painter_loop(dev):
     """Against the reference-shaped per-cell painter loop (oracle/meshflow_oracle.py), small frame."""
     from oracle import meshflow_oracle as mo
