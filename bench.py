@@ -313,7 +313,10 @@ def main():
         if gather_error is not None:
             result['gather_error'] = gather_error
         if world == 1 and not args.no_e2e and args.as_rank_of <= 1:
-            result['end_to_end'] = end_to_end(stab, d_frames, disp, hom, F)
+            try:
+                result['end_to_end'] = end_to_end(stab, d_frames, disp, hom, F)
+            except Exception as e:                      # (host memory): never let the side measurement take the line down
+                result['end_to_end'] = {'error': f'{type(e).__name__}: {e}'}
         if world == 1 and args.cpu_frames > 0:
             result['cpu_baseline'] = cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, args.cpu_frames)
         else:
