@@ -223,33 +223,36 @@ def main():
     # (mfs.py:236-452 after the tracker), synthetic features for the same number of frame pairs.
     motion_row = None
     if rank == 0:
-        from meshflow_amd import host as mfhost
-        Fm = min(F, per_gpu)                          # one GPU's worth of frame pairs, whatever N is
-        feats = synthetic.features(Fm, H, W, hom[:Fm], seed=seed, per_pair=(1500, 2500))
-        early, late, offsets, kmax = mfhost.pack_features(feats)
-        d_in = [torch.from_numpy(a).to(device) for a in (early, late, offsets, np.ascontiguousarray(hom[:Fm - 1]))]
-        ops.vertex_motion(*d_in, kmax, W, H, R, C, stab.feature_ellipse_row_count, stab.feature_ellipse_col_count)
-        m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        m0.record()
-        for _ in range(3):
-            _, _, status = ops.vertex_motion(*d_in, kmax, W, H, R, C, stab.feature_ellipse_row_count,
-                                             stab.feature_ellipse_col_count)
-        m1.record()
-        torch.cuda.synchronize()
-        ops.vertex_motion_check(status)
-        motion_ms = m0.elapsed_time(m1) / 3
-        motion_row = {'kernels': 'feature_prep + bitonic sort + vertex_median + median_blur + accumulate',
-                      'avg_ms': motion_ms, 'frame_pairs': Fm - 1, 'features': int(early.shape[0]),
-                      'pairs_per_s': (Fm - 1) / (motion_ms * 1e-3),
-                      'note': 'outside the timed region; latency/ALU bound (no meaningful HBM roofline: 14 MB of features)'}
-        del d_in
-        if world == 1 and args.cpu_frames > 0:
-            from oracle import clib
-            threads = clib.set_threads(min(usable_cpus(), 32))
-            t1 = time.perf_counter()
-            clib.vertex_motion(W, H, R, C, stab.feature_ellipse_row_count, stab.feature_ellipse_col_count, feats, hom[:Fm], openmp=True)
-            motion_row['cpu_port_pairs_per_s'] = (Fm - 1) / (time.perf_counter() - t1)
-            motion_row['cpu_port_threads'] = threads
+        try:                                          # rank 0 only: a failure here must not strand the other ranks
+            from meshflow_amd import host as mfhost
+            Fm = min(F, per_gpu)                          # one GPU's worth of frame pairs, whatever N is
+            feats = synthetic.features(Fm, H, W, hom[:Fm], seed=seed, per_pair=(1500, 2500))
+            early, late, offsets, kmax = mfhost.pack_features(feats)
+            d_in = [torch.from_numpy(a).to(device) for a in (early, late, offsets, np.ascontiguousarray(hom[:Fm - 1]))]
+            ops.vertex_motion(*d_in, kmax, W, H, R, C, stab.feature_ellipse_row_count, stab.feature_ellipse_col_count)
+            m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            m0.record()
+            for _ in range(3):
+                _, _, status = ops.vertex_motion(*d_in, kmax, W, H, R, C, stab.feature_ellipse_row_count,
+                                                 stab.feature_ellipse_col_count)
+            m1.record()
+            torch.cuda.synchronize()
+            ops.vertex_motion_check(status)
+            motion_ms = m0.elapsed_time(m1) / 3
+            motion_row = {'kernels': 'feature_prep + bitonic sort + vertex_median + median_blur + accumulate',
+                          'avg_ms': motion_ms, 'frame_pairs': Fm - 1, 'features': int(early.shape[0]),
+                          'pairs_per_s': (Fm - 1) / (motion_ms * 1e-3),
+                          'note': 'outside the timed region; latency/ALU bound (no meaningful HBM roofline: 14 MB of features)'}
+            del d_in
+            if world == 1 and args.cpu_frames > 0:
+                from oracle import clib
+                threads = clib.set_threads(min(usable_cpus(), 32))
+                t1 = time.perf_counter()
+                clib.vertex_motion(W, H, R, C, stab.feature_ellipse_row_count, stab.feature_ellipse_col_count, feats, hom[:Fm], openmp=True)
+                motion_row['cpu_port_pairs_per_s'] = (Fm - 1) / (time.perf_counter() - t1)
+                motion_row['cpu_port_threads'] = threads
+        except Exception as e:
+            motion_row = {'error': f'{type(e).__name__}: {e}'}
     # north_star's "single RCCL gather over xGMI at the end": timed once, after the timed region (it is 7 x 1.87 GB into
     # one GPU -- an order of magnitude above a step -- and a consumer in host memory is better served by every rank
     # draining its own shard over its own PCIe link).  --no-gather skips it.
@@ -318,7 +321,11 @@ def main():
             except Exception as e:                      # (host memory): never let the side measurement take the line down
                 result['end_to_end'] = {'error': f'{type(e).__name__}: {e}'}
         if world == 1 and args.cpu_frames > 0:
-            result['cpu_baseline'] = cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, args.cpu_frames)
+            try:
+                result['cpu_baseline'] = cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, args.cpu_frames)
+            except Exception as e:                      # e.g. no C compiler and no prebuilt oracle on the box
+                result['cpu_baseline'] = {'value': None, 'unit': 'frames/s', 'cores': 0, 'kind': 'port',
+                                          'sample': f'failed: {type(e).__name__}: {e}'}
         else:
             result['cpu_baseline'] = None
         print(json.dumps(result))
