@@ -11,11 +11,21 @@ the reference's outputs), together with this script.  Run from the repo root:
 
     python oracle/gen_golden.py            # needs /root/reference
     python oracle/gen_golden.py motion     # only the vertex-motion vectors (mfs.py:236-452)
+    python oracle/gen_golden.py warp       # only the warp vectors (mfs.py:909-1108)
 
 For the vertex-motion vectors the stub additionally provides `cv2.perspectiveTransform` and `cv2.medianBlur`
 (the build's own restatements from oracle/), and `_get_matched_features_and_homography` (the FAST/LK/RANSAC
 tracker, mfs.py:455-629) is replaced by a lookup into synthetic features; everything else -- the ellipse splat,
 `statistics.median`, the dtype flow, the running sum -- is the reference's own code.
+
+For the warp vectors (`warp_*.npz`) the REAL `_get_stabilized_frames_and_crop_boundaries` (mfs.py:909-1108) runs with
+the four OpenCV calls it makes -- `cv2.findHomography` (mfs.py:1041-1042), `cv2.warpPerspective` (mfs.py:1052; the FULL
+float64 bilinear warp of the mask image, not the non-zero-pattern shortcut), `cv2.perspectiveTransform` (mfs.py:1054)
+and `cv2.remap` (mfs.py:1063-1069) -- served by the restatements in oracle/meshflow_oracle.py.  Everything else is the
+reference's own NumPy: the int64 map templates (mfs.py:983-984), the row-major painter loop with `np.where` on the
+mask's truthiness (mfs.py:1031-1061), the int64 -> float64 promotion of the maps, the four edge scans on the float64
+maps (mfs.py:1075-1098) and the clip-level reduction (mfs.py:1103-1106).  So what stays unpinned in the warp half is
+exactly those four cv2 kernels.
 """
 import os
 import sys
@@ -43,8 +53,29 @@ def import_reference():
         assert ksize == 3
         return mt.median_blur3_f32(img)
 
+    def find_homography(src, dst, *args, **kwargs):
+        from oracle import meshflow_oracle as mo
+        assert not args and not kwargs                                # method 0, mfs.py:1041-1042
+        return mo.find_homography_4pt(src, dst), None
+
+    def warp_perspective(src, m, dsize, *args, **kwargs):
+        from oracle import meshflow_oracle as mo
+        assert not args and not kwargs                                # INTER_LINEAR, BORDER_CONSTANT 0, mfs.py:1052
+        assert np.asarray(src).dtype == np.float64 and np.asarray(src).ndim == 2
+        return mo.warp_perspective_f64_bilinear_np(src, m, dsize[0], dsize[1])
+
+    def remap(src, map1, map2, interpolation, borderValue=(0, 0, 0)):
+        from oracle import meshflow_oracle as mo
+        assert interpolation == stub.INTER_LINEAR                      # mfs.py:1063-1069
+        assert map1.dtype == np.float32 and map2.dtype == np.float32 and map1.shape == src.shape[:2] + (1,)
+        return mo.remap_bilinear_u8c3(src, map1[..., 0], map2[..., 0], borderValue)
+
     stub.perspectiveTransform = perspective_transform
     stub.medianBlur = median_blur
+    stub.findHomography = find_homography
+    stub.warpPerspective = warp_perspective
+    stub.remap = remap
+    stub.INTER_LINEAR = 1
     sys.modules['cv2'] = stub
     sys.path.insert(0, REFERENCE_DIR)
     import meshflowstabilizer as mfs
@@ -111,10 +142,53 @@ def motion_goldens(MFS):
                             velocities=vel, displacements=disp, counts0=counts, lists0_x=flat_x, lists0_y=flat_y)
 
 
+WARP_CASES = (
+    # name, W, H, R, C, frames, frame kind, border (B, G, R), motion keywords, extra global shift (dx, dy) on the last frame
+    ('warp_small', 64, 48, 3, 3, 3, 'noise', (0, 0, 255), dict(translation_sigma=1.5, field_sigma=0.6), None),
+    ('warp_ragged', 101, 75, 5, 3, 2, 'noise', (0, 0, 255), dict(translation_sigma=2.0, field_sigma=1.0, jitter_sigma=0.3), None),   # R != C, W % 4 != 0
+    ('warp_jitter', 96, 64, 4, 6, 3, 'noise', (17, 200, 3), dict(translation_sigma=2.0, field_sigma=1.0, jitter_sigma=2.0), None),   # strong iid vertex jitter
+    ('warp_shift', 128, 72, 8, 8, 2, 'pattern', (0, 0, 255), dict(translation_sigma=0.5, field_sigma=0.3), (5.0, -3.0)),            # global shift of the last frame: wide uncovered bands
+    ('warp_mesh16', 256, 144, 16, 16, 2, 'noise', (0, 0, 255), dict(translation_sigma=2.0, field_sigma=1.0, jitter_sigma=0.5), None),  # the default mesh
+)
+
+
+def warp_inputs(W, H, R, C, F, kind, motion_kw, shift, seed):
+    """Frames + unstabilized / stabilized vertex displacements of one case (regenerated in the tests from the
+    build's hash-based generator; the "stabilized" paths are a damped copy of the unstabilized ones, which is
+    all the warp needs -- it only sees their difference, mfs.py:964-967)."""
+    from meshflow_amd import synthetic
+    frames = synthetic.frames_numpy(F, H, W, seed=seed, kind=kind)
+    unstab, _ = synthetic.motion(F, R, C, seed=seed, **motion_kw)
+    stab = 0.35 * unstab
+    if shift is not None:
+        stab = stab.copy()
+        stab[-1] += np.asarray(shift)
+    return frames, unstab, stab
+
+
+def warp_goldens(MFS):
+    """(7) the mesh warp and crop-boundary scan, mfs.py:909-1108 -- see the module docstring for what is stubbed."""
+    for i, (name, W, H, R, C, F, kind, border, motion_kw, shift) in enumerate(WARP_CASES):
+        frames, unstab, stab = warp_inputs(W, H, R, C, F, kind, motion_kw, shift, seed=40 + i)
+        s = MFS(mesh_row_count=R, mesh_col_count=C, color_outside_image_area_bgr=border)
+        out, bounds = s._get_stabilized_frames_and_crop_boundaries(F, list(frames), unstab, stab)
+        assert len(out) == F and all(o.dtype == np.uint8 and o.shape == (H, W, 3) for o in out)
+        assert all(isinstance(b, np.integer) for b in bounds)
+        np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), width=W, height=H, R=R, C=C, F=F, kind=kind,
+                            border=np.array(border), seed=40 + i, frames=frames, unstab=unstab, stab=stab,
+                            out=np.stack(out), bounds=np.array(bounds, dtype=np.int64))
+        print(name, 'bounds', tuple(int(b) for b in bounds), 'border pixels',
+              int((np.stack(out) == np.array(border, dtype=np.uint8)).all(axis=-1).sum()))
+
+
 def main():
     from meshflow_amd import synthetic
     MFS = import_reference()
     os.makedirs(GOLDEN, exist_ok=True)
+    if sys.argv[1:] == ['warp']:
+        warp_goldens(MFS)
+        print('warp vectors written to', GOLDEN)
+        return
     if sys.argv[1:] == ['motion']:
         motion_goldens(MFS)
         print('vertex-motion vectors written to', GOLDEN)
@@ -193,6 +267,7 @@ def main():
     np.savez_compressed(os.path.join(GOLDEN, 'stability.npz'), **out)
 
     motion_goldens(MFS)
+    warp_goldens(MFS)
     print('golden vectors written to', GOLDEN)
 
 

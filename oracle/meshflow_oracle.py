@@ -393,6 +393,43 @@ def warp_perspective_f64_bilinear(src, H_fwd, frame_width, frame_height):
     return out
 
 
+def warp_perspective_f64_bilinear_np(src, H_fwd, frame_width, frame_height):
+    """The same arithmetic as `warp_perspective_f64_bilinear`, vectorised (NumPy) so that whole frames are affordable:
+    this is what the stub `cv2.warpPerspective` of oracle/gen_golden.py runs inside the REAL reference's per-cell loop
+    (mfs.py:1052).  float64 source, float32 weight products from the 32-entry table, taps outside the source = 0,
+    sum in the order S00*w0 + S01*w1 + S10*w2 + S11*w3 (imgwarp.cpp remapBilinear, WT = double, AT = float)."""
+    src = np.asarray(src, dtype=np.float64)
+    sh, sw = src.shape
+    M = invert3x3(np.asarray(H_fwd, dtype=np.float64)).reshape(9)
+    xs = np.arange(frame_width, dtype=np.float64)
+    xb = np.floor(xs / 64.0) * 64.0
+    x1 = xs - xb
+    y = np.arange(frame_height, dtype=np.float64)[:, None]
+    X0 = (M[0] * xb[None, :] + M[1] * y) + M[2]
+    Y0 = (M[3] * xb[None, :] + M[4] * y) + M[5]
+    W0 = (M[6] * xb[None, :] + M[7] * y) + M[8]
+    Wd = W0 + M[6] * x1[None, :]
+    with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+        Ws = np.where(Wd != 0.0, 32.0 / Wd, 0.0)
+        fX = np.maximum(float(INT_MIN), np.minimum(float(INT_MAX), (X0 + M[0] * x1[None, :]) * Ws))
+        fY = np.maximum(float(INT_MIN), np.minimum(float(INT_MAX), (Y0 + M[3] * x1[None, :]) * Ws))
+    X = _cv_round_f64(fX)
+    Y = _cv_round_f64(fY)
+    ix, iy, fx, fy = X >> 5, Y >> 5, X & 31, Y & 31
+    tab = np.array([1.0 - np.float32(i) / np.float32(32) for i in range(32)], dtype=np.float32)
+    wx = (tab[fx], np.float32(1.0) - tab[fx])
+    wy = (tab[fy], np.float32(1.0) - tab[fy])
+    acc = np.zeros((frame_height, frame_width))
+    for dy in (0, 1):
+        for dx in (0, 1):
+            tx, ty = ix + dx, iy + dy
+            inside = (tx >= 0) & (tx < sw) & (ty >= 0) & (ty < sh)
+            v = np.where(inside, src[np.clip(ty, 0, sh - 1), np.clip(tx, 0, sw - 1)], 0.0)
+            acc = acc + v * (wy[dy] * wx[dx]).astype(np.float32).astype(np.float64)
+    outside = (ix >= sw) | (ix + 1 < 0) | (iy >= sh) | (iy + 1 < 0)
+    return np.where(outside, 0.0, acc)
+
+
 def perspective_transform_f32(points_xy_f32, H):
     """cv2.perspectiveTransform on float32 2-channel points with a float64 3x3 matrix
     (core/matmul.simd.hpp perspectiveTransform_): w = x*m6 + y*m7 + m8 in double; if |w| > FLT_EPSILON

@@ -5,9 +5,12 @@
 #   3. the same two PMC passes on tools/calib_fetch (known byte counts) to calibrate the counters
 tag=${1:-r01}
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$tag; mkdir -p $O; cd /tmp
-BENCH="python3 $R/bench.py --steps 5 --warmup 1 --cpu-frames 0"
+WORKLOAD=${WORKLOAD:-cfg2}
+BENCH="python3 $R/bench.py --steps 5 --warmup 1 --cpu-frames 0 --no-e2e --workload $WORKLOAD"
+# >= 50 launches per kernel for the duration statistics (the PMC passes serialise kernels and need fewer)
+BENCH_STATS="python3 $R/bench.py --steps ${STATS_STEPS:-50} --warmup 5 --cpu-frames 0 --no-e2e --workload $WORKLOAD"
 rm -rf /tmp/ps /tmp/pf /tmp/pw /tmp/cf /tmp/cw
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -o r -- $BENCH > $O/stats_run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -o r -- $BENCH_STATS > $O/stats_run.log 2>&1
 grep -E "\"Name\"|mf::" /tmp/ps/r_kernel_stats.csv > $O/kernel_stats.csv
 cp /tmp/ps/r_domain_stats.csv $O/ 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o r -- $BENCH > $O/fetch_run.log 2>&1
