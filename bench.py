@@ -1,27 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the MeshFlow hot path (Jacobi smoothing + mesh warp) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4shard|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4shard|small] [--mode shard|clips|e2e]
 
 A "step" is one pass of the hot path over one synthetic clip whose inputs (frames, vertex
 displacements) are already resident in HBM: Jacobi coefficient setup (host, O(F)) -> Jacobi sweep ->
-per-cell homography table -> mesh warp + crop scan -> clip-level crop bounds.  Steps are issued back to back
-(the host prepares clip i+1 while the GPU works on clip i); the degenerate-mesh counter of all steps is read
-once, before the closing barrier.  N = 1 runs
-BASELINE.json configs[1] (1080p, 300 frames, 16x16 mesh, 100 Jacobi sweeps, ORIGINAL weights).
-N > 1 (launched by torch.distributed.run, one rank per GPU) shards ONE clip of 300*N frames by contiguous
-frame range: Jacobi replicated, each rank warps its own 300 frames, one 16-byte all-reduce of the crop
-bounds (weak scaling); the RCCL gather of all frames to rank 0 is timed once after the timed region.
+per-cell homography table -> mesh warp + crop scan -> clip-level crop bounds -> (N > 1) 16-byte crop all-reduce.
+It is `meshflow_amd.dist.stabilize_sharded` -- the function tests/test_dist_gloo.py drives under gloo -- with the HIP
+operators plugged in.  Steps are issued back to back (the host prepares clip i+1 while the GPU works on clip i); the
+degenerate-mesh counter of all steps is read once, before the closing barrier.  N = 1 runs BASELINE.json configs[1]
+(1080p, 300 frames, 16x16 mesh, 100 Jacobi sweeps, ORIGINAL weights).
+
+N > 1: one process per GPU.  Either launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or by `python bench.py --gpus N` alone: the parent then
+starts N fresh child processes with that environment BEFORE anything touches a GPU, waits for them and exits non-zero
+if any of them failed.  --mode shard: ONE clip of frames-per-GPU x N frames sharded by contiguous frame range, Jacobi
+replicated, one 16-byte all-reduce of the crop bounds (weak scaling); the RCCL gather of all frames to rank 0 that
+north_star names is timed once AFTER the timed region, next to the time every rank needs to drain its own shard to host
+memory.  --mode clips: N independent clips, no collective (BASELINE config 5).
+
+--mode e2e: `value` / `ms_per_step` are the host-to-host clip -- stabilize_clip() from a Python list of NumPy frames in
+host memory to the stabilized frames, crop bounds, paths and score back in host memory (PCIe both ways), mean over K
+runs, min beside it.  This is the ">= 500 frames/s end-to-end stabilize()" figure of BASELINE.json; it is never the
+default `value`, which is the HBM-resident rate.
 
 Rank 0 prints ONE JSON line (fields: see the task's bench contract) including
   roofline:     warp kernel, algorithmic bytes 2*H*W*3 per frame over its HIP-event time, vs 8 TB/s HBM
-  end_to_end:   stabilize_clip() from host frames to host frames (PCIe both ways), N = 1 only; never `value`
-  cpu_baseline: the C oracle (oracle/warp_oracle.c, OpenMP) timed on this box's host cores on a bounded
-                sample of the same workload (N = 1 only).
+  end_to_end:   the e2e figure above for the same workload (mean and min of 5 runs), N = 1 only
+  cpu_baseline: the C oracle (oracle/warp_oracle.c, OpenMP) timed on this box's host cores on a bounded sample of the
+                same workload (kind "port"), and under "reference_faithful" the reference's own formulation -- dense
+                matmul Jacobi per vertex (mfs.py:695-704, 875-876), per-cell full-frame painter loop (mfs.py:1031-1061)
+                -- restated in NumPy, timed on a few vertices / frames / cells and scaled (N = 1 only)
+  cfg1:         BASELINE.json configs[0] (videos/video-1/video-1.m4v through the reference on the CPU) needs a video
+                decoder; reported as "skipped: no decoder" where cv2 is absent.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -85,23 +102,133 @@ def cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, budget_frames):
         'sample': f'C oracle (OpenMP, {threads} threads, bbox-culled single-pass warp): Jacobi of the full clip '
                   f'({t_jac:.2f} s) + warp of {len(sel)} of {F} frames ({t_warp:.2f} s), warp scaled linearly',
         'jacobi_s': t_jac, 'warp_s_per_frame': t_warp / len(sel),
+    }, stab
+
+
+def cpu_reference_faithful(H, W, F, R, C, omega, iters, disp, hom, stab, vertices=8, frames=2, cells=16):
+    """The reference's OWN formulation of the two stages, restated in NumPy (oracle/meshflow_oracle.py) and timed on a
+    bounded sample, scaled linearly (CPU baseline figure 1):
+      Jacobi: dense F x F coefficient matrices (mfs.py:713-783) and, per vertex, `iters` x two dense np.matmul
+              (mfs.py:695-704, 871-876) on `vertices` of the V vertices;
+      warp:   per frame the row-major painter loop over cells -- two 4-point homographies, the full-frame float64 mask
+              through the bilinear warpPerspective, perspectiveTransform of every pixel, two np.where (mfs.py:1031-1061)
+              -- on `cells` of the R*C cells of `frames` frames, plus the per-frame remap and four edge scans
+              (mfs.py:1063-1098).  Every cell does the same full-frame passes, so the loop scales with the cell count.
+    OpenCV's own C++ would be faster than these NumPy restatements of its kernels; the figure is an upper bound on the
+    reference's time, labelled as scaled."""
+    from meshflow_amd import synthetic
+    from oracle import meshflow_oracle as mo
+    V = (R + 1) * (C + 1)
+    vertices = min(vertices, V)
+    cells = min(cells, R * C)
+    frames = min(frames, F)
+    t0 = time.perf_counter()
+    off, on = mo.jacobi_method_input(F, W, H, 0, hom, omega)
+    t_setup = time.perf_counter() - t0
+    flat = disp.reshape(F, V, 2)
+    vsel = np.unique(np.linspace(0, V - 1, vertices).astype(int))
+    t0 = time.perf_counter()
+    for v in vsel:
+        mo.jacobi_method_output_dense(off, on, flat[:, v], flat[:, v], iters)
+    t_vertex = (time.perf_counter() - t0) / len(vsel)
+    t_jac = t_setup + t_vertex * V
+    fsel = np.linspace(0, F - 1, frames).astype(int)
+    frame = synthetic.frames_numpy(1, H, W, seed=0, kind='pattern')[0]
+    t_fixed = t_cells = 0.0
+    for f in fsel:
+        t0 = time.perf_counter()
+        mo.warp_frame(frame, R, C, disp[f], stab[f], max_cells=0)
+        t1 = time.perf_counter()
+        mo.warp_frame(frame, R, C, disp[f], stab[f], max_cells=cells, full_mask=True)
+        t2 = time.perf_counter()
+        t_fixed += t1 - t0
+        t_cells += max((t2 - t1) - (t1 - t0), 0.0)
+    per_frame = t_fixed / len(fsel) + (t_cells / len(fsel)) * (R * C / cells)
+    per_clip = t_jac + per_frame * F
+    return {
+        'value': F / per_clip, 'unit': 'frames/s', 'cores': 1,
+        'kind': f'reference-faithful, scaled from {len(vsel)} of {V} vertices and {cells} of {R * C} cells of {len(fsel)} of {F} frames',
+        'sample': f'NumPy restatement of the reference\'s formulation (single thread apart from BLAS): dense Jacobi set-up {t_setup:.2f} s + '
+                  f'{t_vertex * 1e3:.1f} ms per vertex; painter loop {t_cells / len(fsel) / cells * 1e3:.0f} ms per cell and frame + '
+                  f'{t_fixed / len(fsel):.2f} s per frame for templates, remap and edge scans',
+        'jacobi_s_per_clip': t_jac, 'warp_s_per_frame': per_frame,
     }
 
 
-def end_to_end(stab, d_frames, disp, hom, F):
-    """BASELINE.json's other figure: frames/s of stabilize_clip() from a Python list of NumPy frames in host memory to a list
-    of stabilized frames + crop bounds + paths + stability score back in host memory (PCIe both ways, pageable buffers, as
-    the reference passes them).  Never `value`.  Best of three."""
-    frames = [f.copy() for f in d_frames.cpu().numpy()]           # separate allocations, like a decoder's output
-    best = float('inf')
-    for _ in range(3):
+def cfg1_status():
+    """BASELINE.json configs[0]: videos/video-1/video-1.m4v through the reference's CPU path (mfs.py:1325-1340).  Needs a
+    video decoder (cv2); the reference and its videos do not exist on the GPU box either."""
+    try:
+        import cv2  # noqa: F401
+    except Exception:
+        return 'skipped: no decoder'
+    video = os.path.join(os.environ.get('MESHFLOW_REFERENCE_DIR', '/root/reference'), 'videos', 'video-1', 'video-1.m4v')
+    if not os.path.exists(video):
+        return 'skipped: videos/video-1/video-1.m4v is not on this box'
+    return 'skipped: decoder present but the CPU reference leg is not part of this bench (run the reference directly)'
+
+
+def host_clip(stab, frames, disp, hom, runs):
+    """stabilize_clip() from host frames to host frames, `runs` times: list of seconds."""
+    times = []
+    for _ in range(runs):
         t0 = time.perf_counter()
         out = stab.stabilize_clip(frames, disp, hom)
-        best = min(best, time.perf_counter() - t0)
+        times.append(time.perf_counter() - t0)
         del out
-    return {'value': F / best, 'unit': 'frames/s', 'ms_per_clip': best * 1e3,
+    return times
+
+
+def end_to_end(stab, d_frames, disp, hom, F, runs=5):
+    """BASELINE.json's other figure: frames/s of stabilize_clip() from a Python list of NumPy frames in host memory to a list
+    of stabilized frames + crop bounds + paths + stability score back in host memory (PCIe both ways, pageable buffers, as
+    the reference passes them).  Never `value` outside --mode e2e.  One untimed run first, then mean and min of `runs`."""
+    frames = [f.copy() for f in d_frames.cpu().numpy()]           # separate allocations, like a decoder's output
+    host_clip(stab, frames, disp, hom, 1)
+    t = host_clip(stab, frames, disp, hom, runs)
+    mean, best = float(np.mean(t)), float(np.min(t))
+    return {'value': F / mean, 'unit': 'frames/s', 'ms_per_clip': mean * 1e3, 'min_ms_per_clip': best * 1e3,
+            'best_value': F / best, 'runs': runs,
             'what': 'stabilize_clip(list of F host frames) -> list of F host frames + crop bounds + paths + score; '
-                    'chunked, overlapped PCIe staging (meshflow_amd/pipeline.py); best of 3'}
+                    f'chunked, overlapped PCIe staging (meshflow_amd/pipeline.py); mean of {runs} runs after one untimed run, min beside it'}
+
+
+def launch_children(args):
+    """`python bench.py --gpus N` by itself: N fresh child processes, one per GPU, with torchrun's environment.  Nothing in
+    this parent touches a GPU (counting devices does not initialise HIP on this image); children are separate processes
+    started with subprocess -- never an exec of a process that has initialised the GPU.  Exit code: the first non-zero
+    child code."""
+    import torch
+    backend = os.environ.get('MESHFLOW_DIST_BACKEND', 'nccl')
+    visible = torch.cuda.device_count()
+    if visible < 1 or (backend == 'nccl' and visible < args.gpus):
+        print(f'bench.py: --gpus {args.gpus} but {visible} GPU(s) visible (one rank per GPU under RCCL; '
+              f'MESHFLOW_DIST_BACKEND=gloo lets ranks share a GPU for functional tests)', file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cpus() // args.gpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in pending:              # a dead rank strands the others in their collectives: end them (exact PIDs)
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def main():
@@ -111,18 +238,23 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
     ap.add_argument('--frames-kind', default='pattern', choices=['pattern', 'noise'])
-    ap.add_argument('--cpu-frames', type=int, default=300, help='frames warped by the CPU baseline (0 = skip)')
+    ap.add_argument('--cpu-frames', type=int, default=300, help='frames warped by the CPU baseline (0 = skip both CPU legs)')
     # default: the whole clip, ~5-10 s of host time
+    ap.add_argument('--no-faithful', action='store_true', help='skip the reference-faithful (dense / per-cell) CPU leg (~20 s)')
     ap.add_argument('--gather', action='store_true', help='(default for N > 1 in shard mode; kept for compatibility)')
     ap.add_argument('--no-gather', action='store_true', help='N > 1: skip the RCCL gather of all frames to rank 0 after the timed region')
-    ap.add_argument('--mode', default='shard', choices=['shard', 'clips'],
-                    help='N > 1: "shard" = ONE clip of N x frames sharded by frame range (Jacobi replicated, 16-byte crop '
-                         'all-reduce); "clips" = N independent clips, one per GPU, no collective (BASELINE config 5)')
-    ap.add_argument('--no-e2e', action='store_true', help='skip the host-buffers-in / host-buffers-out measurement (N = 1 only)')
+    ap.add_argument('--mode', default='shard', choices=['shard', 'clips', 'e2e'],
+                    help='"shard" = ONE clip of N x frames sharded by frame range (Jacobi replicated, 16-byte crop all-reduce); '
+                         '"clips" = N independent clips, one per GPU, no collective (BASELINE config 5); '
+                         '"e2e" = host frames in -> host frames out, PCIe both ways (N independent clips when N > 1)')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the host-buffers-in / host-buffers-out side measurement (N = 1 only)')
     ap.add_argument('--as-rank-of', type=int, default=0, metavar='N',
                     help='single process only: do the work rank 0 of an N-GPU "shard" run does (clip of N x frames, own '
                          'frame range, replicated Jacobi) without the collective -- predicts weak scaling on one GPU')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_children(args))
 
     import torch
     import torch.distributed as dist
@@ -131,17 +263,17 @@ def main():
 
     rank, world, device = mfdist.init_from_env('cuda')
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     H, W, per_gpu, R, C, omega, iters = WORKLOADS[args.workload]
-    clips_mode = args.mode == 'clips' and world > 1
+    e2e_mode = args.mode == 'e2e'
+    clips_mode = (args.mode == 'clips' and world > 1) or e2e_mode
     if clips_mode:                       # every rank owns a whole clip of its own (seed = rank)
-        F, lo, hi = per_gpu, 0, per_gpu
+        F, shard = per_gpu, (1, 0)
     elif args.as_rank_of > 1 and world == 1:
-        F = per_gpu * args.as_rank_of
-        lo, hi = host.shard_range(F, args.as_rank_of, 0)
+        F, shard = per_gpu * args.as_rank_of, (args.as_rank_of, 0)
     else:
-        F = per_gpu * world
-        lo, hi = host.shard_range(F, world, rank)
+        F, shard = per_gpu * world, (world, rank)
+    lo, hi = host.shard_range(F, *shard)
 
     stab = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=omega,
                               optimization_num_iterations=iters, device=str(device))
@@ -149,32 +281,83 @@ def main():
     disp, hom = synthetic.motion(F, R, C, seed=seed)
     d_disp = torch.from_numpy(disp).to(device)
     d_frames = synthetic.frames_torch(hi - lo, H, W, device, seed=seed, kind=args.frames_kind, first_frame=lo)
-    d_out = torch.empty_like(d_frames)
-    table = ops.CellTable(hi - lo, W, H, R, C, device)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    jev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
-    def step(i=None):
-        if i is not None:
-            jev[i][0].record()
-        d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
-        if i is not None:
-            jev[i][1].record()
-        ops.cell_table(d_disp[lo:hi], d_stab[lo:hi], W, H, R, C, table=table, reset_status=False)
-        if i is not None:
-            ev[i][0].record()
-        ops.warp(d_frames, table, stab.color_outside_image_area_bgr, out=d_out)
-        if i is not None:
-            ev[i][1].record()
-        bounds = ops.crop_reduce(table.crop, W, H)
-        if not clips_mode:
-            bounds = mfdist.allreduce_crop(bounds)
-        return d_stab, bounds              # degenerate-mesh counter accumulates in table.status (checked below)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        return float(mfdist.all_reduce_max(t).item())
+
+    comm = {'world_size': dist.get_world_size() if world > 1 else 1,
+            'backend': (dist.get_backend() if world > 1 else None),
+            'note': 'world size as the torch.distributed communicator reports it ("nccl" is RCCL on ROCm)'}
+
+    if e2e_mode:
+        # host frames in -> host frames out; K timed clips after W untimed ones, barrier on both sides
+        frames_h = [f.copy() for f in d_frames.cpu().numpy()]
+        del d_frames
+        host_clip(stab, frames_h, disp, hom, max(args.warmup, 1))
+        barrier()
+        t0 = time.perf_counter()
+        times = host_clip(stab, frames_h, disp, hom, args.steps)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            print(json.dumps({
+                'metric': 'frames/sec end-to-end stabilize_clip(): host frames in -> stabilized host frames + crop bounds + paths + score out (PCIe both ways)',
+                'value': F * world * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': max(args.warmup, 1),
+                'ms_per_step': elapsed / args.steps * 1e3, 'min_ms_per_step_rank0': float(np.min(times)) * 1e3,
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+                'data': f'synthetic ({args.frames_kind} frames, injected random mesh motion, seed = rank)',
+                'config': {'workload': f'{args.workload}: {W}x{H}, {per_gpu} frames per clip, {R}x{C} mesh, omega={omega}, {iters} Jacobi sweeps, '
+                                       f'ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL; pageable NumPy frame list in, list out',
+                           'parallelism': f'{world} independent clip(s), one per GPU, each over its own PCIe link'},
+                'roofline': None, 'cpu_baseline': None, 'communicator': comm,
+                'note': 'PCIe-inclusive rate; the HBM-resident rate and the kernel roofline are the default mode\'s line'}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    d_out = torch.empty_like(d_frames)
+    table = ops.CellTable(hi - lo, W, H, R, C, device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    jev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    now = {'i': None}                      # index of the timed step being issued (None during warm-up)
+
+    # The three stages handed to dist.stabilize_sharded; HIP events bracket the Jacobi stage and the warp kernel on the
+    # launch stream (torch's current stream IS the stream ops.* launch on).
+    def jacobi_fn():
+        i = now['i']
+        if i is not None:
+            jev[i][0].record()
+        d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
+        if i is not None:
+            jev[i][1].record()
+        return d_stab
+
+    def warp_fn(lo_, hi_, d_stab):
+        i = now['i']
+        ops.cell_table(d_disp[lo_:hi_], d_stab[lo_:hi_], W, H, R, C, table=table, reset_status=False)
+        if i is not None:
+            ev[i][0].record()
+        ops.warp(d_frames, table, stab.color_outside_image_area_bgr, out=d_out)
+        if i is not None:
+            ev[i][1].record()
+        return d_out, table.crop           # degenerate-mesh counter accumulates in table.status (checked below)
+
+    def crop_reduce_fn(crop):
+        return ops.crop_reduce(crop, W, H)
+
+    def step(i=None):
+        now['i'] = i
+        _, bounds, d_stab, _ = mfdist.stabilize_sharded(F, jacobi_fn, warp_fn, crop_reduce_fn, gather=False, shard=shard,
+                                                        collective=not clips_mode)
+        return d_stab, bounds
 
     for _ in range(args.warmup):
         step()
@@ -184,10 +367,7 @@ def main():
         d_stab, bounds = step(i)
     table.check()                          # degenerate-mesh check of all K steps: one 4-byte D2H, inside the timing
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        elapsed = float(mfdist.all_reduce_max(t).item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
     warp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     jac_ms = float(np.mean([a.elapsed_time(b) for a, b in jev]))
@@ -255,16 +435,25 @@ def main():
             motion_row = {'error': f'{type(e).__name__}: {e}'}
     # north_star's "single RCCL gather over xGMI at the end": timed once, after the timed region (it is 7 x 1.87 GB into
     # one GPU -- an order of magnitude above a step -- and a consumer in host memory is better served by every rank
-    # draining its own shard over its own PCIe link).  --no-gather skips it.
-    gather_ms, gather_error = None, None
+    # draining its own shard over its own PCIe link).  Both figures are reported side by side;
+    # --no-gather skips them.
+    gather_ms = gather_error = d2h_ms = None
     if world > 1 and not clips_mode and not args.no_gather:
         try:
             barrier()
             t1 = time.perf_counter()
             gathered = mfdist.gather_frames(d_out, F)
             barrier()
-            gather_ms = (time.perf_counter() - t1) * 1e3
+            gather_ms = max_over_ranks(time.perf_counter() - t1) * 1e3
             del gathered
+            pinned = torch.empty(d_out.shape, dtype=torch.uint8, pin_memory=True)
+            pinned.copy_(d_out)                      # touch the pages once
+            barrier()
+            t1 = time.perf_counter()
+            pinned.copy_(d_out, non_blocking=True)
+            barrier()
+            d2h_ms = max_over_ranks(time.perf_counter() - t1) * 1e3
+            del pinned
         except Exception as e:                      # never let the optional collective take the measurement down
             gather_error = f'{type(e).__name__}: {e}'
 
@@ -298,6 +487,8 @@ def main():
                        'bound': 'fp64 vector ALU + LDS (the state never leaves the chip)', 'achieved': jac_flops / (jac_kernel_ms * 1e-3) / 1e12,
                        'peak': 78.6, 'unit': 'TFLOP/s', 'frac': jac_flops / (jac_kernel_ms * 1e-3) / 78.6e12},
             'crop_bounds': [int(v) for v in bounds.tolist()],
+            'communicator': comm,
+            'cfg1': cfg1_status(),
         }
         if resize_ms is not None:
             result['next_rows'] = {'crop_resize': {'kernel': 'resize_kernel', 'avg_launch_ms': resize_ms, 'bound': 'hbm',
@@ -312,7 +503,10 @@ def main():
             result.setdefault('next_rows', {})['vertex_motion'] = motion_row
         if gather_ms is not None:
             result['gather_to_rank0_ms'] = gather_ms
-            result['gather_note'] = 'one RCCL gather of every rank\'s stabilized frames to rank 0, after the timed region'
+            result['sharded_d2h_ms'] = d2h_ms
+            result['gather_note'] = ('after the timed region, max over ranks: gather_to_rank0_ms = one gather of every rank\'s stabilized frames '
+                                     'to rank 0 over xGMI (north_star\'s final gather); sharded_d2h_ms = every rank draining its own shard to '
+                                     'pinned host memory over its own PCIe link (what a host-memory consumer would use instead)')
         if gather_error is not None:
             result['gather_error'] = gather_error
         if world == 1 and not args.no_e2e and args.as_rank_of <= 1:
@@ -322,10 +516,16 @@ def main():
                 result['end_to_end'] = {'error': f'{type(e).__name__}: {e}'}
         if world == 1 and args.cpu_frames > 0:
             try:
-                result['cpu_baseline'] = cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, args.cpu_frames)
+                result['cpu_baseline'], stab_cpu = cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, args.cpu_frames)
             except Exception as e:                      # e.g. no C compiler and no prebuilt oracle on the box
+                stab_cpu = None
                 result['cpu_baseline'] = {'value': None, 'unit': 'frames/s', 'cores': 0, 'kind': 'port',
                                           'sample': f'failed: {type(e).__name__}: {e}'}
+            if stab_cpu is not None and not args.no_faithful:
+                try:
+                    result['cpu_baseline']['reference_faithful'] = cpu_reference_faithful(H, W, F, R, C, omega, iters, disp, hom, stab_cpu)
+                except Exception as e:
+                    result['cpu_baseline']['reference_faithful'] = {'value': None, 'kind': 'reference-faithful', 'sample': f'failed: {type(e).__name__}: {e}'}
         else:
             result['cpu_baseline'] = None
         print(json.dumps(result))

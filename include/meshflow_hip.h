@@ -133,7 +133,8 @@ int mf_vertex_motion_f64(const double* d_early, const double* d_late, const int3
  * d_stab: [F][S] float64 as for mf_jacobi_f64 (S = V*2: x and y of every vertex interleaved).  Per series the fraction of
  * the velocity profile's spectral energy that sits in DFT bins 1..5 (five direct sums + Parseval for the total);
  * d_series: [S] float64 receives those fractions, d_score: [1] float64 the clip-level score
- * (mean over x series + mean over y series) / 2.  Needs F >= 7.  Agrees with np.fft to float64 rounding. */
+ * (mean over x series + mean over y series) / 2.  F >= 2; with fewer than 7 frames the slice [1:6] of mfs.py:1250-1251 holds
+ * fewer bins (bins 1..min(5, F-2)), exactly as in the reference.  Agrees with np.fft to float64 rounding. */
 int mf_stability_score_f64(const double* d_stab, int F, int S, double* d_series, double* d_score, void* stream);
 
 /* Device self-test: sqrt() on (0, 0.25] (the ellipse half-width, mfs.py:444) must be correctly rounded; *mismatches

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void stability_series_kernel(const double* __re
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const double r = wave_sum(re[k]), i = wave_sum(im[k]);
-        low += r * r + i * i;                                  // bins 1..5 all exist: the launcher requires N >= 6
+        if (k + 1 <= N - 1) low += r * r + i * i;              // the reference's slice [1:6] of N bins holds bins 1..min(5, N-1)
     }
     if (lane == 0) ratio[s] = low / ((double)N * tot);
 }
@@ -76,8 +76,10 @@ __global__ __launch_bounds__(256) void stability_reduce_kernel(const double* __r
 
 int launch_stability_score(const double* stab, int F, int S, double* ratio, double* score, hipStream_t st)
 {
-    if (F < 7 || S < 2 || (S & 1)) {
-        set_error("mf_stability_score_f64: needs at least 7 frames and an even number of series (F=%d S=%d)", F, S);
+    // F = 1 has an empty velocity profile (np.fft.fft of it raises ValueError in the reference, mfs.py:1245); from F = 2 on
+    // the slice [1:6] simply holds fewer bins (mfs.py:1250-1251)
+    if (F < 2 || S < 2 || (S & 1)) {
+        set_error("mf_stability_score_f64: needs at least 2 frames and an even number of series (F=%d S=%d)", F, S);
         return MF_ERR_INVALID_ARG;
     }
     stability_series_kernel<<<S, 64, 0, st>>>(stab, F, S, ratio);

@@ -108,19 +108,26 @@ def gather_frames(local_frames, num_frames, dst=0):
     return None
 
 
-def stabilize_sharded(num_frames, jacobi_fn, warp_fn, crop_reduce_fn, gather=False):
-    """Frame-range sharded pass of the hot path.
+def stabilize_sharded(num_frames, jacobi_fn, warp_fn, crop_reduce_fn, gather=False, shard=None, collective=True):
+    """Frame-range sharded pass of the hot path -- the function bench.py's timed step calls (with the HIP operators) and
+    tests/test_dist_gloo.py drives under gloo (with the oracle standing in for the kernels).
 
     jacobi_fn() -> stabilized displacements of ALL frames (replicated on every rank)
     warp_fn(lo, hi, stab_all) -> (stabilized frames [hi-lo, H, W, 3], per-frame crop values [hi-lo, 4])
     crop_reduce_fn(per_frame_crop) -> int32 tensor {left, top, right, bottom} of this shard
+    shard: (G, g) to take the frame range of rank g of G instead of this process's place in the process group (bench.py:
+    independent clips = (1, 0); rehearsal of one rank of a larger job); collective=False skips the crop all-reduce
+    (independent clips need none).
     Returns (local or gathered frames, clip-level crop bounds tensor, stab_all, (lo, hi))."""
-    G = world_size()
-    rank = dist.get_rank() if G > 1 else 0
-    lo, hi = host.shard_range(num_frames, G, rank)
+    if shard is None:
+        G = world_size()
+        shard = (G, dist.get_rank() if G > 1 else 0)
+    lo, hi = host.shard_range(num_frames, *shard)
     stab_all = jacobi_fn()
     frames, crop = warp_fn(lo, hi, stab_all)
-    bounds = allreduce_crop(crop_reduce_fn(crop))
+    bounds = crop_reduce_fn(crop)
+    if collective:
+        bounds = allreduce_crop(bounds)
     if gather:
         frames = gather_frames(frames, num_frames)
     return frames, bounds, stab_all, (lo, hi)

@@ -76,14 +76,36 @@ class MeshFlowStabilizer:
         cv2 = frontend_cv2.require_cv2()
         unstabilized_frames, num_frames, frames_per_second, codec = self._get_unstabilized_frames_and_video_features(input_path)
         disp, homographies = self._get_unstabilized_vertex_displacements_and_homographies(num_frames, unstabilized_frames)
-        _, _, stab, stability_score, cropped_frames = self.stabilize_clip(
-            unstabilized_frames, disp, homographies, adaptive_weights_definition, crop=True, keep_uncropped=False)
+        if self._boundary_overridden():
+            # A subclass (or an instance attribute) replaces one of the reference's boundary methods: keep the reference's
+            # own call sequence (mfs.py:150-162) so that the replacement is honoured, at the price of one PCIe round trip
+            # per method instead of one for the whole path.
+            stab = self._get_stabilized_vertex_displacements(
+                num_frames, unstabilized_frames, adaptive_weights_definition, disp, homographies)               # mfs.py:150
+            stabilized_frames, crop_boundaries = self._get_stabilized_frames_and_crop_boundaries(
+                num_frames, unstabilized_frames, disp, stab)                                                     # mfs.py:154
+            cropped_frames = self._crop_frames(stabilized_frames, crop_boundaries)                               # mfs.py:159
+            stability_score = self._compute_stability_score(num_frames, stab)                                    # mfs.py:162
+        else:
+            _, _, stab, stability_score, cropped_frames = self.stabilize_clip(
+                unstabilized_frames, disp, homographies, adaptive_weights_definition, crop=True, keep_uncropped=False)
         cropping_ratio, distortion_score = self._compute_cropping_ratio_and_distortion_score(
             num_frames, unstabilized_frames, cropped_frames)
         self._write_stabilized_video(output_path, num_frames, frames_per_second, codec, cropped_frames)
         if self.visualize:
             frontend_cv2.show_loop(cv2, frames_per_second, unstabilized_frames, cropped_frames)
         return (cropping_ratio, distortion_score, stability_score)
+
+    _BOUNDARY_METHODS = ('_get_stabilized_vertex_displacements', '_get_stabilized_frames_and_crop_boundaries',
+                         '_crop_frames', '_compute_stability_score')
+
+    def _boundary_overridden(self):
+        """True when one of the reference's boundary methods (called at mfs.py:150-162) is not this class's
+        own implementation: overridden in a subclass or patched on the instance."""
+        for name in self._BOUNDARY_METHODS:
+            if name in vars(self) or getattr(type(self), name) is not getattr(MeshFlowStabilizer, name):
+                return True
+        return False
 
     # ---- the reference's OpenCV-side helpers, same names, delegating to cv2 (frontend_cv2.py) ----
 

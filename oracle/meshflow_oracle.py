@@ -513,21 +513,33 @@ def cell_tables(frame_width, frame_height, mesh_rows, mesh_cols, unstab_disp_f, 
     return cells
 
 
-def warp_frame(frame, mesh_rows, mesh_cols, unstab_disp_f, stab_disp_f, border_bgr=(0, 0, 255)):
+def warp_frame(frame, mesh_rows, mesh_cols, unstab_disp_f, stab_disp_f, border_bgr=(0, 0, 255), max_cells=None,
+               full_mask=False):
     """One iteration of the frame loop mfs.py:1000-1100.
 
     Returns (stabilized_frame uint8 HxWx3, (left, top, right, bottom) per-frame crop values,
-    map_x float64 HxW, map_y float64 HxW)."""
+    map_x float64 HxW, map_y float64 HxW).
+    max_cells (TIMING ONLY, bench.py's reference-faithful CPU leg): stop the painter loop after that many cells -- every
+    cell costs the same full-frame passes, so the loop time scales linearly; the frame returned is then incomplete.
+    full_mask: build the cell mask like the reference does (full float64 mask image through the bilinear warp,
+    mfs.py:1050-1052) instead of through its non-zero pattern; same result (tests/test_oracle_warp_kat.py)."""
     frame = np.asarray(frame, dtype=np.uint8)
     H, W = frame.shape[:2]
     map_x = np.full((H, W), W + 1)                                                  # mfs.py:983, 1017
     map_y = np.full((H, W), H + 1)                                                  # mfs.py:984, 1018
     xy = np.swapaxes(np.indices((W, H), dtype=np.float32), 0, 2)                    # mfs.py:985  [y][x] = (x, y)
-    for Hf, Hi, (L, T, Rt, B) in cell_tables(W, H, mesh_rows, mesh_cols, unstab_disp_f, stab_disp_f):
+    for k, (Hf, Hi, (L, T, Rt, B)) in enumerate(cell_tables(W, H, mesh_rows, mesh_cols, unstab_disp_f, stab_disp_f)):
+        if max_cells is not None and k >= max_cells:
+            break
         if Hf is None or Hi is None:
             raise ValueError('degenerate mesh cell (cv2.findHomography would return None)')
         rect = (max(L, 0), max(T, 0), min(Rt, W - 1), min(B, H - 1))                # numpy slice clipping, mfs.py:1051
-        mask = warp_perspective_rect_mask(rect, Hf, W, H)                           # mfs.py:1050-1052
+        if full_mask:
+            cell_mask = np.zeros((H, W))                                            # mfs.py:1050
+            cell_mask[rect[1]:rect[3] + 1, rect[0]:rect[2] + 1] = 255               # mfs.py:1051
+            mask = warp_perspective_f64_bilinear_np(cell_mask, Hf, W, H)            # mfs.py:1052
+        else:
+            mask = warp_perspective_rect_mask(rect, Hf, W, H)                       # mfs.py:1050-1052
         cell_xy = perspective_transform_f32(xy, Hi)                                 # mfs.py:1054-1056
         map_x = np.where(mask, cell_xy[..., 0], map_x)                              # mfs.py:1060 (-> float64)
         map_y = np.where(mask, cell_xy[..., 1], map_y)                              # mfs.py:1061

@@ -1,4 +1,5 @@
-"""bench.py prints ONE JSON line with the fields the driver's contract names (run on the small workload)."""
+"""bench.py prints ONE JSON line with the fields the driver's contract names (run on the small workload); `--gpus 2` by
+itself starts two ranks and runs the real sharded step, all-reduce and gather of bench.py (gloo, both ranks on one GPU)."""
 import json
 import os
 import subprocess
@@ -11,19 +12,27 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_json_line_contract():
-    proc = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--workload', 'small', '--steps', '3', '--warmup', '1',
-                           '--cpu-frames', '4'], cwd=REPO, capture_output=True, text=True, timeout=600)
-    assert proc.returncode == 0, proc.stderr[-2000:]
-    lines = [l for l in proc.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+def _run(*flags, env=None):
+    proc = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--workload', 'small', *flags], cwd=REPO,
+                          capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _contract(d, n_gpus, steps, warmup):
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert key in d, key
-    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['n_gpus'] == n_gpus and d['steps'] == steps and d['warmup'] == warmup and d['higher_is_better'] is True
     assert d['scaling'] == 'weak' and d['vs_baseline'] is None and d['unit'] == 'frames/s' and d['value'] > 0
     assert 'workload' in d['config'] and 'model' not in d['config']
+
+
+def test_bench_json_line_contract():
+    d = _run('--steps', '3', '--warmup', '1', '--cpu-frames', '4')
+    _contract(d, 1, 3, 1)
     r = d['roofline']
     for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert key in r, key
@@ -32,4 +41,54 @@ def test_bench_json_line_contract():
     for key in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert key in c, key
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0
-    assert d['end_to_end']['value'] > 0 and d['next_rows']['vertex_motion']['avg_ms'] > 0
+    f = c['reference_faithful']                                  # the reference's own formulation, scaled from a sample
+    assert f['kind'].startswith('reference-faithful, scaled from') and 0 < f['value'] < c['value']
+    e = d['end_to_end']
+    assert e['value'] > 0 and e['runs'] >= 5 and e['min_ms_per_clip'] <= e['ms_per_clip']
+    assert d['next_rows']['vertex_motion']['avg_ms'] > 0
+    assert d['cfg1'].startswith('skipped')                       # BASELINE configs[0]: no decoder / no video on the box
+    assert d['communicator']['world_size'] == 1
+
+
+def test_bench_e2e_mode_value_is_the_host_to_host_clip():
+    d = _run('--mode', 'e2e', '--steps', '3', '--warmup', '1')
+    _contract(d, 1, 3, 1)
+    assert 'end-to-end' in d['metric'] and d['min_ms_per_step_rank0'] <= d['ms_per_step'] * 1.001
+    assert abs(d['value'] - 64 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']
+
+
+def test_bench_two_ranks_started_by_bench_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent starts both ranks.  gloo so that they can share the one
+    GPU of the test box; the step, the crop all-reduce, the frame gather and the sharded drain are bench.py's own code."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['MESHFLOW_DIST_BACKEND'] = 'gloo'
+    proc = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--workload', 'small', '--gpus', '2', '--steps', '2',
+                           '--warmup', '1'], cwd=REPO, capture_output=True, text=True, timeout=900, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    d = json.loads(lines[0])
+    _contract(d, 2, 2, 1)
+    assert d['communicator'] == {**d['communicator'], 'world_size': 2, 'backend': 'gloo'}
+    assert d['gather_to_rank0_ms'] > 0 and d['sharded_d2h_ms'] > 0 and 'gather_error' not in d
+    assert '128 total' in d['config']['workload'] and d['cpu_baseline'] is None
+    # the clip-level crop bounds of the two-rank run = those of ONE process warping all 128 frames of the same clip
+    from meshflow_amd import ops, synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    import torch
+    dev = torch.device('cuda:0')
+    disp, hom = synthetic.motion(128, 16, 16, seed=0)
+    s = MeshFlowStabilizer(device='cuda:0')
+    d_disp = torch.from_numpy(disp).to(dev)
+    d_stab = s._stabilized_vertex_displacements_device(d_disp, 640, 360, 0, hom)
+    _, crop = s._stabilized_frames_device(synthetic.frames_torch(128, 360, 640, dev, seed=0), d_disp, d_stab)
+    assert d['crop_bounds'] == ops.crop_reduce(crop, 640, 360).tolist()
+
+
+def test_bench_failed_rank_gives_nonzero_exit():
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['MESHFLOW_DIST_BACKEND'] = 'no-such-backend'
+    proc = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--workload', 'small', '--gpus', '2', '--steps', '1',
+                           '--warmup', '0'], cwd=REPO, capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode != 0
+    assert not [l for l in proc.stdout.splitlines() if l.strip().startswith('{')]

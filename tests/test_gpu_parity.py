@@ -511,7 +511,7 @@ def test_methods_borrowed_by_a_foreign_class(dev):
     assert len(cropped) == F and cropped[0].shape == (H, W, 3)
 
 
-@pytest.mark.parametrize('F,R,C', [(300, 16, 16), (48, 4, 4), (7, 2, 3), (601, 32, 32)])
+@pytest.mark.parametrize('F,R,C', [(300, 16, 16), (48, 4, 4), (7, 2, 3), (601, 32, 32), (6, 2, 2), (4, 3, 2), (3, 2, 2), (2, 1, 1)])
 def test_stability_score_on_device_vs_host(dev, F, R, C):
     """mf_stability_score_f64 (five direct DFT bins + Parseval) against the reference's np.fft formulation (host.py,
     pinned against the reference's own value in tests/test_oracle_golden.py): float64 rounding apart."""
@@ -523,5 +523,5 @@ def test_stability_score_on_device_vs_host(dev, F, R, C):
     xs = np.diff(disp.reshape(F, -1), axis=0).T                                # (S, N)
     en = np.square(np.abs(np.fft.fft(xs)))
     np.testing.assert_allclose(series.cpu().numpy(), en[:, 1:6].sum(1) / en.sum(1), rtol=1e-10, atol=1e-14)
-    with pytest.raises(ValueError):
-        ops.stability_score(torch.zeros((6, 3, 3, 2), dtype=torch.float64, device=dev))
+    with pytest.raises(ValueError):                                           # F = 1: np.fft.fft of an empty profile raises too
+        ops.stability_score(torch.zeros((1, 3, 3, 2), dtype=torch.float64, device=dev))

@@ -67,3 +67,41 @@ def test_stabilize_without_trackable_features_raises(cv2_stub):
     s = MeshFlowStabilizer(mesh_row_count=4, mesh_col_count=4, homography_min_number_corresponding_features=10 ** 6)
     with pytest.raises(ValueError, match='features could be tracked'):
         s.stabilize('in.m4v', 'out.m4v')
+
+
+def test_stabilize_honours_overridden_boundary_methods(cv2_stub):
+    """mfs.py:150-159: `stabilize` reaches the hot path through the two private methods (and `_crop_frames`).  A subclass
+    that overrides them -- the documented drop-in boundary -- must see its overrides called by the build's own `stabilize`,
+    with the reference's argument lists, and the result must equal the un-overridden fast path."""
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    _make_video(cv2_stub, 'in.m4v')
+    kw = dict(mesh_row_count=4, mesh_col_count=4, mesh_outlier_subframe_row_count=2, mesh_outlier_subframe_col_count=2,
+              feature_ellipse_row_count=3, feature_ellipse_col_count=3, temporal_smoothing_radius=3, optimization_num_iterations=10)
+    calls = []
+
+    class Traced(MeshFlowStabilizer):
+        def _get_stabilized_vertex_displacements(self, num_frames, unstabilized_frames, adaptive_weights_definition,
+                                                 vertex_unstabilized_displacements_by_frame_index, homographies):
+            calls.append(('jacobi', num_frames, adaptive_weights_definition, vertex_unstabilized_displacements_by_frame_index.shape))
+            return super()._get_stabilized_vertex_displacements(num_frames, unstabilized_frames, adaptive_weights_definition,
+                                                                vertex_unstabilized_displacements_by_frame_index, homographies)
+
+        def _get_stabilized_frames_and_crop_boundaries(self, num_frames, unstabilized_frames, unstab, stab):
+            calls.append(('warp', num_frames, len(unstabilized_frames), stab.shape))
+            return super()._get_stabilized_frames_and_crop_boundaries(num_frames, unstabilized_frames, unstab, stab)
+
+        def _crop_frames(self, uncropped_frames, crop_boundaries):
+            calls.append(('crop', len(uncropped_frames), tuple(int(v) for v in crop_boundaries)))
+            return super()._crop_frames(uncropped_frames, crop_boundaries)
+
+    assert not MeshFlowStabilizer(**kw)._boundary_overridden() and Traced(**kw)._boundary_overridden()
+    got = Traced(**kw).stabilize('in.m4v', 'traced.m4v', MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_FLIPPED)
+    assert [c[0] for c in calls] == ['jacobi', 'warp', 'crop']
+    assert calls[0][1:] == (10, 1, (10, 5, 5, 2)) and calls[1][1:] == (10, 10, (10, 5, 5, 2)) and calls[2][1] == 10
+    want = MeshFlowStabilizer(**kw).stabilize('in.m4v', 'plain.m4v', MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_FLIPPED)
+    assert got == want
+    np.testing.assert_array_equal(np.stack(cv2_stub.WRITTEN['traced.m4v']['frames']), np.stack(cv2_stub.WRITTEN['plain.m4v']['frames']))
+    # an instance-level patch counts as an override as well
+    s = MeshFlowStabilizer(**kw)
+    s._compute_stability_score = lambda num_frames, stab: 0.25
+    assert s._boundary_overridden() and s.stabilize('in.m4v', 'patched.m4v')[2] == 0.25
