@@ -153,6 +153,35 @@ int mf_jacobi_f64_host(const double* b, double* x, const double* taps, const dou
 int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab, const double* stab,
                       int n, int W, int H, int R, int C, const uint8_t border_bgr[3],
                       int32_t* crop /* [n][4] */, float* kernel_ms);
+/* The same for frames that are separate allocations (the reference's Python lists of per-frame arrays, mfs.py:997, 1100):
+ * frames[i] / out[i] point to frame i, H*W*3 bytes each.  mf_warp_u8c3_host is this with frames[i] = frames + i*H*W*3.
+ * Both move the clip in chunks of 16 frames on three upload and three download threads with their own HIP streams; a
+ * chunk is warped as soon as it has landed and travels back while later chunks are still going up (pageable memory is
+ * fine; memory from mf_malloc_host makes the copies truly asynchronous).  Device buffers and streams are kept between
+ * calls (grow-only, one cache per process, calls are serialised); mf_host_cache_release() frees them. */
+int mf_warp_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* out, const double* unstab, const double* stab,
+                             int n, int W, int H, int R, int C, const uint8_t border_bgr[3],
+                             int32_t* crop /* [n][4] */, float* kernel_ms);
+int mf_host_cache_release(void);
+
+/* ---- multi-GPU exchange steps, on RCCL directly: ONE process drives the GPUs 0..ndev-1 of a node ----
+ * The path shards by contiguous frame range: every GPU warps its own frames (mf_warp_u8c3 on that device) after a replicated
+ * mf_jacobi_f64; these are the only two exchanges.  librccl is opened with dlopen at mf_comm_init_all (error -2 when the
+ * box has none).  RCCL errors come back as -1000 - ncclResult_t.  All three calls are synchronous; the device buffers
+ * handed in must be complete (mf_stream_synchronize the streams that wrote them first).
+ *   mf_comm_init_all(ndev)   ncclCommInitAll over devices 0..ndev-1 (rccl.h:236) + one stream per device
+ *   mf_allreduce_crop        d_bounds[g]: {left, top, right, bottom} int32 on device g (that shard's mf_crop_reduce result);
+ *                            afterwards every device holds the clip-level rectangle {max, max, min, min} (mfs.py:1103-1106):
+ *                            16 bytes, one grouped call (ncclAllReduce max on the first pair, min on the second)
+ *   mf_gather_frames         d_shards[g] (shard_bytes[g] bytes on device g, the stabilized frames of rank g's frame range) ->
+ *                            d_dst on device `root`, back to back in rank order: one group of ncclSend / ncclRecv with
+ *                            per-rank byte counts (shards are ragged when ndev does not divide the frame count)
+ *   mf_comm_destroy          frees the communicators and streams */
+int mf_comm_init_all(int ndev);
+int mf_comm_size(int* ndev);
+int mf_allreduce_crop(int32_t* const* d_bounds);
+int mf_gather_frames(const uint8_t* const* d_shards, const size_t* shard_bytes, uint8_t* d_dst, int root);
+int mf_comm_destroy(void);
 
 #ifdef __cplusplus
 }

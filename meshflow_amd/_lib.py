@@ -46,6 +46,13 @@ SIGNATURES = {
     'mf_selftest_recip': (_i, [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     'mf_jacobi_f64_host': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_float)]),
     'mf_warp_u8c3_host': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    'mf_warp_u8c3_host_frames': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    'mf_host_cache_release': (_i, []),
+    'mf_comm_init_all': (_i, [_i]),
+    'mf_comm_size': (_i, [ctypes.POINTER(_i)]),
+    'mf_allreduce_crop': (_i, [_vp]),
+    'mf_gather_frames': (_i, [_vp, _vp, _vp, _i]),
+    'mf_comm_destroy': (_i, []),
 }
 
 

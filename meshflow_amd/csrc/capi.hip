@@ -220,46 +220,4 @@ int mf_jacobi_f64_host(const double* b, double* x, const double* taps, const dou
     return MF_OK;
 }
 
-int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab, const double* stab,
-                      int n, int W, int H, int R, int C, const uint8_t border_bgr[3], int32_t* crop,
-                      float* kernel_ms)
-{
-    if (!frames || !out || !unstab || !stab || !border_bgr || !crop) { set_error("mf_warp_u8c3_host: null pointer"); return MF_ERR_INVALID_ARG; }
-    if (n <= 0 || W < 2 || H < 2 || R <= 0 || C <= 0) { set_error("mf_warp_u8c3_host: bad sizes"); return MF_ERR_INVALID_ARG; }
-    const size_t fb = (size_t)n * W * H * 3;
-    const size_t vb = (size_t)n * (R + 1) * (C + 1) * 2 * sizeof(double);
-    DevBuf dfr, dout, du, ds, dtab, dcrop, dstat;
-    Stream st; Event e0, e1;
-    MF_HIP_TRY(hipStreamCreate(&st.s));
-    MF_HIP_TRY(hipEventCreate(&e0.e));
-    MF_HIP_TRY(hipEventCreate(&e1.e));
-    MF_HIP_TRY(dfr.alloc(fb)); MF_HIP_TRY(dout.alloc(fb));
-    MF_HIP_TRY(du.alloc(vb)); MF_HIP_TRY(ds.alloc(vb));
-    MF_HIP_TRY(dtab.alloc(mf_cell_table_bytes(n, W, H, R, C)));
-    MF_HIP_TRY(dcrop.alloc((size_t)n * 4 * sizeof(int32_t)));
-    MF_HIP_TRY(dstat.alloc(sizeof(int32_t)));
-    MF_HIP_TRY(hipMemsetAsync(dstat.p, 0, sizeof(int32_t), st.s));
-    MF_HIP_TRY(hipMemcpyAsync(dfr.p, frames, fb, hipMemcpyHostToDevice, st.s));
-    MF_HIP_TRY(hipMemcpyAsync(du.p, unstab, vb, hipMemcpyHostToDevice, st.s));
-    MF_HIP_TRY(hipMemcpyAsync(ds.p, stab, vb, hipMemcpyHostToDevice, st.s));
-    MF_HIP_TRY(hipEventRecord(e0.e, st.s));
-    int rc = mf_cell_table_f64((const double*)du.p, (const double*)ds.p, n, W, H, R, C, dtab.p, (int32_t*)dcrop.p,
-                               (int32_t*)dstat.p, st.s);
-    if (rc != MF_OK) return rc;
-    rc = mf_warp_u8c3((const uint8_t*)dfr.p, (uint8_t*)dout.p, dtab.p, n, W, H, R, C, border_bgr, (int32_t*)dcrop.p, st.s);
-    if (rc != MF_OK) return rc;
-    MF_HIP_TRY(hipEventRecord(e1.e, st.s));
-    int32_t status = 0;
-    MF_HIP_TRY(hipMemcpyAsync(out, dout.p, fb, hipMemcpyDeviceToHost, st.s));
-    MF_HIP_TRY(hipMemcpyAsync(crop, dcrop.p, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st.s));
-    MF_HIP_TRY(hipMemcpyAsync(&status, dstat.p, sizeof(int32_t), hipMemcpyDeviceToHost, st.s));
-    MF_HIP_TRY(hipStreamSynchronize(st.s));
-    if (kernel_ms) MF_HIP_TRY(hipEventElapsedTime(kernel_ms, e0.e, e1.e));
-    if (status != 0) {
-        set_error("mf_warp_u8c3_host: %d degenerate mesh cell(s): no homography exists (cv2.findHomography would return None)", status);
-        return MF_ERR_DEGENERATE;
-    }
-    return MF_OK;
-}
-
 }  // extern "C"

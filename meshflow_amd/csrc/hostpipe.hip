@@ -1,0 +1,262 @@
+// Host-buffer entry points of the warp (what a ctypes stub inside the reference's
+// _get_stabilized_frames_and_crop_boundaries, mfs.py:909-1108, calls): frames in host memory in, stabilized frames in host
+// memory out, with the PCIe transfers chunked and overlapped with each other and with the kernels.
+//
+// The clip moves in chunks of MF_PIPE_CHUNK frames.  UP host threads each own a HIP stream and copy "their" chunks up
+// (pageable memory is fine: the runtime stages it; pinned memory -- mf_malloc_host -- makes the copies truly asynchronous);
+// the calling thread waits for chunk k's upload event, launches the cell table + warp of that chunk on the compute stream
+// and records an event; DOWN host threads wait for it on their own streams and copy the stabilized chunk back, while
+// later chunks are still going up.  PCIe carries both directions at once and the kernels disappear behind the copies
+// (the same scheme as meshflow_amd/pipeline.py, below Python).  Device buffers, streams and the per-chunk cell table are
+// kept between calls (grow-only cache, one per process, serialised by a mutex; mf_host_cache_release frees it).
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "mf_common.h"
+
+namespace mf {
+namespace {
+
+constexpr int PIPE_CHUNK = 16;     // frames per chunk (100 MB at 1080p)
+constexpr int PIPE_UP = 3;         // upload threads / streams
+constexpr int PIPE_DOWN = 3;       // download threads / streams
+
+struct Grow {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct PipeCache {
+    std::mutex lock;
+    int device = -1;
+    Grow frames, out, table, unstab, stab, crop, status;
+    hipStream_t compute = nullptr, up[PIPE_UP] = {}, down[PIPE_DOWN] = {};
+    void release()
+    {
+        frames.release(); out.release(); table.release(); unstab.release(); stab.release(); crop.release(); status.release();
+        if (compute) (void)hipStreamDestroy(compute);
+        for (auto& s : up) { if (s) (void)hipStreamDestroy(s); s = nullptr; }
+        for (auto& s : down) { if (s) (void)hipStreamDestroy(s); s = nullptr; }
+        compute = nullptr;
+        device = -1;
+    }
+};
+PipeCache g_pipe;
+
+struct Shared {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<char> up_ready, warp_ready;
+    hipError_t err = hipSuccess;
+    const char* what = "";
+    bool abort = false;
+    void fail(hipError_t e, const char* w)
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (err == hipSuccess) { err = e; what = w; }
+        abort = true;
+        cv.notify_all();
+    }
+    void mark(std::vector<char>& v, int k)
+    {
+        { std::lock_guard<std::mutex> g(m); v[k] = 1; }
+        cv.notify_all();
+    }
+    bool wait(std::vector<char>& v, int k)               // false: another thread failed
+    {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] { return v[k] || abort; });
+        return v[k] && !abort;
+    }
+};
+
+// frames i0..i1-1 between host pointers and the device stack, as few copies as the host layout allows
+hipError_t copy_frames(uint8_t* dev, const uint8_t* const* host, int i0, int i1, size_t fb, bool to_device, hipStream_t st)
+{
+    int i = i0;
+    while (i < i1) {
+        int j = i + 1;
+        while (j < i1 && host[j] == host[j - 1] + fb) ++j;            // run of frames contiguous in host memory
+        const size_t bytes = (size_t)(j - i) * fb;
+        hipError_t e = to_device ? hipMemcpyAsync(dev + (size_t)i * fb, host[i], bytes, hipMemcpyHostToDevice, st)
+                                 : hipMemcpyAsync(const_cast<uint8_t*>(host[i]), dev + (size_t)i * fb, bytes, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return e;
+        i = j;
+    }
+    return hipSuccess;
+}
+
+}  // namespace
+
+int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, const double* unstab, const double* stab, int n, int W,
+                     int H, int R, int C, const uint8_t border_bgr[3], int32_t* crop, float* kernel_ms)
+{
+    std::lock_guard<std::mutex> cache_guard(g_pipe.lock);
+    PipeCache& pc = g_pipe;
+    int dev = 0;
+    MF_HIP_TRY(hipGetDevice(&dev));
+    if (pc.device != dev) {
+        if (pc.device >= 0) { int keep = dev; (void)hipSetDevice(pc.device); pc.release(); (void)hipSetDevice(keep); }
+        pc.device = dev;
+        MF_HIP_TRY(hipStreamCreateWithFlags(&pc.compute, hipStreamNonBlocking));
+        for (auto& s : pc.up) MF_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        for (auto& s : pc.down) MF_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
+    const size_t fb = (size_t)W * H * 3;
+    const size_t vb1 = (size_t)(R + 1) * (C + 1) * 2 * sizeof(double);        // vertex displacements of one frame
+    const int chunk = n < PIPE_CHUNK ? n : PIPE_CHUNK;
+    const int nchunks = (n + chunk - 1) / chunk;
+    MF_HIP_TRY(pc.frames.need(fb * n)); MF_HIP_TRY(pc.out.need(fb * n));
+    MF_HIP_TRY(pc.unstab.need(vb1 * n)); MF_HIP_TRY(pc.stab.need(vb1 * n));
+    MF_HIP_TRY(pc.table.need(table_bytes(chunk, W, H, R, C)));
+    MF_HIP_TRY(pc.crop.need((size_t)n * 4 * sizeof(int32_t)));
+    MF_HIP_TRY(pc.status.need(sizeof(int32_t)));
+    uint8_t* d_frames = (uint8_t*)pc.frames.p;
+    uint8_t* d_out = (uint8_t*)pc.out.p;
+    int32_t* d_crop = (int32_t*)pc.crop.p;
+
+    std::vector<hipEvent_t> up_done(nchunks, nullptr), warp_done(nchunks, nullptr), t0(nchunks, nullptr), t1(nchunks, nullptr);
+    struct EventGuard {
+        std::vector<hipEvent_t>* v[4];
+        ~EventGuard() { for (auto* vec : v) for (hipEvent_t e : *vec) if (e) (void)hipEventDestroy(e); }
+    } guard{{&up_done, &warp_done, &t0, &t1}};
+    for (int k = 0; k < nchunks; ++k) {
+        MF_HIP_TRY(hipEventCreateWithFlags(&up_done[k], hipEventDisableTiming));
+        MF_HIP_TRY(hipEventCreateWithFlags(&warp_done[k], hipEventDisableTiming));
+        if (kernel_ms) { MF_HIP_TRY(hipEventCreate(&t0[k])); MF_HIP_TRY(hipEventCreate(&t1[k])); }
+    }
+
+    Shared sh;
+    sh.up_ready.assign(nchunks, 0);
+    sh.warp_ready.assign(nchunks, 0);
+    std::vector<std::thread> workers;
+    const int n_up = nchunks < PIPE_UP ? nchunks : PIPE_UP, n_down = nchunks < PIPE_DOWN ? nchunks : PIPE_DOWN;
+    for (int t = 0; t < n_up; ++t)
+        workers.emplace_back([&, t] {
+            if (hipSetDevice(dev) != hipSuccess) { sh.fail(hipErrorInvalidDevice, "hipSetDevice (upload thread)"); return; }
+            for (int k = t; k < nchunks; k += n_up) {
+                const int i0 = k * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+                hipError_t e = copy_frames(d_frames, frames, i0, i1, fb, true, pc.up[t]);
+                if (e == hipSuccess) e = hipEventRecord(up_done[k], pc.up[t]);
+                if (e != hipSuccess) { sh.fail(e, "upload of a frame chunk"); return; }
+                sh.mark(sh.up_ready, k);
+                { std::lock_guard<std::mutex> g(sh.m); if (sh.abort) return; }
+            }
+        });
+    for (int t = 0; t < n_down; ++t)
+        workers.emplace_back([&, t] {
+            if (hipSetDevice(dev) != hipSuccess) { sh.fail(hipErrorInvalidDevice, "hipSetDevice (download thread)"); return; }
+            for (int k = t; k < nchunks; k += n_down) {
+                if (!sh.wait(sh.warp_ready, k)) return;
+                const int i0 = k * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+                hipError_t e = hipStreamWaitEvent(pc.down[t], warp_done[k], 0);
+                if (e == hipSuccess) e = copy_frames(d_out, out, i0, i1, fb, false, pc.down[t]);
+                if (e != hipSuccess) { sh.fail(e, "download of a frame chunk"); return; }
+            }
+            hipError_t e = hipStreamSynchronize(pc.down[t]);
+            if (e != hipSuccess) sh.fail(e, "hipStreamSynchronize (download stream)");
+        });
+
+    // the calling thread: vertex paths up, then the kernels of every chunk as soon as its frames have landed
+    int rc = MF_OK;
+    const uint32_t border = (uint32_t)border_bgr[0] | ((uint32_t)border_bgr[1] << 8) | ((uint32_t)border_bgr[2] << 16);
+    hipError_t e = hipMemsetAsync(pc.status.p, 0, sizeof(int32_t), pc.compute);
+    if (e == hipSuccess) e = hipMemcpyAsync(pc.unstab.p, unstab, vb1 * n, hipMemcpyHostToDevice, pc.compute);
+    if (e == hipSuccess) e = hipMemcpyAsync(pc.stab.p, stab, vb1 * n, hipMemcpyHostToDevice, pc.compute);
+    if (e != hipSuccess) { sh.fail(e, "upload of the vertex displacements"); }
+    for (int k = 0; k < nchunks && e == hipSuccess && rc == MF_OK; ++k) {
+        if (!sh.wait(sh.up_ready, k)) break;
+        const int i0 = k * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n, m = i1 - i0;
+        e = hipStreamWaitEvent(pc.compute, up_done[k], 0);
+        if (e != hipSuccess) { sh.fail(e, "hipStreamWaitEvent"); break; }
+        if (kernel_ms) (void)hipEventRecord(t0[k], pc.compute);
+        const TableView tv = table_view(pc.table.p, m, W, H, R, C);
+        rc = launch_cell_table((const double*)((const char*)pc.unstab.p + vb1 * i0), (const double*)((const char*)pc.stab.p + vb1 * i0), m,
+                               W, H, R, C, tv, d_crop + 4 * (size_t)i0, (int32_t*)pc.status.p, pc.compute);
+        if (rc == MF_OK) rc = launch_warp(d_frames + fb * i0, d_out + fb * i0, tv, m, W, H, R, C, border, d_crop + 4 * (size_t)i0, pc.compute);
+        if (rc != MF_OK) { sh.fail(hipErrorUnknown, "kernel launch"); break; }
+        if (kernel_ms) (void)hipEventRecord(t1[k], pc.compute);
+        e = hipEventRecord(warp_done[k], pc.compute);
+        if (e != hipSuccess) { sh.fail(e, "hipEventRecord"); break; }
+        sh.mark(sh.warp_ready, k);
+    }
+    int32_t status = 0;
+    if (!sh.abort) {
+        e = hipMemcpyAsync(crop, d_crop, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute);
+        if (e == hipSuccess) e = hipMemcpyAsync(&status, pc.status.p, sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute);
+        if (e == hipSuccess) e = hipStreamSynchronize(pc.compute);
+        if (e != hipSuccess) sh.fail(e, "download of the crop values");
+    }
+    for (auto& w : workers) w.join();
+    if (sh.abort) {
+        (void)hipDeviceSynchronize();
+        if (rc != MF_OK) return rc;                        // launch_* already set the message
+        return hip_fail(sh.err, sh.what);
+    }
+    if (kernel_ms) {
+        float total = 0.0f;
+        for (int k = 0; k < nchunks; ++k) { float ms = 0.0f; MF_HIP_TRY(hipEventElapsedTime(&ms, t0[k], t1[k])); total += ms; }
+        *kernel_ms = total;
+    }
+    if (status != 0) {
+        set_error("mf_warp_u8c3_host: %d degenerate mesh cell(s): no homography exists (cv2.findHomography would return None)", status);
+        return MF_ERR_DEGENERATE;
+    }
+    return MF_OK;
+}
+
+}  // namespace mf
+
+using namespace mf;
+
+extern "C" {
+
+int mf_warp_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* out, const double* unstab, const double* stab, int n,
+                             int W, int H, int R, int C, const uint8_t border_bgr[3], int32_t* crop, float* kernel_ms)
+{
+    if (!frames || !out || !unstab || !stab || !border_bgr || !crop) { set_error("mf_warp_u8c3_host_frames: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (n <= 0 || W < 2 || H < 2 || R <= 0 || C <= 0) { set_error("mf_warp_u8c3_host_frames: bad sizes"); return MF_ERR_INVALID_ARG; }
+    for (int i = 0; i < n; ++i)
+        if (!frames[i] || !out[i]) { set_error("mf_warp_u8c3_host_frames: null frame pointer %d", i); return MF_ERR_INVALID_ARG; }
+    return warp_host_frames(frames, out, unstab, stab, n, W, H, R, C, border_bgr, crop, kernel_ms);
+}
+
+int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab, const double* stab,
+                      int n, int W, int H, int R, int C, const uint8_t border_bgr[3], int32_t* crop,
+                      float* kernel_ms)
+{
+    if (!frames || !out || !unstab || !stab || !border_bgr || !crop) { set_error("mf_warp_u8c3_host: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (n <= 0 || W < 2 || H < 2 || R <= 0 || C <= 0) { set_error("mf_warp_u8c3_host: bad sizes"); return MF_ERR_INVALID_ARG; }
+    const size_t fb = (size_t)W * H * 3;
+    std::vector<const uint8_t*> in(n);
+    std::vector<uint8_t*> outp(n);
+    for (int i = 0; i < n; ++i) { in[i] = frames + fb * i; outp[i] = out + fb * i; }
+    return warp_host_frames(in.data(), outp.data(), unstab, stab, n, W, H, R, C, border_bgr, crop, kernel_ms);
+}
+
+int mf_host_cache_release(void)
+{
+    std::lock_guard<std::mutex> g(g_pipe.lock);
+    if (g_pipe.device >= 0) {
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(g_pipe.device);
+        (void)hipDeviceSynchronize();
+        g_pipe.release();
+        (void)hipSetDevice(prev);
+    }
+    return MF_OK;
+}
+
+}  // extern "C"
