@@ -65,7 +65,7 @@ CFG3 = dict(F=600, H=1080, W=1920, R=32, C=32, omega=30, iters=200)
 
 @pytest.fixture(scope='module')
 def cfg3(dev):
-    """Config-3 motion and its smoothed paths (HIP Jacobi: bit-identical to the C oracle, test_gpu_parity.py)."""
+    """Config-3 motion and its smoothed paths (HIP Jacobi)."""
     from meshflow_amd import synthetic
     from meshflow_amd.stabilizer import MeshFlowStabilizer
     c = CFG3
@@ -85,11 +85,12 @@ def test_cfg3_warp_frames_vs_c_oracle(dev, cfg3, kind):
     c = CFG3
     s, disp, hom, d_disp, d_stab = cfg3
     stab = d_stab.cpu().numpy()
-    # the smoothed paths themselves: the C oracle's banded Jacobi, same bits
+    # the smoothed paths themselves against the C oracle's banded Jacobi (the product's O(F) coefficient set-up differs from
+    # the oracle's by float64 rounding, so this is a tolerance; the kernel alone is bit-identical: test_gpu_parity.py)
     from oracle import meshflow_oracle as mo
     taps, lam, on = mo.jacobi_band_coefficients(c['F'], c['W'], c['H'], 0, hom, c['omega'])
     want_stab = clib.jacobi_banded(disp.reshape(c['F'], -1), taps, lam, np.reciprocal(on), c['omega'], c['iters'], openmp=True)
-    np.testing.assert_array_equal(stab.reshape(c['F'], -1), want_stab)
+    assert np.abs(stab.reshape(c['F'], -1) - want_stab).max() <= 1e-9 * max(1.0, np.abs(want_stab).max())
     sel = [0, 201, 418, 599]
     frames = np.concatenate([synthetic.frames_numpy(1, c['H'], c['W'], seed=0, kind=kind, first_frame=f) for f in sel])
     d_fr = torch.from_numpy(frames).to(dev)
