@@ -9,6 +9,8 @@
 // later chunks are still going up.  PCIe carries both directions at once and the kernels disappear behind the copies
 // (the same scheme as meshflow_amd/pipeline.py, below Python).  Device buffers, streams and the per-chunk cell table are
 // kept between calls (grow-only cache, one per process, serialised by a mutex; mf_host_cache_release frees it).
+#include <stdlib.h>
+
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -22,6 +24,15 @@ namespace {
 constexpr int PIPE_CHUNK = 16;     // frames per chunk (100 MB at 1080p)
 constexpr int PIPE_UP = 3;         // upload threads / streams
 constexpr int PIPE_DOWN = 3;       // download threads / streams
+constexpr int PIPE_MAX = 8;        // upper bound on either thread count (MF_PIPE_UP / MF_PIPE_DOWN / MF_PIPE_CHUNK tune them)
+
+int env_int(const char* name, int fallback, int lo, int hi)
+{
+    const char* v = getenv(name);
+    if (!v || !*v) return fallback;
+    const int x = atoi(v);
+    return x < lo ? lo : (x > hi ? hi : x);
+}
 
 struct Grow {
     void* p = nullptr;
@@ -41,7 +52,7 @@ struct PipeCache {
     std::mutex lock;
     int device = -1;
     Grow frames, out, table, unstab, stab, crop, status;
-    hipStream_t compute = nullptr, up[PIPE_UP] = {}, down[PIPE_DOWN] = {};
+    hipStream_t compute = nullptr, up[PIPE_MAX] = {}, down[PIPE_MAX] = {};
     void release()
     {
         frames.release(); out.release(); table.release(); unstab.release(); stab.release(); crop.release(); status.release();
@@ -115,7 +126,9 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, const do
     }
     const size_t fb = (size_t)W * H * 3;
     const size_t vb1 = (size_t)(R + 1) * (C + 1) * 2 * sizeof(double);        // vertex displacements of one frame
-    const int chunk = n < PIPE_CHUNK ? n : PIPE_CHUNK;
+    static const int cfg_chunk = env_int("MF_PIPE_CHUNK", PIPE_CHUNK, 1, 4096), cfg_up = env_int("MF_PIPE_UP", PIPE_UP, 1, PIPE_MAX),
+                     cfg_down = env_int("MF_PIPE_DOWN", PIPE_DOWN, 1, PIPE_MAX);
+    const int chunk = n < cfg_chunk ? n : cfg_chunk;
     const int nchunks = (n + chunk - 1) / chunk;
     MF_HIP_TRY(pc.frames.need(fb * n)); MF_HIP_TRY(pc.out.need(fb * n));
     MF_HIP_TRY(pc.unstab.need(vb1 * n)); MF_HIP_TRY(pc.stab.need(vb1 * n));
@@ -141,7 +154,7 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, const do
     sh.up_ready.assign(nchunks, 0);
     sh.warp_ready.assign(nchunks, 0);
     std::vector<std::thread> workers;
-    const int n_up = nchunks < PIPE_UP ? nchunks : PIPE_UP, n_down = nchunks < PIPE_DOWN ? nchunks : PIPE_DOWN;
+    const int n_up = nchunks < cfg_up ? nchunks : cfg_up, n_down = nchunks < cfg_down ? nchunks : cfg_down;
     for (int t = 0; t < n_up; ++t)
         workers.emplace_back([&, t] {
             if (hipSetDevice(dev) != hipSuccess) { sh.fail(hipErrorInvalidDevice, "hipSetDevice (upload thread)"); return; }

@@ -51,6 +51,16 @@ constexpr int FOOT_H = MF_FOOT_H;   // 64 lanes / 8
 constexpr int FOOTS = 1;        // footprints per wavefront (1 measured best: 1.83 ms vs 2.01 at 2, 1.95 at 4)
 constexpr int TILE_H = FOOT_H * FOOTS;
 constexpr int MAX_MESH = 64;    // R, C <= 64
+#ifdef MF_EXP_STAGE256
+// LDS image of the staged window: 12 rows of 256 bytes.  Lane l fetches chunk (l & 15) of rows (l >> 4), (l >> 4) + 4, (l >> 4) + 8
+// (three global->LDS loads whose LDS destination is lane-linear, i.e. 16 slots per row; lanes with (l & 15) >= 10 are masked
+// off: the window is 10 chunks wide) -- row and column are a shift and a mask instead of a division by 10.
+constexpr int LDS_PITCH = 256;
+constexpr int LDS_WINDOW_BYTES = MF_STAGE_ROWS * LDS_PITCH;
+#else
+constexpr int LDS_PITCH = MF_STAGE_PITCH;
+constexpr int LDS_WINDOW_BYTES = MF_STAGE_CHUNKS * 16;
+#endif
 
 // a * b + c on the 24-bit multiplier.  The empty asm makes `c` opaque so that the compiler keeps two chained
 // v_mad_u32_u24 instead of re-associating them into mul + mul + add3 (no instruction is emitted by it, so the
@@ -120,6 +130,23 @@ __device__ __forceinline__ double recip_unit_range(double w)
     return __builtin_fma(e, r, r);
 }
 
+#ifdef MF_EXP_RECIP
+// 1/w for the lane's pixels 1..3 from pixel 0's reciprocal r0: w_j = w_0 + j h6 (up to rounding), so
+// 1/w_j = r0 (1 - e + e^2 - ...), e = j h6 r0.  The second-order guess r0 - j c1 + j^2 c2 (c1 = h6 r0^2, c2 = h6^2 r0^3) is within
+// e^3 of 1/w_j; one Newton step squares that, and the same residual-correction step as recip_unit_range rounds correctly.
+__device__ __forceinline__ double recip_guess(double r0, double c1, double c2, double j)
+{
+    return __builtin_fma(j * j, c2, __builtin_fma(-j, c1, r0));
+}
+__device__ __forceinline__ double recip_from_guess(double w, double r)
+{
+    double e = __builtin_fma(-w, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-w, r, 1.0);
+    return __builtin_fma(e, r, r);
+}
+#endif
+
 // Source coordinates of the lane's four pixels under cell `rec`'s inverse homography:
 // cv2.perspectiveTransform (matmul.simd.hpp) -- float32 point, float64 matrix, float32 result.
 // SELECT = false: every pixel takes the new coordinates; true: only those in `pass`.
@@ -132,6 +159,9 @@ __device__ __forceinline__ void cell_coords(const double* __restrict__ rec, doub
     for (int i = 0; i < 9; ++i) Hi[i] = rec[MF_CELL_OFF_HI + i];
     const double t6 = yy * Hi[7], t0 = yy * Hi[1], t3 = yy * Hi[4];
     double w4[4];
+#ifdef MF_EXP_RECIP
+    double iw0 = 0.0, c1 = 0.0, c2 = 0.0;
+#endif
     uint32_t eor = 0;                                          // |w| in [0.5, 2) <=> frexp exponent in {0, 1}
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -139,11 +169,20 @@ __device__ __forceinline__ void cell_coords(const double* __restrict__ rec, doub
         w4[j] = (xs * Hi[6] + t6) + Hi[8];
         eor |= (uint32_t)__builtin_amdgcn_frexp_exp(w4[j]);
     }
+#ifdef MF_EXP_NOEXP
+    if (true) {
+#else
     if (__ballot(eor > 1u) == 0) {
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const double xs = xs0 + (double)j;
+#ifdef MF_EXP_RECIP
+            const double iw = j == 0 ? recip_unit_range(w4[0]) : recip_from_guess(w4[j], recip_guess(iw0, c1, c2, (double)j));
+            if (j == 0) { iw0 = iw; c1 = Hi[6] * (iw * iw); c2 = (Hi[6] * c1) * iw; }
+#else
             const double iw = recip_unit_range(w4[j]);
+#endif
             const float un = (float)(((xs * Hi[0] + t0) + Hi[2]) * iw);
             const float vn = (float)(((xs * Hi[3] + t3) + Hi[5]) * iw);
             if (SELECT) {
@@ -230,7 +269,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
     __shared__ __attribute__((aligned(16))) double s_hi[4][8][10];
     // source region of the footprint, per wavefront: MF_STAGE_ROWS rows of MF_STAGE_PITCH bytes (+ slack for the
     // third dword of the last tap)
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[4][MF_STAGE_CHUNKS * 16 + 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[4][LDS_WINDOW_BYTES + 64];
     // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2: with the
     // natural order the four neighbours of a tile -- whose staged source windows overlap this tile's by 60 % -- would
     // all run on other XCDs and each L2 would fetch the shared rows again.  Workgroup L therefore takes tile
@@ -281,6 +320,20 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
             const uint8_t* __restrict__ gbase = src + (size_t)sy0 * row_bytes + bs;
             // chunk i sits at row i / 10, byte 16 (i % 10) of the window = byte (i / 10) (row_bytes - 160) + 16 i from gbase;
             // uniform base + opaque 32-bit lane offset keeps the address arithmetic 32-bit (saddr + voffset form)
+#ifdef MF_EXP_STAGE256
+            uint32_t o0 = __umul24((uint32_t)lane >> 4, row_bytes) + (((uint32_t)lane & 15u) << 4);
+            asm("" : "+v"(o0));
+            if (((uint32_t)lane & 15u) < (uint32_t)(MF_STAGE_PITCH / 16)) {
+                const uint8_t* __restrict__ g1 = gbase + 4u * row_bytes;
+                const uint8_t* __restrict__ g2 = gbase + 8u * row_bytes;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o0),
+                                                 (__attribute__((address_space(3))) void*)&s_src[wave][0], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g1 + o0),
+                                                 (__attribute__((address_space(3))) void*)&s_src[wave][1024], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g2 + o0),
+                                                 (__attribute__((address_space(3))) void*)&s_src[wave][2048], 16, 0, 0);
+            }
+#else
             uint32_t o0 = __umul24(((uint32_t)lane * 205u) >> 11, row_bytes - (uint32_t)MF_STAGE_PITCH) + ((uint32_t)lane << 4);
             uint32_t o1 = __umul24((((uint32_t)lane + 64u) * 205u) >> 11, row_bytes - (uint32_t)MF_STAGE_PITCH) +
                           (((uint32_t)lane << 4) + 1024u);
@@ -290,7 +343,11 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                                              (__attribute__((address_space(3))) void*)&s_src[wave][0], 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o1),
                                              (__attribute__((address_space(3))) void*)&s_src[wave][1024], 16, 0, 0);
-            lds_origin = sy0 * (uint32_t)MF_STAGE_PITCH + bs;
+#endif
+            lds_origin = sy0 * (uint32_t)LDS_PITCH + bs;
+#ifdef MF_EXP_LDSBASE
+            lds_origin -= (uint32_t)(uintptr_t)&s_src[wave][0];       // taps are addressed by absolute LDS byte address
+#endif
         }
 
         // Source coordinates of the lane's 4 pixels; (W+1, H+1) = "no cell covers it" (mfs.py:983-984).
@@ -525,11 +582,15 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 // shifted down by the byte misalignment (v_alignbyte takes the low two bits of the address)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const uint32_t at = umad24(__builtin_amdgcn_ubfe(by[j], 5, 17), (uint32_t)MF_STAGE_PITCH,
+                    const uint32_t at = umad24(__builtin_amdgcn_ubfe(by[j], 5, 17), (uint32_t)LDS_PITCH,
                                                umad24(__builtin_amdgcn_ubfe(bx[j], 5, 17), 3u, 0u - lds_origin));
+#ifdef MF_EXP_LDSBASE
+                    const uint32_t* __restrict__ p = (const uint32_t*)(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(at & ~3u);
+#else
                     const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(&s_src[wave][at & ~3u]);
+#endif
                     const uint32_t t0 = p[0], t1 = p[1], t2 = p[2];
-                    const uint32_t u0 = p[MF_STAGE_PITCH / 4], u1 = p[MF_STAGE_PITCH / 4 + 1], u2 = p[MF_STAGE_PITCH / 4 + 2];
+                    const uint32_t u0 = p[LDS_PITCH / 4], u1 = p[LDS_PITCH / 4 + 1], u2 = p[LDS_PITCH / 4 + 2];
                     a[j].x = __builtin_amdgcn_alignbyte(t1, t0, at);
                     a[j].y = __builtin_amdgcn_alignbyte(t2, t1, at);
                     b[j].x = __builtin_amdgcn_alignbyte(u1, u0, at);
@@ -551,10 +612,17 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
             for (int j = 0; j < 4; ++j) {
                 // a[j].x = B0 G0 R0 B1, a[j].y = G1 R1 . .   (pixel ix, pixel ix+1 of row iy; b: row iy+1)
                 const uint32_t fx = bx[j] & 31u;
+#ifdef MF_EXP_WMAD
+                // (32 - fx) | fx << 24 = 32 + fx (2^24 - 1), etc.: one v_mad_u32_u24 each
+                const uint32_t wb = umad24(fx, 0xFFFFFFu, 32u);
+                const uint32_t wg = umad24(fx, 255u, 32u);
+                const uint32_t wr = umad24(fx, 0xFF0000u, 0x200000u);
+#else
                 const uint32_t w0 = 32u - fx;
                 const uint32_t wb = w0 | (fx << 24);          // weights on bytes 0 and 3 of .x  (B0, B1)
                 const uint32_t wg = w0 | (fx << 8);           // weights on bytes 0, 1 of the permuted dword (G0, G1)
                 const uint32_t wr = wg << 16;                 // weights on bytes 2, 3 (R0, R1)
+#endif
                 const uint32_t pa = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x05020401u);   // G0 G1 R0 R1
                 const uint32_t pb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x05020401u);
                 // horizontal lerps (<= 255*32), v_dot4_u32_u8

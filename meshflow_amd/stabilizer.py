@@ -23,6 +23,31 @@ except Exception:  # pragma: no cover
     _tqdm = None
 
 
+def _warp_host_c(self, clip, unstab, stab):
+    """Host frames in -> host frames out through the C ABI's own chunked pipeline (csrc/hostpipe.hip:
+    `mf_warp_u8c3_host_frames`, upload / kernel / download threads below Python, GIL released for the whole call).
+    Returns (stabilized frames (F, H, W, 3) uint8 array, clip-level crop bounds as np.int64 (left, top, right,
+    bottom), mfs.py:1103-1106)."""
+    import ctypes
+    from . import _lib, pipeline
+    dev = self._torch_device()
+    n, H, W = clip.num_frames, clip.height, clip.width
+    frames = [clip.array[i] for i in range(n)] if clip.array is not None else \
+        [pipeline._as_frame(f, H, W) for f in clip.frames]
+    out = np.empty((n, H, W, 3), dtype=np.uint8)
+    fb = H * W * 3
+    pin = (ctypes.c_void_p * n)(*[f.ctypes.data for f in frames])
+    pout = (ctypes.c_void_p * n)(*[out.ctypes.data + i * fb for i in range(n)])
+    crop = np.empty((n, 4), dtype=np.int32)
+    border = (ctypes.c_uint8 * 3)(*[int(max(0, min(255, round(float(c))))) for c in self.color_outside_image_area_bgr])
+    _lib.check(_lib.lib.mf_set_device(dev.index if dev.index is not None else 0))
+    _lib.check(_lib.lib.mf_warp_u8c3_host_frames(
+        pin, pout, unstab.ctypes.data_as(ctypes.c_void_p), stab.ctypes.data_as(ctypes.c_void_p), n, W, H,
+        self.mesh_row_count, self.mesh_col_count, border, crop.ctypes.data_as(ctypes.c_void_p), None))
+    bounds = (np.int64(crop[:, 0].max()), np.int64(crop[:, 1].max()), np.int64(crop[:, 2].min()), np.int64(crop[:, 3].min()))
+    return out, bounds
+
+
 class MeshFlowStabilizer:
     ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL = 0
     ADAPTIVE_WEIGHTS_DEFINITION_FLIPPED = 1
@@ -178,7 +203,7 @@ class MeshFlowStabilizer:
             d_stab = self._stabilized_vertex_displacements_device(torch.from_numpy(unstab).to(dev), W, H,
                                                                   adaptive_weights_definition, homographies)
             stab = d_stab.cpu().numpy()
-            out_host, bounds = self._warp_host_c(clip, unstab, stab)
+            out_host, bounds = _warp_host_c(self, clip, unstab, stab)
             return list(out_host), bounds, stab, self._compute_stability_score(num_frames, stab)
         io = pipeline.ChunkedTransfer(dev, io_threads, io_threads)
         try:
@@ -246,30 +271,6 @@ class MeshFlowStabilizer:
             table.check()
         return out_host, d_out, tuple(np.int64(v) for v in bounds_h)
 
-    def _warp_host_c(self, clip, unstab, stab):
-        """Host frames in -> host frames out through the C ABI's own chunked pipeline (csrc/hostpipe.hip:
-        `mf_warp_u8c3_host_frames`, upload / kernel / download threads below Python, GIL released for the whole call).
-        Returns (stabilized frames (F, H, W, 3) uint8 array, clip-level crop bounds as np.int64 (left, top, right,
-        bottom), mfs.py:1103-1106)."""
-        import ctypes
-        from . import _lib, pipeline
-        dev = self._torch_device()
-        n, H, W = clip.num_frames, clip.height, clip.width
-        frames = [clip.array[i] for i in range(n)] if clip.array is not None else \
-            [pipeline._as_frame(f, H, W) for f in clip.frames]
-        out = np.empty((n, H, W, 3), dtype=np.uint8)
-        fb = H * W * 3
-        pin = (ctypes.c_void_p * n)(*[f.ctypes.data for f in frames])
-        pout = (ctypes.c_void_p * n)(*[out.ctypes.data + i * fb for i in range(n)])
-        crop = np.empty((n, 4), dtype=np.int32)
-        border = (ctypes.c_uint8 * 3)(*[int(max(0, min(255, round(float(c))))) for c in self.color_outside_image_area_bgr])
-        _lib.check(_lib.lib.mf_set_device(dev.index if dev.index is not None else 0))
-        _lib.check(_lib.lib.mf_warp_u8c3_host_frames(
-            pin, pout, unstab.ctypes.data_as(ctypes.c_void_p), stab.ctypes.data_as(ctypes.c_void_p), n, W, H,
-            self.mesh_row_count, self.mesh_col_count, border, crop.ctypes.data_as(ctypes.c_void_p), None))
-        bounds = (np.int64(crop[:, 0].max()), np.int64(crop[:, 1].max()), np.int64(crop[:, 2].min()), np.int64(crop[:, 3].min()))
-        return out, bounds
-
     # ------------------------------------------------------------------------------------------
     # drop-in boundary, host buffers (same signatures as the reference)
     # ------------------------------------------------------------------------------------------
@@ -305,7 +306,7 @@ class MeshFlowStabilizer:
         self._check_mesh_shape(unstab, num_frames)
         self._check_mesh_shape(stab, num_frames)
         clip = pipeline.HostClip(unstabilized_frames, num_frames)
-        out_host, bounds = self._warp_host_c(clip, unstab, stab)
+        out_host, bounds = _warp_host_c(self, clip, unstab, stab)
         return list(out_host), bounds
 
     def _get_unstabilized_vertex_displacements_from_features(self, num_frames, frame_width, frame_height,

@@ -26,7 +26,7 @@ enum {
     FMA_F32, MUL_F32, ADD_F32, PK_FMA_F32, PK_MUL_F32, RNDNE_F32, CVT_I32_F32, CVT_F32_UBYTE, MAX_F32, MED3_F32,
     AND_B32, LSHL_B32, ADD_U32, BFE_U32, PERM_B32, ALIGNBYTE, MAD_U24, MUL_U24, DOT4_U8, DOT2_U16, LSHL_OR, AND_OR,
     CNDMASK, CMP_F32, MIN_U32, MAX3_U32, MUL_LO_U32, MAD_U64_U32, PK_MAD_U16, PK_MUL_LO_U16, MOV_B32, ADD3_U32, SAD_U8,
-    LSHL_ADD, XAD_U32, MAD_I32_I24, MBCNT,
+    LSHL_ADD, XAD_U32, MAD_I32_I24, MBCNT, OR_B32, XOR_B32, SUB_U32, CNDMASK_S, CMP_CND, FMAC_F32, SUB_F32, CVT_F32_U32, CVT_U32_F32, LSHR_B32, BFI_B32, MOV_DPP, ADD_CO, ADDC, MUL_HI_U32, MAD_U32_U16,
     DS_READ_B32, DS_READ_B64, DS_READ_B128, NOPS
 };
 
@@ -181,6 +181,55 @@ __device__ __forceinline__ void body(double (&d)[8], uint32_t (&i)[8], double ca
 #define A(k) "v_mbcnt_lo_u32_b32 %" #k ", %18, %" #k "\n"
     if (OP == MBCNT) asm volatile(I32(A) OPERANDS);
 #undef A
+
+#define A(k) "v_or_b32 %" #k ", %" #k ", %18\n"
+    if (OP == OR_B32) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_xor_b32 %" #k ", %" #k ", %18\n"
+    if (OP == XOR_B32) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_sub_u32 %" #k ", %" #k ", %18\n"
+    if (OP == SUB_U32) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_cndmask_b32 %" #k ", %" #k ", %18, s[20:21]\n"
+    if (OP == CNDMASK_S) asm volatile(I32(A) OPERANDS, "s20", "s21");
+#undef A
+#define A(k) "v_cmp_gt_u32 vcc, %" #k ", %18\n v_cndmask_b32 %" #k ", %" #k ", %19, vcc\n"
+    if (OP == CMP_CND) asm volatile(I8(A) I8(A) OPERANDS);
+#undef A
+#define A(k) "v_fmac_f32 %" #k ", %18, %19\n"
+    if (OP == FMAC_F32) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_sub_f32 %" #k ", %" #k ", %18\n"
+    if (OP == SUB_F32) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_cvt_f32_u32 %" #k ", %" #k "\n"
+    if (OP == CVT_F32_U32) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_cvt_u32_f32 %" #k ", %" #k "\n"
+    if (OP == CVT_U32_F32) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_lshrrev_b32 %" #k ", 1, %" #k "\n"
+    if (OP == LSHR_B32) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_bfi_b32 %" #k ", %" #k ", %18, %19\n"
+    if (OP == BFI_B32) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_mov_b32_dpp %" #k ", %" #k " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+    if (OP == MOV_DPP) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_add_co_u32 %" #k ", vcc, %" #k ", %18\n"
+    if (OP == ADD_CO) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_addc_co_u32 %" #k ", vcc, %" #k ", %18, vcc\n"
+    if (OP == ADDC) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_mul_hi_u32 %" #k ", %" #k ", %18\n"
+    if (OP == MUL_HI_U32) asm volatile(I32(A) OPERANDS);
+#undef A
+#define A(k) "v_mad_u32_u16 %" #k ", %" #k ", %18, %19\n"
+    if (OP == MAD_U32_U16) asm volatile(I32(A) OPERANDS);
+#undef A
     // ---- LDS reads: address in a VGPR, results into the accumulators, one wait per 8 ----
     if (OP == DS_READ_B32) {
         asm volatile("ds_read_b32 %8, %22\n ds_read_b32 %9, %22 offset:256\n ds_read_b32 %10, %22 offset:512\n ds_read_b32 %11, %22 offset:768\n"
@@ -198,8 +247,8 @@ __device__ __forceinline__ void body(double (&d)[8], uint32_t (&i)[8], double ca
     }
     if (OP == DS_READ_B64) {
 #define L(k, o) "ds_read_b64 %" #k ", %22 offset:" #o "\n"
-        asm volatile(L(0, 0) L(1, 512) L(2, 1024) L(3, 1536) L(4, 2048) L(5, 2560) L(6, 3072) L(7, 3584) L(0, 0) L(1, 512) L(2, 1024) L(3, 1536) L(4, 2048) L(5, 2560) L(6, 3072) L(7, 3584)
-                     L(0, 0) L(1, 512) L(2, 1024) L(3, 1536) L(4, 2048) L(5, 2560) L(6, 3072) L(7, 3584) L(0, 0) L(1, 512) L(2, 1024) L(3, 1536) L(4, 2048) L(5, 2560) L(6, 3072) L(7, 3584)
+        asm volatile(L(0, 0) L(1, 448) L(2, 896) L(3, 1344) L(4, 1792) L(5, 2240) L(6, 2688) L(7, 3136) L(0, 0) L(1, 448) L(2, 896) L(3, 1344) L(4, 1792) L(5, 2240) L(6, 2688) L(7, 3136)
+                     L(0, 0) L(1, 448) L(2, 896) L(3, 1344) L(4, 1792) L(5, 2240) L(6, 2688) L(7, 3136) L(0, 0) L(1, 448) L(2, 896) L(3, 1344) L(4, 1792) L(5, 2240) L(6, 2688) L(7, 3136)
                      "s_waitcnt lgkmcnt(0)\n"
                      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]),
                        "+v"(i[0]), "+v"(i[1]), "+v"(i[2]), "+v"(i[3]), "+v"(i[4]), "+v"(i[5]), "+v"(i[6]), "+v"(i[7])
@@ -214,6 +263,7 @@ __device__ __forceinline__ void run_op(int op, double (&d)[8], uint32_t (&i)[8],
 template <int OP>
 __global__ __launch_bounds__(64) void k_single(double* out, const double* in, long long* ticks)
 {
+    constexpr bool OPSEL_B64 = OP == DS_READ_B64;
     __shared__ uint32_t s_lds[1024];
     double d[8]; uint32_t i[8];
     for (int q = 0; q < 8; ++q) { d[q] = in[q] + 1e-9 * threadIdx.x; i[q] = (uint32_t)(in[q] * 1000) + threadIdx.x; }
@@ -222,7 +272,7 @@ __global__ __launch_bounds__(64) void k_single(double* out, const double* in, lo
     const uint32_t sa = __builtin_amdgcn_readfirstlane(ia), sb = __builtin_amdgcn_readfirstlane(ib);
     for (int q = threadIdx.x; q < 1024; q += 64) s_lds[q] = q;
     __syncthreads();
-    const uint32_t lds = (uint32_t)(uintptr_t)s_lds + 4u * threadIdx.x;
+    const uint32_t lds = (uint32_t)(uintptr_t)s_lds + (OPSEL_B64 ? 8u : 4u) * threadIdx.x;
     const long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
     for (int r = 0; r < TRIPS; ++r) body<OP>(d, i, ca, cb, ia, ib, sa, sb, lds);
@@ -237,6 +287,7 @@ __global__ __launch_bounds__(64) void k_single(double* out, const double* in, lo
 template <int OPA, int OPB>
 __global__ __launch_bounds__(64) void k_pair(double* out, const double* in, long long* ticks)
 {
+    constexpr bool OPSEL_B64 = false;
     __shared__ uint32_t s_lds[1024];
     double d[8]; uint32_t i[8];
     for (int q = 0; q < 8; ++q) { d[q] = in[q] + 1e-9 * threadIdx.x; i[q] = (uint32_t)(in[q] * 1000) + threadIdx.x; }
@@ -245,7 +296,7 @@ __global__ __launch_bounds__(64) void k_pair(double* out, const double* in, long
     const uint32_t sa = __builtin_amdgcn_readfirstlane(ia), sb = __builtin_amdgcn_readfirstlane(ib);
     for (int q = threadIdx.x; q < 1024; q += 64) s_lds[q] = q;
     __syncthreads();
-    const uint32_t lds = (uint32_t)(uintptr_t)s_lds + 4u * threadIdx.x;
+    const uint32_t lds = (uint32_t)(uintptr_t)s_lds + (OPSEL_B64 ? 8u : 4u) * threadIdx.x;
     // blocks go round-robin over XCDs (8), then CUs...: use a coarse split so that both kinds land on every SIMD
     const bool second = ((blockIdx.x >> 10) & 1) != 0;
     const long long t0 = __builtin_amdgcn_s_memtime();
@@ -298,6 +349,14 @@ int main(int argc, char** argv)
     double h[16]; for (int q = 0; q < 16; ++q) h[q] = 1.0 + q * 0.001;
     hipMemcpy(g_in, h, sizeof(h), hipMemcpyHostToDevice);
     const int quick = argc > 1 && !strcmp(argv[1], "quick");
+    if (argc > 1 && !strcmp(argv[1], "more")) {
+        for (int w = 4; w <= 8; w *= 2) {
+            SINGLE(AND_B32, w); SINGLE(OR_B32, w); SINGLE(XOR_B32, w); SINGLE(SUB_U32, w); SINGLE(ADD_U32, w); SINGLE(CNDMASK, w); SINGLE(CNDMASK_S, w); SINGLE(CMP_CND, w);
+            SINGLE(FMAC_F32, w); SINGLE(SUB_F32, w); SINGLE(CVT_F32_U32, w); SINGLE(CVT_U32_F32, w); SINGLE(LSHR_B32, w); SINGLE(BFI_B32, w); SINGLE(MOV_DPP, w);
+            SINGLE(ADD_CO, w); SINGLE(ADDC, w); SINGLE(MUL_HI_U32, w); SINGLE(MAD_U32_U16, w); SINGLE(DS_READ_B32, w); SINGLE(DS_READ_B64, w); SINGLE(FMA_F64, w); SINGLE(DOT4_U8, w);
+        }
+        return 0;
+    }
     for (int w = 1; w <= 8; w *= 2) {
         if (quick && w != 1 && w != 8) continue;
         SINGLE(FMA_F64, w); SINGLE(MUL_F64, w); SINGLE(ADD_F64, w); SINGLE(RCP_F64, w); SINGLE(CVT_F32_F64, w);
