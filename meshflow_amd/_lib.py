@@ -67,6 +67,13 @@ def _load():
         raise ImportError(
             f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             f'or `make -C meshflow_amd/csrc` (needs hipcc). There is no CPU fallback.')
+    # The process must hold ONE HIP runtime.  torch ships its own libamdhip64; when this library is loaded first it pulls
+    # in /opt/rocm's copy, initialises the GPU through it, and torch then finds "no HIP GPUs" (observed on MI355X / ROCm 7).
+    # Loading torch first makes the dynamic loader bind this library to the runtime torch already holds.
+    try:
+        import torch  # noqa: F401
+    except ImportError:      # a pure-ctypes host without torch: /opt/rocm's runtime is the only one
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)

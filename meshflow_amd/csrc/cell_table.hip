@@ -312,6 +312,8 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
     const float cxs[2] = { (float)xa, (float)xb }, cys[2] = { (float)ya, (float)yb };
     float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
     bool sane = true;
+    float single_edge[2][3] = { { 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f } };   // the one uncertain edge of the first two entries
+    bool single_ok[2] = { false, false };
     for (int r = r_hi; r >= r_lo && !closed && !overflow; --r)
         for (int c = c_hi; c >= c_lo && !closed && !overflow; --c) {
             const int k = r * C + c;
@@ -331,6 +333,10 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
             }
             if (any_out) continue;
             if (cnt == 8) { overflow = true; break; }
+            if (cnt < 2 && uncertain == 1) {
+                single_ok[cnt] = true;
+                for (int q = 0; q < 3; ++q) single_edge[cnt][q] = ed[3 * which + q];
+            }
             codes[cnt] = (uint16_t)(MF_PLAN_CODES | (uncertain == 1 ? which : uncertain == 2 ? (8 | which2 | (which << 4)) : 4));
             p.e[cnt++] = (uint16_t)(k | MF_PLAN_VALID | (all_in ? MF_PLAN_IN : 0u));
             if (all_in) closed = true;
@@ -355,6 +361,17 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
         p.e[0] = (uint16_t)r_lo; p.e[1] = (uint16_t)r_hi; p.e[2] = (uint16_t)c_lo; p.e[3] = (uint16_t)c_hi;
         p.e[4] = p.e[5] = p.e[6] = 0; p.e[7] = (uint16_t)MF_PLAN_OVERFLOW;
     }
+    // Two cells that meet inside the footprint, each with ONE uncertain edge g0, g1 (the pair path of the warp kernel): a pixel
+    // without owner would fail both, g0 <= m and g1 <= m (m = the kernel's float32 margin).  g0 + g1 is affine, so if it
+    // exceeds 2 m + 1 at the four corners it does everywhere and every pixel has an owner -- the footprint can be certified
+    // like one whose list ends with an IN cell.
+    bool covered = closed;
+    if (!closed && !overflow && cnt == 2 && single_ok[0] && single_ok[1]) {
+        const float a = single_edge[0][0] + single_edge[1][0], b = single_edge[0][1] + single_edge[1][1];
+        const float c = single_edge[0][2] + single_edge[1][2];
+        const float gmin = (fminf(a * cxs[0], a * cxs[1]) + fminf(b * cys[0], b * cys[1])) + c;
+        covered = gmin > 2.0f * ((float)(W > H ? W : H) * (1.0f / 16384.0f)) + 1.0f;
+    }
     region = 0;
     if (sane && cnt > 0 && !overflow && (W & 3) == 0 && 3 * W >= MF_STAGE_PITCH && H > MF_STAGE_ROWS &&
         umin > -4.0f && vmin > -4.0f && umax < 40000.0f && vmax < 40000.0f) {
@@ -364,7 +381,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
         const int sx0 = min(max(ix_lo, 0), (3 * W - MF_STAGE_PITCH) / 3), sy0 = min(max(iy_lo, 0), H - MF_STAGE_ROWS - 1);
         if (ix_lo >= sx0 && ix_hi <= sx0 + MF_STAGE_COLS - 1 && iy_lo >= sy0 && iy_hi <= sy0 + MF_STAGE_ROWS - 1)
             region = MF_REGION_STAGED | ((uint32_t)sy0 << 15) | (uint32_t)sx0 |
-                     (closed && ix_lo >= 2 && ix_hi <= W - 3 && iy_lo >= 2 && iy_hi <= H - 3 ? MF_REGION_DEEP : 0u);
+                     (covered && ix_lo >= 2 && ix_hi <= W - 3 && iy_lo >= 2 && iy_hi <= H - 3 ? MF_REGION_DEEP : 0u);
     }
 }
 

@@ -10,6 +10,8 @@
 // (the same scheme as meshflow_amd/pipeline.py, below Python).  Device buffers, streams and the per-chunk cell table are
 // kept between calls (grow-only cache, one per process, serialised by a mutex; mf_host_cache_release frees it).
 #include <stdlib.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <condition_variable>
 #include <mutex>
@@ -22,8 +24,9 @@ namespace mf {
 namespace {
 
 constexpr int PIPE_CHUNK = 16;     // frames per chunk (100 MB at 1080p)
-constexpr int PIPE_UP = 3;         // upload threads / streams
-constexpr int PIPE_DOWN = 3;       // download threads / streams
+constexpr int PIPE_UP = 4;         // upload threads / streams   (2/2: 59 ms, 3/3: 64, 4/4: 58, 6/6: 57 per cfg2 clip)
+constexpr int PIPE_DOWN = 4;       // download threads / streams
+constexpr int PIPE_POPULATE = 8;   // threads that fault the output pages in ahead of the downloads (MF_PIPE_POPULATE, 0 = none)
 constexpr int PIPE_MAX = 8;        // upper bound on either thread count (MF_PIPE_UP / MF_PIPE_DOWN / MF_PIPE_CHUNK tune them)
 
 int env_int(const char* name, int fallback, int lo, int hi)
@@ -68,7 +71,7 @@ PipeCache g_pipe;
 struct Shared {
     std::mutex m;
     std::condition_variable cv;
-    std::vector<char> up_ready, warp_ready;
+    std::vector<char> up_ready, warp_ready, populated;
     hipError_t err = hipSuccess;
     const char* what = "";
     bool abort = false;
@@ -108,6 +111,28 @@ hipError_t copy_frames(uint8_t* dev, const uint8_t* const* host, int i0, int i1,
     return hipSuccess;
 }
 
+// A freshly allocated output buffer (np.empty: untouched anonymous memory) costs one page fault + page clearing per 4 KB
+// when the download threads first write it; taken inside the three or four download threads that roughly doubles the clip
+// time (114 ms against 55 ms into a buffer that has been used before).  These threads fault the pages of chunk k in BEFORE
+// chunk k's download may start (the download waits for a flag), several chunks in parallel and concurrently with the
+// uploads: one byte written per page -- harmless, because the download overwrites every byte of the chunk afterwards.
+// (Eight threads populate 1.87 GB in 12 ms on the MI355X hosts; MADV_POPULATE_WRITE was measured at half that rate.)
+void populate_frames(uint8_t* const* host, int i0, int i1, size_t fb)
+{
+    static const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+    int i = i0;
+    while (i < i1) {
+        int j = i + 1;
+        while (j < i1 && host[j] == host[j - 1] + fb) ++j;
+        const uintptr_t begin = (uintptr_t)host[i], end = begin + (size_t)(j - i) * fb;
+        const uintptr_t lo = (begin + page - 1) & ~(page - 1), hi = end & ~(page - 1);
+        for (uintptr_t a = lo; a < hi; a += page) *(volatile uint8_t*)a = 0;
+        *(volatile uint8_t*)begin = 0;                                                  // the partial pages at both ends
+        *(volatile uint8_t*)(end - 1) = 0;
+        i = j;
+    }
+}
+
 }  // namespace
 
 int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, const double* unstab, const double* stab, int n, int W,
@@ -127,7 +152,7 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, const do
     const size_t fb = (size_t)W * H * 3;
     const size_t vb1 = (size_t)(R + 1) * (C + 1) * 2 * sizeof(double);        // vertex displacements of one frame
     static const int cfg_chunk = env_int("MF_PIPE_CHUNK", PIPE_CHUNK, 1, 4096), cfg_up = env_int("MF_PIPE_UP", PIPE_UP, 1, PIPE_MAX),
-                     cfg_down = env_int("MF_PIPE_DOWN", PIPE_DOWN, 1, PIPE_MAX);
+                     cfg_down = env_int("MF_PIPE_DOWN", PIPE_DOWN, 1, PIPE_MAX), cfg_pop = env_int("MF_PIPE_POPULATE", PIPE_POPULATE, 0, PIPE_MAX);
     const int chunk = n < cfg_chunk ? n : cfg_chunk;
     const int nchunks = (n + chunk - 1) / chunk;
     MF_HIP_TRY(pc.frames.need(fb * n)); MF_HIP_TRY(pc.out.need(fb * n));
@@ -153,8 +178,17 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, const do
     Shared sh;
     sh.up_ready.assign(nchunks, 0);
     sh.warp_ready.assign(nchunks, 0);
+    sh.populated.assign(nchunks, cfg_pop > 0 ? 0 : 1);
     std::vector<std::thread> workers;
     const int n_up = nchunks < cfg_up ? nchunks : cfg_up, n_down = nchunks < cfg_down ? nchunks : cfg_down;
+    const int n_pop = nchunks < cfg_pop ? nchunks : cfg_pop;
+    for (int t = 0; t < n_pop; ++t)
+        workers.emplace_back([&, t] {
+            for (int k = t; k < nchunks; k += n_pop) {
+                populate_frames(out, k * chunk, (k * chunk + chunk < n) ? k * chunk + chunk : n, fb);
+                sh.mark(sh.populated, k);
+            }
+        });
     for (int t = 0; t < n_up; ++t)
         workers.emplace_back([&, t] {
             if (hipSetDevice(dev) != hipSuccess) { sh.fail(hipErrorInvalidDevice, "hipSetDevice (upload thread)"); return; }
@@ -171,7 +205,7 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, const do
         workers.emplace_back([&, t] {
             if (hipSetDevice(dev) != hipSuccess) { sh.fail(hipErrorInvalidDevice, "hipSetDevice (download thread)"); return; }
             for (int k = t; k < nchunks; k += n_down) {
-                if (!sh.wait(sh.warp_ready, k)) return;
+                if (!sh.wait(sh.warp_ready, k) || !sh.wait(sh.populated, k)) return;
                 const int i0 = k * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
                 hipError_t e = hipStreamWaitEvent(pc.down[t], warp_done[k], 0);
                 if (e == hipSuccess) e = copy_frames(d_out, out, i0, i1, fb, false, pc.down[t]);

@@ -54,7 +54,8 @@ struct alignas(16) FootPlan { uint16_t e[8]; };
 #define MF_STAGE_ROWS 12
 #define MF_STAGE_COLS 52
 #define MF_REGION_STAGED 0x80000000u
-// bit 30 = DEEP (only with STAGED): the candidate list ends with an IN cell (every pixel has an owner) and the region
+// bit 30 = DEEP (only with STAGED): the candidate list ends with an IN cell, or consists of two single-edge cells whose masks
+// provably overlap across the footprint (either way every pixel has an owner), and the region
 // stays two pixels inside the frame, so the warp kernel needs neither the interior check nor the crop flags.
 #define MF_REGION_DEEP 0x40000000u
 #define MF_STAGE_CHUNKS 128            // two 16-byte chunks per lane: 12 rows x 10 chunks + 8 chunks of a 13th row (unused)

@@ -45,22 +45,24 @@
 
 namespace mf {
 
+// The cell table is written by earlier kernels and only read here: pointers into it live in the constant address space, so
+// that wave-uniform reads stay scalar loads (s_load) whatever else the kernel does (the global->LDS copies count as memory
+// writes for the compiler, which otherwise turns later record reads into per-lane vector loads and spends 40 VGPRs on them).
+typedef const __attribute__((address_space(4))) double* crec_t;
+typedef const __attribute__((address_space(4))) float* cedge_t;
+
 constexpr int TILE_W = 128;
 constexpr int FOOT_W = MF_FOOT_W;   // 8 lanes x 4 pixels
 constexpr int FOOT_H = MF_FOOT_H;   // 64 lanes / 8
 constexpr int FOOTS = 1;        // footprints per wavefront (1 measured best: 1.83 ms vs 2.01 at 2, 1.95 at 4)
 constexpr int TILE_H = FOOT_H * FOOTS;
 constexpr int MAX_MESH = 64;    // R, C <= 64
-#ifdef MF_EXP_STAGE256
-// LDS image of the staged window: 12 rows of 256 bytes.  Lane l fetches chunk (l & 15) of rows (l >> 4), (l >> 4) + 4, (l >> 4) + 8
-// (three global->LDS loads whose LDS destination is lane-linear, i.e. 16 slots per row; lanes with (l & 15) >= 10 are masked
-// off: the window is 10 chunks wide) -- row and column are a shift and a mask instead of a division by 10.
-constexpr int LDS_PITCH = 256;
-constexpr int LDS_WINDOW_BYTES = MF_STAGE_ROWS * LDS_PITCH;
-#else
+// A pixel's owner is kept as the byte offset of the owner's row in the wavefront's s_hi block (80-byte rows, one per list
+// entry).  Row 8 holds the matrix {0, 0, W+1; 0, 0, H+1; 0, 0, 1}: a pixel no cell covers runs through the same arithmetic and
+// comes out at exactly (W+1, H+1) (mfs.py:983-984) -- no special case, no select, in the coordinate code.
+constexpr uint32_t OWN_ROW = 80, OWN_NONE = 8 * OWN_ROW;
 constexpr int LDS_PITCH = MF_STAGE_PITCH;
 constexpr int LDS_WINDOW_BYTES = MF_STAGE_CHUNKS * 16;
-#endif
 
 // a * b + c on the 24-bit multiplier.  The empty asm makes `c` opaque so that the compiler keeps two chained
 // v_mad_u32_u24 instead of re-associating them into mul + mul + add3 (no instruction is emitted by it, so the
@@ -130,28 +132,32 @@ __device__ __forceinline__ double recip_unit_range(double w)
     return __builtin_fma(e, r, r);
 }
 
-#ifdef MF_EXP_RECIP
-// 1/w for the lane's pixels 1..3 from pixel 0's reciprocal r0: w_j = w_0 + j h6 (up to rounding), so
-// 1/w_j = r0 (1 - e + e^2 - ...), e = j h6 r0.  The second-order guess r0 - j c1 + j^2 c2 (c1 = h6 r0^2, c2 = h6^2 r0^3) is within
-// e^3 of 1/w_j; one Newton step squares that, and the same residual-correction step as recip_unit_range rounds correctly.
+// 1/w for the lane's pixels 1..3 WITHOUT v_rcp_f64 (16 issue cycles) and with one Newton step less: the denominators of
+// consecutive pixels differ by h6 (w_j = w_0 + j h6 up to rounding), so with r0 = 1/w_0
+//     1/w_j = r0 (1 - e + e^2 - ...),  e = j h6 r0,
+// and the second-order guess g = r0 - j c1 + j^2 c2 (c1 = h6 r0^2, c2 = h6^2 r0^3) is within e^3 (1 + e) of 1/w_j.  One Newton
+// step squares that; the residual-correction step of recip_unit_range then delivers the correctly rounded quotient exactly as
+// it does there, where its input is also an approximation good to about one ulp.  The caller guarantees |c1| <= 2.5e-4, i.e.
+// e <= 3 |c1| / |r0| <= 1.5e-3 (|r0| > 1/2), so the Newton step leaves a relative error below (1.002 * 3.4e-9)^2 < 2^-56.
+// mf_selftest_recip checks it against IEEE division on hashed (w_0, h6, j).
+constexpr double RECIP_GUESS_LIMIT = 2.5e-4;
 __device__ __forceinline__ double recip_guess(double r0, double c1, double c2, double j)
 {
     return __builtin_fma(j * j, c2, __builtin_fma(-j, c1, r0));
 }
-__device__ __forceinline__ double recip_from_guess(double w, double r)
+__device__ __forceinline__ double recip_from_guess(double w, double g)
 {
-    double e = __builtin_fma(-w, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-w, r, 1.0);
-    return __builtin_fma(e, r, r);
+    double e = __builtin_fma(-w, g, 1.0);
+    g = __builtin_fma(g, e, g);
+    e = __builtin_fma(-w, g, 1.0);
+    return __builtin_fma(e, g, g);
 }
-#endif
 
 // Source coordinates of the lane's four pixels under cell `rec`'s inverse homography:
 // cv2.perspectiveTransform (matmul.simd.hpp) -- float32 point, float64 matrix, float32 result.
 // SELECT = false: every pixel takes the new coordinates; true: only those in `pass`.
 template <bool SELECT>
-__device__ __forceinline__ void cell_coords(const double* __restrict__ rec, double xs0, double yy, int x0, uint32_t pass,
+__device__ __forceinline__ void cell_coords(crec_t rec, double xs0, double yy, int x0, uint32_t pass,
                                             float (&u)[4], float (&v)[4])
 {
     double Hi[9];
@@ -159,9 +165,6 @@ __device__ __forceinline__ void cell_coords(const double* __restrict__ rec, doub
     for (int i = 0; i < 9; ++i) Hi[i] = rec[MF_CELL_OFF_HI + i];
     const double t6 = yy * Hi[7], t0 = yy * Hi[1], t3 = yy * Hi[4];
     double w4[4];
-#ifdef MF_EXP_RECIP
-    double iw0 = 0.0, c1 = 0.0, c2 = 0.0;
-#endif
     uint32_t eor = 0;                                          // |w| in [0.5, 2) <=> frexp exponent in {0, 1}
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -169,20 +172,17 @@ __device__ __forceinline__ void cell_coords(const double* __restrict__ rec, doub
         w4[j] = (xs * Hi[6] + t6) + Hi[8];
         eor |= (uint32_t)__builtin_amdgcn_frexp_exp(w4[j]);
     }
-#ifdef MF_EXP_NOEXP
-    if (true) {
-#else
-    if (__ballot(eor > 1u) == 0) {
-#endif
+    // pixel 0: full reciprocal; pixels 1..3 start from it (recip_guess).  A cell whose denominator leaves [0.5, 2) or
+    // changes too fast along x for the guess (strong perspective: |h6| / w^2 > 2.5e-4 per pixel) takes the generic division.
+    // (the test |h6| <= limit * w0^2 is the same condition as |c1| <= limit without waiting for the reciprocal)
+    const bool guess_ok = fabs(Hi[6]) <= (0.96 * RECIP_GUESS_LIMIT) * (w4[0] * w4[0]);
+    if (__ballot(eor > 1u || !guess_ok) == 0) {
+        const double iw0 = recip_unit_range(w4[0]);
+        const double c1 = Hi[6] * (iw0 * iw0), c2 = (Hi[6] * c1) * iw0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const double xs = xs0 + (double)j;
-#ifdef MF_EXP_RECIP
-            const double iw = j == 0 ? recip_unit_range(w4[0]) : recip_from_guess(w4[j], recip_guess(iw0, c1, c2, (double)j));
-            if (j == 0) { iw0 = iw; c1 = Hi[6] * (iw * iw); c2 = (Hi[6] * c1) * iw; }
-#else
-            const double iw = recip_unit_range(w4[j]);
-#endif
+            const double iw = j == 0 ? iw0 : recip_from_guess(w4[j], recip_guess(iw0, c1, c2, (double)j));
             const float un = (float)(((xs * Hi[0] + t0) + Hi[2]) * iw);
             const float vn = (float)(((xs * Hi[3] + t3) + Hi[5]) * iw);
             if (SELECT) {
@@ -219,7 +219,7 @@ __device__ __forceinline__ void cell_coords(const double* __restrict__ rec, doub
 // fX = fl(Xn * fl(32/Wd)) differs from 32 Xn / Wd by < 1e-9 relative, and rint(fX) > lo <=> fX > lo + 1/2
 // (lo is even).  So the sign of q = 32 Xn - (lo + 1/2) Wd (and its three siblings) decides the test unless
 // |q| <= 1e-6 Wd; only then is the exact arithmetic (division, rint) needed.
-__device__ __forceinline__ uint32_t cell_mask_test(const double* __restrict__ rec, double xs0, double yy, int x0, int y,
+__device__ __forceinline__ uint32_t cell_mask_test(crec_t rec, double xs0, double yy, int x0, int y,
                                                    uint32_t unowned)
 {
     double M[9];
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                                                    uint32_t border, int32_t* __restrict__ crop)
 {
     // inverse homographies of a footprint's candidate cells, per wavefront: [entry][Hi0..Hi8, pad] (80-byte rows)
-    __shared__ __attribute__((aligned(16))) double s_hi[4][8][10];
+    __shared__ __attribute__((aligned(16))) double s_hi[4][9][10];        // row 8: the "no cell" matrix, see OWN_NONE
     // source region of the footprint, per wavefront: MF_STAGE_ROWS rows of MF_STAGE_PITCH bytes (+ slack for the
     // third dword of the last tap)
     __shared__ __attribute__((aligned(16))) uint8_t s_src[4][LDS_WINDOW_BYTES + 64];
@@ -289,8 +289,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
     const uint8_t* __restrict__ src = frames + (size_t)f * frame_bytes;
     uint8_t* __restrict__ dst = out + (size_t)f * frame_bytes;
     const size_t limit = (size_t)(n - f) * frame_bytes;
-    const double* __restrict__ frec = records + (size_t)f * ncell * MF_CELL_DOUBLES;
-    const float* __restrict__ fedge = edges + (size_t)f * ncell * MF_EDGE_FLOATS;
+    const crec_t frec = (crec_t)(uintptr_t)(records + (size_t)f * ncell * MF_CELL_DOUBLES);
+    const cedge_t fedge = (cedge_t)(uintptr_t)(edges + (size_t)f * ncell * MF_EDGE_FLOATS);
     const uint4* __restrict__ fplan = reinterpret_cast<const uint4*>(plan) + ((size_t)f * nfy * nfx + (tile_x * (TILE_W / FOOT_W) + wave));
     const uint32_t* __restrict__ fregion = regions + ((size_t)f * nfy * nfx + (tile_x * (TILE_W / FOOT_W) + wave));
 
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
         // (64+i)-th 16-byte chunk of the window (10 chunks = 160 bytes per row), which land at LDS offsets 16 i and
         // 1024 + 16 i.
         const bool staged = (rg & MF_REGION_STAGED) != 0 && stage_ok != 0;
-        uint32_t lds_origin = 0;                                          // LDS byte address = 160 iy + 3 ix - lds_origin
+        uint32_t lds_origin = 0;                                          // LDS byte address = LDS_PITCH iy + 3 ix - lds_origin
         if (staged) {
             const uint32_t sx0 = rg & 0x7FFFu, sy0 = (rg >> 15) & 0x7FFFu;
             const uint32_t bs = (3u * sx0) & ~3u;                         // dword holding the first column
@@ -320,20 +320,6 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
             const uint8_t* __restrict__ gbase = src + (size_t)sy0 * row_bytes + bs;
             // chunk i sits at row i / 10, byte 16 (i % 10) of the window = byte (i / 10) (row_bytes - 160) + 16 i from gbase;
             // uniform base + opaque 32-bit lane offset keeps the address arithmetic 32-bit (saddr + voffset form)
-#ifdef MF_EXP_STAGE256
-            uint32_t o0 = __umul24((uint32_t)lane >> 4, row_bytes) + (((uint32_t)lane & 15u) << 4);
-            asm("" : "+v"(o0));
-            if (((uint32_t)lane & 15u) < (uint32_t)(MF_STAGE_PITCH / 16)) {
-                const uint8_t* __restrict__ g1 = gbase + 4u * row_bytes;
-                const uint8_t* __restrict__ g2 = gbase + 8u * row_bytes;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o0),
-                                                 (__attribute__((address_space(3))) void*)&s_src[wave][0], 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g1 + o0),
-                                                 (__attribute__((address_space(3))) void*)&s_src[wave][1024], 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g2 + o0),
-                                                 (__attribute__((address_space(3))) void*)&s_src[wave][2048], 16, 0, 0);
-            }
-#else
             uint32_t o0 = __umul24(((uint32_t)lane * 205u) >> 11, row_bytes - (uint32_t)MF_STAGE_PITCH) + ((uint32_t)lane << 4);
             uint32_t o1 = __umul24((((uint32_t)lane + 64u) * 205u) >> 11, row_bytes - (uint32_t)MF_STAGE_PITCH) +
                           (((uint32_t)lane << 4) + 1024u);
@@ -343,11 +329,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                                              (__attribute__((address_space(3))) void*)&s_src[wave][0], 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o1),
                                              (__attribute__((address_space(3))) void*)&s_src[wave][1024], 16, 0, 0);
-#endif
-            lds_origin = sy0 * (uint32_t)LDS_PITCH + bs;
-#ifdef MF_EXP_LDSBASE
-            lds_origin -= (uint32_t)(uintptr_t)&s_src[wave][0];       // taps are addressed by absolute LDS byte address
-#endif
+            // taps are addressed by absolute LDS byte address: the wavefront's window base is folded into the origin
+            lds_origin = sy0 * (uint32_t)LDS_PITCH + bs - (uint32_t)(uintptr_t)&s_src[wave][0];
         }
 
         // Source coordinates of the lane's 4 pixels; (W+1, H+1) = "no cell covers it" (mfs.py:983-984).
@@ -370,7 +353,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
             while (!done && cr >= r_lo) {
                 const int k = cr * C + cc;
                 if (--cc < c_lo) { cc = c_hi; --cr; }
-                const double* __restrict__ rec = frec + (uint32_t)k * MF_CELL_DOUBLES;
+                const crec_t rec = frec + (uint32_t)k * MF_CELL_DOUBLES;
                 if (rec[MF_CELL_OFF_STATUS] != 0.0) continue;
                 const uint32_t pass = cell_mask_test(rec, xs0, yy, x0, y, unowned);
                 if (__ballot(pass != 0) == 0) continue;
@@ -389,17 +372,22 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 const uint32_t d = i < 2 ? pv.x : i < 4 ? pv.y : i < 6 ? pv.z : pv.w;
                 if (ne == i && ((d >> (16 * (i & 1))) & MF_PLAN_VALID)) ne = i + 1;
             }
-            for (int base = 0; base < ne * 9; base += 64) {
-                const int i = base + lane;
-                if (i < ne * 9) {
-                    const int e = (i * 57) >> 9;                                  // i / 9 for i < 72
-                    const int dd = i - 9 * e;
+            // (a) entry e's nine doubles are 18 consecutive dwords of its record: lanes 0..19 copy them (and two dwords of padding)
+            // straight into row e of s_hi, one global->LDS load per entry with a scalar base address -- no per-lane cell lookup
+            if (lane < 20) {
+                const uint32_t lo4 = (uint32_t)lane << 2;
+#pragma unroll 1
+                for (int e = 0; e < ne; ++e) {
                     const uint32_t d = e < 2 ? pv.x : e < 4 ? pv.y : e < 6 ? pv.z : pv.w;
                     const uint32_t k = (d >> (16 * (e & 1))) & 0xFFFu;
-                    s_hi[wave][e][dd] = frec[k * MF_CELL_DOUBLES + MF_CELL_OFF_HI + dd];
+                    const uint8_t* __restrict__ g = (const uint8_t*)(uintptr_t)(frec + k * MF_CELL_DOUBLES + MF_CELL_OFF_HI);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + lo4),
+                                                     (__attribute__((address_space(3))) void*)&s_hi[wave][e][0], 4, 0, 0);
                 }
             }
-            int own[4];
+            uint32_t own[4];                                            // byte offset of the owner's matrix row (OWN_ROW * entry)
+            if (!(rg & MF_REGION_DEEP) && lane < 10)                    // only uncertified footprints can have uncovered pixels
+                s_hi[wave][8][lane] = lane == 2 ? (double)(W + 1) : lane == 5 ? (double)(H + 1) : lane == 8 ? 1.0 : 0.0;
             const float yf = (float)y, xf0 = (float)x0;
             // The common shape -- exactly two cells, each with ONE mask edge crossing the footprint (a footprint on the
             // border between two cells): one fma per pixel and cell decides, straight-line.
@@ -412,35 +400,35 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
             if (quad) {
                 float near = 1e30f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) own[j] = -1;
+                for (int j = 0; j < 4; ++j) own[j] = OWN_NONE;
 #pragma unroll
                 for (int i = 3; i >= 0; --i) {                  // first entry last: it wins
                     const uint32_t ent = (i < 2 ? pv.x : pv.y) >> (16 * (i & 1));
                     const uint32_t cd = i == 0 ? cd0 : i == 1 ? cd1 : i == 2 ? cd2 : cd3;
-                    const float* __restrict__ ed = fedge + (ent & 0xFFFu) * MF_EDGE_FLOATS;
-                    const float* __restrict__ e1 = ed + 3u * (cd & 3u);
-                    const float* __restrict__ e2 = ed + 3u * ((cd >> 4) & 3u);
+                    const cedge_t ed = fedge + (ent & 0xFFFu) * MF_EDGE_FLOATS;
+                    const cedge_t e1 = ed + 3u * (cd & 3u);
+                    const cedge_t e2 = ed + 3u * ((cd >> 4) & 3u);
                     const float r1 = __builtin_fmaf(e1[1], yf, e1[2]), r2 = __builtin_fmaf(e2[1], yf, e2[2]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float xf = xf0 + (float)j;
                         const float g = fminf(__builtin_fmaf(e1[0], xf, r1), __builtin_fmaf(e2[0], xf, r2));
-                        own[j] = g > edge_margin ? i : own[j];
+                        own[j] = g > edge_margin ? OWN_ROW * (uint32_t)i : own[j];
                         near = fminf(near, fabsf(g));
                     }
                 }
                 general = __ballot(!(near > edge_margin) && y < H && x0 < W) != 0;
             }
             if (pair) {
-                const float* __restrict__ eb = fedge + (pv.x & 0xFFFu) * MF_EDGE_FLOATS + 3u * cd0;            // later cell: wins
-                const float* __restrict__ ea = fedge + ((pv.x >> 16) & 0xFFFu) * MF_EDGE_FLOATS + 3u * cd1;
+                const cedge_t eb = fedge + (pv.x & 0xFFFu) * MF_EDGE_FLOATS + 3u * cd0;            // later cell: wins
+                const cedge_t ea = fedge + ((pv.x >> 16) & 0xFFFu) * MF_EDGE_FLOATS + 3u * cd1;
                 const float rb = __builtin_fmaf(eb[1], yf, eb[2]), ra = __builtin_fmaf(ea[1], yf, ea[2]);
                 float near = 1e30f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float xf = xf0 + (float)j;
                     const float gb = __builtin_fmaf(eb[0], xf, rb), ga = __builtin_fmaf(ea[0], xf, ra);
-                    own[j] = gb > edge_margin ? 0 : (ga > edge_margin ? 1 : -1);
+                    own[j] = gb > edge_margin ? 0u : (ga > edge_margin ? OWN_ROW : OWN_NONE);
                     near = fminf(near, fminf(fabsf(gb), fabsf(ga)));
                 }
                 // a pixel inside the float32 error band of a mask edge (or NaN coefficients): the general path decides exactly
@@ -450,7 +438,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
             uint32_t unowned = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                own[j] = -1;
+                own[j] = OWN_NONE;
                 if (x0 + j < W && y < H) unowned |= 1u << j;
             }
             bool done = __ballot(unowned != 0) == 0;
@@ -461,12 +449,12 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 const uint32_t k = e & 0xFFFu;
                 uint32_t pass = unowned;                                   // IN: every unowned pixel passes
                 if (!(e & MF_PLAN_IN)) {
-                    const float* __restrict__ ed = fedge + k * MF_EDGE_FLOATS;
+                    const cedge_t ed = fedge + k * MF_EDGE_FLOATS;
                     // short lists carry an edge code: only one of the four edge functions can fail in this footprint
                     const uint32_t code = ne <= 4 ? (((i < 2 ? pv.z : pv.w) >> (16 * (i & 1))) & 0x3Fu) : 4u;
                     uint32_t ok = 0, amb = 0;
                     if (code < 4u) {
-                        const float* __restrict__ e1 = ed + 3u * code;
+                        const cedge_t e1 = ed + 3u * code;
                         const float rr = __builtin_fmaf(e1[1], yf, e1[2]);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -492,18 +480,19 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                     pass = ok & unowned;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) own[j] = ((pass >> j) & 1u) ? i : own[j];
+                for (int j = 0; j < 4; ++j) own[j] = ((pass >> j) & 1u) ? OWN_ROW * (uint32_t)i : own[j];
                 unowned &= ~pass;
                 done = __ballot(unowned != 0) == 0;
             }
             }
-            // (c) coordinates, once per pixel, owner's matrix from LDS (same wavefront wrote it: in order).  Optimistic: the
+            // (c) coordinates, once per pixel, owner's matrix from LDS.  Optimistic: the
             // trimmed reciprocal is applied straight away (keeps one pixel's intermediates live instead of four) and the
             // rare footprint with a denominator outside [0.5, 2) is redone with the generic division.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the matrices (and the window, issued before them) have landed
             uint32_t eor = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const double* hp = &s_hi[wave][own[j] < 0 ? 0 : own[j]][0];
+                const double* hp = reinterpret_cast<const double*>(reinterpret_cast<const uint8_t*>(&s_hi[wave][0][0]) + own[j]);
                 const double2 h01 = *reinterpret_cast<const double2*>(hp), h23 = *reinterpret_cast<const double2*>(hp + 2);
                 const double2 h45 = *reinterpret_cast<const double2*>(hp + 4), h67 = *reinterpret_cast<const double2*>(hp + 6);
                 const double h8 = hp[8];
@@ -511,17 +500,17 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 const double w = (xs * h67.x + yy * h67.y) + h8;
                 const double nx = (xs * h01.x + yy * h01.y) + h23.x;
                 const double ny = (xs * h23.y + yy * h45.x) + h45.y;
-                eor |= own[j] < 0 ? 0u : (uint32_t)__builtin_amdgcn_frexp_exp(w);
+                eor |= (uint32_t)__builtin_amdgcn_frexp_exp(w);
                 const double iw = recip_unit_range(w);
                 const float un = (float)(nx * iw), vn = (float)(ny * iw);
-                u[j] = own[j] < 0 ? (float)(W + 1) : un;
-                v[j] = own[j] < 0 ? (float)(H + 1) : vn;
+                u[j] = un;
+                v[j] = vn;
             }
             if (__ballot(eor > 1u) != 0) {                             // far-from-affine cell: generic division
 #pragma unroll 1
                 for (int j = 0; j < 4; ++j) {
-                    const int oj = j == 0 ? own[0] : j == 1 ? own[1] : j == 2 ? own[2] : own[3];
-                    const double* hp = &s_hi[wave][oj < 0 ? 0 : oj][0];
+                    const uint32_t oj = j == 0 ? own[0] : j == 1 ? own[1] : j == 2 ? own[2] : own[3];
+                    const double* hp = reinterpret_cast<const double*>(reinterpret_cast<const uint8_t*>(&s_hi[wave][0][0]) + oj);
                     const double xs = xs0 + (double)j;
                     const double w = (xs * hp[6] + yy * hp[7]) + hp[8];
                     float un = 0.0f, vn = 0.0f;
@@ -530,7 +519,6 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                         un = (float)(((xs * hp[0] + yy * hp[1]) + hp[2]) * iw);
                         vn = (float)(((xs * hp[3] + yy * hp[4]) + hp[5]) * iw);
                     }
-                    if (oj < 0) { un = (float)(W + 1); vn = (float)(H + 1); }
                     if (j == 0) { u[0] = un; v[0] = vn; }
                     else if (j == 1) { u[1] = un; v[1] = vn; }
                     else if (j == 2) { u[2] = un; v[2] = vn; }
@@ -584,11 +572,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t at = umad24(__builtin_amdgcn_ubfe(by[j], 5, 17), (uint32_t)LDS_PITCH,
                                                umad24(__builtin_amdgcn_ubfe(bx[j], 5, 17), 3u, 0u - lds_origin));
-#ifdef MF_EXP_LDSBASE
                     const uint32_t* __restrict__ p = (const uint32_t*)(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(at & ~3u);
-#else
-                    const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(&s_src[wave][at & ~3u]);
-#endif
                     const uint32_t t0 = p[0], t1 = p[1], t2 = p[2];
                     const uint32_t u0 = p[LDS_PITCH / 4], u1 = p[LDS_PITCH / 4 + 1], u2 = p[LDS_PITCH / 4 + 2];
                     a[j].x = __builtin_amdgcn_alignbyte(t1, t0, at);
@@ -612,17 +596,11 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
             for (int j = 0; j < 4; ++j) {
                 // a[j].x = B0 G0 R0 B1, a[j].y = G1 R1 . .   (pixel ix, pixel ix+1 of row iy; b: row iy+1)
                 const uint32_t fx = bx[j] & 31u;
-#ifdef MF_EXP_WMAD
-                // (32 - fx) | fx << 24 = 32 + fx (2^24 - 1), etc.: one v_mad_u32_u24 each
-                const uint32_t wb = umad24(fx, 0xFFFFFFu, 32u);
-                const uint32_t wg = umad24(fx, 255u, 32u);
-                const uint32_t wr = umad24(fx, 0xFF0000u, 0x200000u);
-#else
-                const uint32_t w0 = 32u - fx;
-                const uint32_t wb = w0 | (fx << 24);          // weights on bytes 0 and 3 of .x  (B0, B1)
-                const uint32_t wg = w0 | (fx << 8);           // weights on bytes 0, 1 of the permuted dword (G0, G1)
-                const uint32_t wr = wg << 16;                 // weights on bytes 2, 3 (R0, R1)
-#endif
+                // weight pairs (32 - fx, fx) placed on the bytes they multiply, one v_mad_u32_u24 each:
+                // (32 - fx) | fx << 24 = 32 + fx (2^24 - 1), (32 - fx) | fx << 8 = 32 + 255 fx, and that << 16
+                const uint32_t wb = umad24(fx, 0xFFFFFFu, 32u);         // bytes 0 and 3 of .x  (B0, B1)
+                const uint32_t wg = umad24(fx, 255u, 32u);              // bytes 0, 1 of the permuted dword (G0, G1)
+                const uint32_t wr = umad24(fx, 0xFF0000u, 0x200000u);   // bytes 2, 3 (R0, R1)
                 const uint32_t pa = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x05020401u);   // G0 G1 R0 R1
                 const uint32_t pb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x05020401u);
                 // horizontal lerps (<= 255*32), v_dot4_u32_u8
@@ -733,6 +711,22 @@ __global__ void selftest_recip_kernel(unsigned long long n, unsigned long long s
         const double a = recip_unit_range(w);
         const double b = 1.0 / w;
         if (__double_as_longlong(a) != __double_as_longlong(b)) ++bad;
+        // the neighbour-pixel route: w_j = w + j h6 with |h6| / w^2 up to the limit the kernel accepts (a second hash draws h6)
+        unsigned long long z2 = (z ^ 0xD6E8FEB86659FD93ull) * 0x9E3779B97F4A7C15ull;
+        z2 ^= z2 >> 29;
+        const double frac = (double)(long long)(z2 >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;        // (-1, 1)
+        const double scale = (i & 7) == 0 ? 1.0 : (double)((z2 & 1023) + 1) * (1.0 / 1024.0);                // often small, sometimes the limit
+        const double h6 = frac * scale * RECIP_GUESS_LIMIT * (w * w);
+        const double c1 = h6 * (a * a), c2 = (h6 * c1) * a;
+        if (fabs(c1) <= RECIP_GUESS_LIMIT) {
+            const double j = (double)(1 + (int)(z2 % 3));
+            const double wj = w + j * h6;
+            if (fabs(wj) >= 0.5 && fabs(wj) < 2.0) {
+                const double g = recip_from_guess(wj, recip_guess(a, c1, c2, j));
+                const double q = 1.0 / wj;
+                if (__double_as_longlong(g) != __double_as_longlong(q)) ++bad;
+            }
+        }
     }
     if (bad) atomicAdd(mismatches, bad);
 }

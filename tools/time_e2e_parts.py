@@ -3,6 +3,12 @@ import ctypes, os, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
+if len(sys.argv) > 1 and sys.argv[1] == 'fresh-sweep':
+    for pop, thp in ((0, 0), (4, 0), (4, 1), (8, 0), (8, 1), (2, 0)):
+        env = dict(os.environ, MF_PIPE_POPULATE=str(pop), MF_PIPE_THP=str(thp))
+        out = subprocess.run([sys.executable, __file__, 'fresh'], env=env, capture_output=True, text=True).stdout.strip().splitlines()
+        print(f'populate={pop} thp={thp}:', ' | '.join(out), flush=True)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
     for up, down, chunk in ((3, 3, 16), (2, 2, 16), (4, 4, 16), (6, 6, 16), (3, 3, 8), (3, 3, 32), (4, 4, 8), (1, 1, 16)):
         env = dict(os.environ, MF_PIPE_UP=str(up), MF_PIPE_DOWN=str(down), MF_PIPE_CHUNK=str(chunk))
@@ -39,6 +45,9 @@ def bench(label, fn, n=6):
 out = np.empty_like(frames)
 contig = [frames[i] for i in range(F)]
 separate = [frames[i].copy() for i in range(F)]
+if len(sys.argv) > 1 and sys.argv[1] == 'fresh':
+    bench('separate in, fresh out', lambda: call(separate, np.empty_like(frames)))
+    sys.exit(0)
 bench('contiguous in, reused out', lambda: call(contig, out))
 if len(sys.argv) > 1 and sys.argv[1] == 'one':
     sys.exit(0)
@@ -47,5 +56,6 @@ bench('separate in, fresh out', lambda: call(separate, np.empty_like(frames)))
 bench('np.empty + touch 1.87 GB', lambda: np.empty_like(frames).fill(0))
 from meshflow_amd.stabilizer import MeshFlowStabilizer
 s = MeshFlowStabilizer(device='cuda:0')
-bench('stabilize_clip(list)', lambda: s.stabilize_clip(separate, disp, hom))
+import torch
+bench("stabilize_clip(list)", lambda: s.stabilize_clip(separate, disp, hom))
 bench('stabilize_clip(array)', lambda: s.stabilize_clip(frames, disp, hom))
