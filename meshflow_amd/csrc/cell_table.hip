@@ -312,6 +312,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
     const float cxs[2] = { (float)xa, (float)xb }, cys[2] = { (float)ya, (float)yb };
     float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
     bool sane = true;
+    float wlo = 1e30f, whi = -1e30f, h6_first = 0.0f;          // denominator range of the FIRST listed cell over the footprint
     float single_edge[2][3] = { { 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f } };   // the one uncertain edge of the first two entries
     bool single_ok[2] = { false, false };
     for (int r = r_hi; r >= r_lo && !closed && !overflow; --r)
@@ -348,6 +349,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
                 const float cx = cxs[q & 1], cy = cys[q >> 1];
                 const float w = h[6] * cx + h[7] * cy + h[8];
                 sane = sane && w > 0.25f && w < 4.0f;                     // (NaN fails)
+                if (cnt == 1) { wlo = fminf(wlo, w); whi = fmaxf(whi, w); h6_first = h[6]; }
                 const float iw = 1.0f / w;
                 const float u = (h[0] * cx + h[1] * cy + h[2]) * iw, v = (h[3] * cx + h[4] * cy + h[5]) * iw;
                 umin = fminf(umin, u); umax = fmaxf(umax, u);
@@ -356,6 +358,8 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
         }
     if (!overflow && cnt <= 4)
         for (int i = 0; i < cnt; ++i) p.e[4 + i] = codes[i];      // short list: room for the per-entry edge codes
+    if (cnt == 1 && closed && sane && wlo > 0.52f && whi < 1.9f && fabsf(h6_first) <= 0.9f * 2.5e-4f * (wlo * wlo))
+        p.e[1] = (uint16_t)MF_PLAN_UNIT;                           // (float32 evaluation: 1e-6 of error against margins of 4 % and 10 %)
     if (overflow) {
         // more than 8 candidates: hand the whole range to the warp kernel instead
         p.e[0] = (uint16_t)r_lo; p.e[1] = (uint16_t)r_hi; p.e[2] = (uint16_t)c_lo; p.e[3] = (uint16_t)c_hi;

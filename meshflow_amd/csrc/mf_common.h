@@ -44,6 +44,10 @@ inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 #define MF_PLAN_VALID 0x4000u
 #define MF_PLAN_IN 0x8000u
 #define MF_PLAN_OVERFLOW 0xFFFFu
+// A list that consists of ONE IN entry leaves entry 1 unused (bit 14 clear); its bit 0 then certifies the cell's projective
+// denominator on this footprint: 0.52 < w < 1.9 at the four corners (hence on every pixel: w is affine) and |h6| <= 0.9 * 2.5e-4 *
+// min(w)^2, the condition of the warp kernel's reciprocal guess -- the kernel skips both per-pixel tests.
+#define MF_PLAN_UNIT 0x0001u
 struct alignas(16) FootPlan { uint16_t e[8]; };
 // Source region of a footprint (uint32): bits 0-14 first source column sx0, bits 15-29 first source row sy0,
 // bit 31 = STAGED: every bilinear tap of every pixel of the footprint lies in columns sx0 .. sx0+MF_STAGE_COLS-1 and

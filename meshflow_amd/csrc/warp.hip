@@ -15,33 +15,42 @@
 // float32, then 1/32-pixel fixed point; interpolation is integer.  The result is bit-identical to the CPU
 // oracle (oracle/warp_oracle.c).
 //
-// Mapping (gfx950).  A 256-thread workgroup owns a 128 x 8 pixel tile of one frame (tile rows start on a
-// 128-byte boundary of the 3-byte-per-pixel output when W % 128 == 0: 1080p, 4K); tiles are handed out XCD-aware
-// (mf_common.h TileOrder).  Each wavefront owns a 32 x 8 pixel "footprint" of the tile; a lane owns 4 consecutive
-// pixels of one row (12 contiguous output bytes -> one global_store_dwordx3).  Per footprint:
+// Mapping (gfx950).  One wavefront = one workgroup = one 32 x 8 pixel "footprint" of one frame; a lane owns 4 consecutive pixels
+// of one row (12 contiguous output bytes -> one global_store_dwordx3).  Footprints are handed out XCD-aware (mf_common.h
+// TileOrder).  Per footprint:
 //   1. footprint_plan_kernel (cell_table.hip) wrote the wave-uniform PLAN (one scalar load): up to 8 candidate cells
-//      in descending order, each IN (all 256 pixels pass its mask test) or MIXED, with -- for short lists -- the one
-//      mask edge that can fail; and the footprint's SOURCE REGION, the window of the source frame that holds every
-//      bilinear tap of every pixel.
+//      in descending order, each IN (all 256 pixels pass its mask test) or MIXED, with -- for short lists -- the one or two
+//      mask edges that can fail; and the footprint's SOURCE REGION, the window of the source frame that holds every
+//      bilinear tap of every pixel, with two certificates (DEEP: every pixel has an owner and every tap is interior;
+//      UNIT: the projective denominator stays in (0.52, 1.9) and varies slowly enough for the reciprocal guess).
 //   2. The window goes to LDS asynchronously: two global_load_lds_dwordx4 per lane, issued first, awaited after the
 //      coordinate arithmetic.
 //   3. One IN cell (~66 % of footprints at config-2 geometry): no per-pixel test; the cell's Hi comes in through
-//      scalar loads and the four coordinates are straight-line float64 code with an IEEE-exact reciprocal trimmed
-//      for 0.5 <= |w| < 2.
-//   4. Two cells with one uncertain edge each (~27 %): one float32 fma per pixel and cell decides ownership.
-//      Otherwise the general last-cell-first loop.  A pixel inside the float32 error band of an edge is decided by a
-//      division-free float64 comparison, and by OpenCV's exact arithmetic (division, rint) only within 1e-6 of the
-//      edge.  Every pixel then computes its coordinates once with its owner's Hi read from LDS.  More than 8
-//      candidates: every cell of the recorded index range is tested.
+//      scalar loads and the four coordinates are straight-line float64 code.  1/w: pixel 0 by v_rcp_f64 + Newton + the
+//      residual correction that makes it the IEEE quotient; pixels 1..3 start from pixel 0's reciprocal (second-order
+//      guess + ONE Newton step + the same correction: no v_rcp_f64, two fma less).
+//   4. Two cells with one uncertain edge each (~25 %): one float32 fma per pixel and cell decides ownership; the four
+//      cells around a mesh vertex: two per cell.  Otherwise the general last-cell-first loop.  A pixel inside the float32
+//      error band of an edge is decided by a division-free float64 comparison, and by OpenCV's exact arithmetic
+//      (division, rint) only within 1e-6 of the edge.  The candidates' Hi go to LDS by global->LDS DMA (one 80-byte load
+//      per candidate, scalar base address); a pixel's owner is kept as the byte offset of its matrix row, and "no owner"
+//      is a ninth row holding the matrix that maps every pixel to (W+1, H+1) -- the coordinate code has no special case.
 //   5. cv2.remap: sx = rint(32u) via one fma against 1.5*2^23; taps = three dword LDS reads per pixel and row +
-//      v_alignbyte_b32, horizontal lerps v_dot4_u32_u8, vertical lerp two chained v_mad_u32_u24 scaled so that the
-//      rounded byte lands in byte 2, nine v_perm_b32 gather the lane's 12 output bytes.  Footprints the plan could
-//      not certify (frame border, uncovered pixels, oversized or unaligned windows) check per pixel and use either
+//      v_alignbyte_b32 (gfx950 does read LDS at unaligned addresses, but 1.4x slower overall), horizontal lerps
+//      v_dot4_u32_u8 with the weight pairs built by v_mad_u32_u24, vertical lerp two chained v_mad_u32_u24 scaled so
+//      that the rounded byte lands in byte 2, nine v_perm_b32 gather the lane's 12 output bytes.  Footprints the plan
+//      could not certify (frame border, uncovered pixels, oversized or unaligned windows) check per pixel and use either
 //      two unaligned 8-byte global loads per pixel or the per-tap path with border colour and crop flags.
 // Algorithmic HBM traffic: 2*H*W*3 bytes per frame (each source byte read once, each output byte written
-// once); measured 1.02x that.  No dense contraction: no MFMA.  The kernel is VALU-issue bound (exact float64
-// coordinates + integer blend), not HBM bound: DESIGN.md section 4.3, profiles/.
+// once); measured 1.02x that.  No dense contraction: no MFMA.  What bounds it: DESIGN.md section 4.3 (ablations: the
+// skeleton without coordinates and blend already takes 0.77 of the 1.28 ms; the wavefronts are latency-bound, throughput
+// follows occupancy), profiles/.
 #include "mf_common.h"
+
+// At most 80 scalar registers: a CU admits min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) workgroups of 256 threads
+// (MI355X_MICROARCH.md), i.e. 7 with the 94 the compiler would take and 8 with 80 (the excess is kept in VGPR lanes, the kernel
+// stays at 64 VGPRs): -1.7 % kernel time.
+#define MF_WARP_ATTR __attribute__((amdgpu_num_sgpr(80)))
 
 namespace mf {
 
@@ -51,11 +60,18 @@ namespace mf {
 typedef const __attribute__((address_space(4))) double* crec_t;
 typedef const __attribute__((address_space(4))) float* cedge_t;
 
-constexpr int TILE_W = 128;
+// Workgroup = ONE wavefront (its tile = its 32 x 8 footprint).  Wavefronts never cooperate (no barrier, no shared LDS data), and
+// a multi-wave workgroup keeps the slots of its finished wavefronts until the slowest one -- often on a slower ownership
+// path -- is done: 4 x 1 wavefronts 1.516 ms (cfg2) / 3.410 (cfg3), 2 x 1: 1.505 / 3.392, 1 x 1: 1.492 / 3.326; 4 x 2 and 4 x 4
+// (fewer dispatches) 1.65 / 1.89.
+constexpr int WAVES_X = 1;      // wavefronts side by side in a workgroup
+constexpr int TILE_W = 32 * WAVES_X;
 constexpr int FOOT_W = MF_FOOT_W;   // 8 lanes x 4 pixels
 constexpr int FOOT_H = MF_FOOT_H;   // 64 lanes / 8
 constexpr int FOOTS = 1;        // footprints per wavefront (1 measured best: 1.83 ms vs 2.01 at 2, 1.95 at 4)
-constexpr int TILE_H = FOOT_H * FOOTS;
+constexpr int WAVES_Y = 1;      // wavefront rows per workgroup
+constexpr int WG_WAVES = WAVES_X * WAVES_Y;
+constexpr int TILE_H = FOOT_H * FOOTS * WAVES_Y;
 constexpr int MAX_MESH = 64;    // R, C <= 64
 // A pixel's owner is kept as the byte offset of the owner's row in the wavefront's s_hi block (80-byte rows, one per list
 // entry).  Row 8 holds the matrix {0, 0, W+1; 0, 0, H+1; 0, 0, 1}: a pixel no cell covers runs through the same arithmetic and
@@ -156,27 +172,32 @@ __device__ __forceinline__ double recip_from_guess(double w, double g)
 // Source coordinates of the lane's four pixels under cell `rec`'s inverse homography:
 // cv2.perspectiveTransform (matmul.simd.hpp) -- float32 point, float64 matrix, float32 result.
 // SELECT = false: every pixel takes the new coordinates; true: only those in `pass`.
+// `certified` (wave-uniform): the plan has checked on the footprint's corners that the denominator stays inside (0.52, 1.9) and
+// that the reciprocal guess applies (MF_PLAN_UNIT) -- both tests are then skipped.
 template <bool SELECT>
 __device__ __forceinline__ void cell_coords(crec_t rec, double xs0, double yy, int x0, uint32_t pass,
-                                            float (&u)[4], float (&v)[4])
+                                            float (&u)[4], float (&v)[4], bool certified = false)
 {
+    (void)x0;
     double Hi[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) Hi[i] = rec[MF_CELL_OFF_HI + i];
     const double t6 = yy * Hi[7], t0 = yy * Hi[1], t3 = yy * Hi[4];
     double w4[4];
-    uint32_t eor = 0;                                          // |w| in [0.5, 2) <=> frexp exponent in {0, 1}
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const double xs = xs0 + (double)j;                     // exact: small integers
-        w4[j] = (xs * Hi[6] + t6) + Hi[8];
-        eor |= (uint32_t)__builtin_amdgcn_frexp_exp(w4[j]);
-    }
+    for (int j = 0; j < 4; ++j) w4[j] = ((xs0 + (double)j) * Hi[6] + t6) + Hi[8];     // (xs0 + j is exact: small integers)
     // pixel 0: full reciprocal; pixels 1..3 start from it (recip_guess).  A cell whose denominator leaves [0.5, 2) or
     // changes too fast along x for the guess (strong perspective: |h6| / w^2 > 2.5e-4 per pixel) takes the generic division.
-    // (the test |h6| <= limit * w0^2 is the same condition as |c1| <= limit without waiting for the reciprocal)
-    const bool guess_ok = fabs(Hi[6]) <= (0.96 * RECIP_GUESS_LIMIT) * (w4[0] * w4[0]);
-    if (__ballot(eor > 1u || !guess_ok) == 0) {
+    bool fast_ok = certified;
+    if (!certified) {
+        uint32_t eor = 0;                                      // |w| in [0.5, 2) <=> frexp exponent in {0, 1}
+#pragma unroll
+        for (int j = 0; j < 4; ++j) eor |= (uint32_t)__builtin_amdgcn_frexp_exp(w4[j]);
+        // (the test |h6| <= limit * w0^2 is the same condition as |c1| <= limit without waiting for the reciprocal)
+        const bool guess_ok = fabs(Hi[6]) <= (0.96 * RECIP_GUESS_LIMIT) * (w4[0] * w4[0]);
+        fast_ok = __ballot(eor > 1u || !guess_ok) == 0;
+    }
+    if (fast_ok) {
         const double iw0 = recip_unit_range(w4[0]);
         const double c1 = Hi[6] * (iw0 * iw0), c2 = (Hi[6] * c1) * iw0;
 #pragma unroll
@@ -195,21 +216,19 @@ __device__ __forceinline__ void cell_coords(crec_t rec, double xs0, double yy, i
             }
         }
     } else {                                                   // far-from-affine cell: generic division
-#pragma unroll 1
+        // (unrolled: a rolled loop indexes u[] / v[] by select chains, and their initial values -- eight moves -- are then
+        // hoisted in front of the branch, onto the fast path)
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (SELECT && !((pass >> j) & 1u)) continue;
-            const double xs = (double)(x0 + j);
-            double w = (xs * Hi[6] + t6) + Hi[8];
-            float un = 0.0f, vn = 0.0f;
-            if (fabs(w) > 1.1920928955078125e-07) {
-                w = 1.0 / w;
-                un = (float)(((xs * Hi[0] + t0) + Hi[2]) * w);
-                vn = (float)(((xs * Hi[3] + t3) + Hi[5]) * w);
-            }
-            if (j == 0) { u[0] = un; v[0] = vn; }
-            else if (j == 1) { u[1] = un; v[1] = vn; }
-            else if (j == 2) { u[2] = un; v[2] = vn; }
-            else { u[3] = un; v[3] = vn; }
+            const double xs = xs0 + (double)j;
+            const double w = w4[j];
+            const bool ok = fabs(w) > 1.1920928955078125e-07;
+            const double iw = 1.0 / w;
+            const float un = ok ? (float)(((xs * Hi[0] + t0) + Hi[2]) * iw) : 0.0f;
+            const float vn = ok ? (float)(((xs * Hi[3] + t3) + Hi[5]) * iw) : 0.0f;
+            const bool p = !SELECT || ((pass >> j) & 1u);
+            u[j] = p ? un : u[j];
+            v[j] = p ? vn : v[j];
         }
     }
 }
@@ -258,7 +277,7 @@ __device__ __forceinline__ uint32_t cell_mask_test(crec_t rec, double xs0, doubl
     return ok & unowned;
 }
 
-__global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out,
+__global__ __launch_bounds__(64 * WG_WAVES) MF_WARP_ATTR void warp_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out,
                                                    const double* __restrict__ records,
                                                    const float* __restrict__ edges,
                                                    const FootPlan* __restrict__ plan, const uint32_t* __restrict__ regions,
@@ -266,10 +285,10 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                                                    uint32_t border, int32_t* __restrict__ crop)
 {
     // inverse homographies of a footprint's candidate cells, per wavefront: [entry][Hi0..Hi8, pad] (80-byte rows)
-    __shared__ __attribute__((aligned(16))) double s_hi[4][9][10];        // row 8: the "no cell" matrix, see OWN_NONE
+    __shared__ __attribute__((aligned(16))) double s_hi[WG_WAVES][9][10];        // row 8: the "no cell" matrix, see OWN_NONE
     // source region of the footprint, per wavefront: MF_STAGE_ROWS rows of MF_STAGE_PITCH bytes (+ slack for the
     // third dword of the last tap)
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[4][LDS_WINDOW_BYTES + 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[WG_WAVES][LDS_WINDOW_BYTES + 64];
     // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2: with the
     // natural order the four neighbours of a tile -- whose staged source windows overlap this tile's by 60 % -- would
     // all run on other XCDs and each L2 would fetch the shared rows again.  Workgroup L therefore takes tile
@@ -279,7 +298,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
     if (!order.decode(blockIdx.x, f, tile_y, tile_x)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps plan/record loads scalar
     const int lane = threadIdx.x & 63;
-    const int xa = tile_x * TILE_W + wave * FOOT_W;                  // footprint x range starts here
+    const int wave_x = wave % WAVES_X, wave_y = wave / WAVES_X;
+    const int xa = tile_x * TILE_W + wave_x * FOOT_W;                // footprint x range starts here
     if (xa >= W) return;                                                 // whole wave outside the frame
     const int x0 = xa + (lane & 7) * 4;                                  // first of this lane's 4 pixels
     const int ncell = R * C;
@@ -291,23 +311,21 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
     const size_t limit = (size_t)(n - f) * frame_bytes;
     const crec_t frec = (crec_t)(uintptr_t)(records + (size_t)f * ncell * MF_CELL_DOUBLES);
     const cedge_t fedge = (cedge_t)(uintptr_t)(edges + (size_t)f * ncell * MF_EDGE_FLOATS);
-    const uint4* __restrict__ fplan = reinterpret_cast<const uint4*>(plan) + ((size_t)f * nfy * nfx + (tile_x * (TILE_W / FOOT_W) + wave));
-    const uint32_t* __restrict__ fregion = regions + ((size_t)f * nfy * nfx + (tile_x * (TILE_W / FOOT_W) + wave));
+    const uint4* __restrict__ fplan = reinterpret_cast<const uint4*>(plan) + ((size_t)f * nfy * nfx + (tile_x * (TILE_W / FOOT_W) + wave_x));
+    const uint32_t* __restrict__ fregion = regions + ((size_t)f * nfy * nfx + (tile_x * (TILE_W / FOOT_W) + wave_x));
 
-    int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
-    bool scanned = false;                     // (wave-uniform) the crop-flag scan ran for some footprint of this wavefront
     const float fWm1 = (float)(W - 1), fHm1 = (float)(H - 1);
     const bool fast_store = (W & 3) == 0;
     const double xs0 = (double)x0;
 
 #pragma unroll 1
     for (int q = 0; q < FOOTS; ++q) {
-        const int ya = tile_y * TILE_H + q * FOOT_H;
+        const int ya = tile_y * TILE_H + (wave_y * FOOTS + q) * FOOT_H;
         if (ya >= H) break;
         const int y = ya + (lane >> 3);
         const double yy = (double)y;
-        const uint4 pv = fplan[(size_t)(tile_y * FOOTS + q) * nfx];   // wave-uniform: scalar load
-        const uint32_t rg = fregion[(size_t)(tile_y * FOOTS + q) * nfx];
+        const uint4 pv = fplan[(size_t)((tile_y * WAVES_Y + wave_y) * FOOTS + q) * nfx];   // wave-uniform: scalar load
+        const uint32_t rg = fregion[(size_t)((tile_y * WAVES_Y + wave_y) * FOOTS + q) * nfx];
         // Source region -> LDS, asynchronously (global_load_lds: no VGPRs, no ds_write): lane i fetches the i-th and
         // (64+i)-th 16-byte chunk of the window (10 chunks = 160 bytes per row), which land at LDS offsets 16 i and
         // 1024 + 16 i.
@@ -337,7 +355,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
         float u[4], v[4];
         if ((pv.x & (MF_PLAN_IN | MF_PLAN_VALID)) == (MF_PLAN_IN | MF_PLAN_VALID) && (pv.w >> 16) != MF_PLAN_OVERFLOW) {
             // one cell owns the whole footprint (the common case): no per-pixel test, no merging
-            cell_coords<false>(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy, x0, 0xFu, u, v);
+            cell_coords<false>(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy, x0, 0xFu, u, v, ((pv.x >> 16) & MF_PLAN_UNIT) != 0);
         } else if ((pv.w >> 16) == MF_PLAN_OVERFLOW) {
             // more than 8 candidate cells: test every cell of the recorded range, last cell first
             uint32_t unowned = 0;
@@ -507,22 +525,15 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
                 v[j] = vn;
             }
             if (__ballot(eor > 1u) != 0) {                             // far-from-affine cell: generic division
-#pragma unroll 1
+#pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const uint32_t oj = j == 0 ? own[0] : j == 1 ? own[1] : j == 2 ? own[2] : own[3];
-                    const double* hp = reinterpret_cast<const double*>(reinterpret_cast<const uint8_t*>(&s_hi[wave][0][0]) + oj);
+                    const double* hp = reinterpret_cast<const double*>(reinterpret_cast<const uint8_t*>(&s_hi[wave][0][0]) + own[j]);
                     const double xs = xs0 + (double)j;
                     const double w = (xs * hp[6] + yy * hp[7]) + hp[8];
-                    float un = 0.0f, vn = 0.0f;
-                    if (fabs(w) > 1.1920928955078125e-07) {
-                        const double iw = 1.0 / w;
-                        un = (float)(((xs * hp[0] + yy * hp[1]) + hp[2]) * iw);
-                        vn = (float)(((xs * hp[3] + yy * hp[4]) + hp[5]) * iw);
-                    }
-                    if (j == 0) { u[0] = un; v[0] = vn; }
-                    else if (j == 1) { u[1] = un; v[1] = vn; }
-                    else if (j == 2) { u[2] = un; v[2] = vn; }
-                    else { u[3] = un; v[3] = vn; }
+                    const bool ok = fabs(w) > 1.1920928955078125e-07;
+                    const double iw = 1.0 / w;
+                    u[j] = ok ? (float)(((xs * hp[0] + yy * hp[1]) + hp[2]) * iw) : 0.0f;
+                    v[j] = ok ? (float)(((xs * hp[3] + yy * hp[4]) + hp[5]) * iw) : 0.0f;
                 }
             }
         }
@@ -563,7 +574,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
         if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the region has landed in LDS
         if (fast) {
             // fast path (wave-uniform): every pixel of the footprint samples the deep interior
-            if (!active) continue;
+            if (active) {
             uint2 a[4], b[4];
             if (staged) {
                 // taps from the staged region: three dwords around byte 160 iy + 3 ix of each of the two rows,
@@ -619,10 +630,11 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
             d.x = __builtin_amdgcn_perm(__builtin_amdgcn_perm(oB[1], oR[0], pair), __builtin_amdgcn_perm(oG[0], oB[0], pair), join);
             d.y = __builtin_amdgcn_perm(__builtin_amdgcn_perm(oG[2], oB[2], pair), __builtin_amdgcn_perm(oR[1], oG[1], pair), join);
             d.z = __builtin_amdgcn_perm(__builtin_amdgcn_perm(oR[3], oG[3], pair), __builtin_amdgcn_perm(oB[3], oR[2], pair), join);
+            }
         } else {
             // generic path: frame borders, uncovered pixels, crop flags, out-of-range coordinates
-            scanned = true;
-            if (!active) continue;
+            int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
+            if (active) {
             uint32_t px[4];
 #pragma unroll 1
             for (int j = 0; j < 4; ++j) {
@@ -660,35 +672,37 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ f
             d.x = px[0] | (px[1] << 24);
             d.y = (px[1] >> 8) | (px[2] << 16);
             d.z = (px[2] >> 16) | (px[3] << 8);
-        }
-        const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
-        if (fast_store && x0 + 3 < W) {
-            *reinterpret_cast<uint3*>(dst + o) = d;
-        } else {
-            const int nb = 3 * min(4, W - x0);                       // W % 4 != 0: byte by byte, up to the row end
-            for (int k = 0; k < nb; ++k) {
-                const uint32_t word = k < 4 ? d.x : k < 8 ? d.y : d.z;
-                dst[o + k] = (uint8_t)(word >> (8 * (k & 3)));
+            }
+            // Crop bounds (only this path can set one): wave reduction, then at most one atomic per bound and wavefront.
+            const bool any = c_left != 0 || c_top != 0 || c_right != W - 1 || c_bottom != H - 1;
+            if (__ballot(any) != 0) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    c_left = max(c_left, __shfl_xor(c_left, off));
+                    c_top = max(c_top, __shfl_xor(c_top, off));
+                    c_right = min(c_right, __shfl_xor(c_right, off));
+                    c_bottom = min(c_bottom, __shfl_xor(c_bottom, off));
+                }
+                if (lane == 0) {
+                    if (c_left != 0) atomicMax(&crop[4 * f + 0], c_left);
+                    if (c_top != 0) atomicMax(&crop[4 * f + 1], c_top);
+                    if (c_right != W - 1) atomicMin(&crop[4 * f + 2], c_right);
+                    if (c_bottom != H - 1) atomicMin(&crop[4 * f + 3], c_bottom);
+                }
             }
         }
-    }
-
-    // Crop bounds: only the generic path can have set one.  Wave reduction, then at most one atomic per bound per wave.
-    if (!scanned) return;
-    const bool any = c_left != 0 || c_top != 0 || c_right != W - 1 || c_bottom != H - 1;
-    if (__ballot(any) != 0) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            c_left = max(c_left, __shfl_xor(c_left, off));
-            c_top = max(c_top, __shfl_xor(c_top, off));
-            c_right = min(c_right, __shfl_xor(c_right, off));
-            c_bottom = min(c_bottom, __shfl_xor(c_bottom, off));
-        }
-        if (lane == 0) {
-            if (c_left != 0) atomicMax(&crop[4 * f + 0], c_left);
-            if (c_top != 0) atomicMax(&crop[4 * f + 1], c_top);
-            if (c_right != W - 1) atomicMin(&crop[4 * f + 2], c_right);
-            if (c_bottom != H - 1) atomicMin(&crop[4 * f + 3], c_bottom);
+        if (active) {                                                   // the lane's 12 output bytes
+            const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
+            if (fast_store && x0 + 3 < W) {
+                *reinterpret_cast<uint3*>(dst + o) = d;
+            } else {
+                const int nb = 3 * min(4, W - x0);                       // W % 4 != 0: byte by byte, up to the row end
+#pragma unroll 1
+                for (int k = 0; k < nb; ++k) {
+                    const uint32_t word = k < 4 ? d.x : k < 8 ? d.y : d.z;
+                    dst[o + k] = (uint8_t)(word >> (8 * (k & 3)));
+                }
+            }
         }
     }
 }
@@ -757,7 +771,7 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
     // coefficients put the evaluation within 2.5 V 2^-23 of the exact value.  The kernel trusts the float32 sign only
     // beyond six times that, max(W, H) 2^-14 (0.12 at 1080p), and decides in float64 inside the band.
     const float edge_margin = (float)(W > H ? W : H) * (1.0f / 16384.0f);
-    hipLaunchKernelGGL(warp_kernel, grid, dim3(256), 0, st, frames, out, tv.records, tv.edges, tv.plan, tv.regions, stage_ok, edge_margin, order, n, W, H, R, C, border,
+    hipLaunchKernelGGL(warp_kernel, grid, dim3(64 * WG_WAVES), 0, st, frames, out, tv.records, tv.edges, tv.plan, tv.regions, stage_ok, edge_margin, order, n, W, H, R, C, border,
                        crop);
     return hip_fail(hipGetLastError(), "warp_kernel launch");
 }
