@@ -238,6 +238,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
     ap.add_argument('--frames-kind', default='pattern', choices=['pattern', 'noise'])
+    ap.add_argument('--frames', type=int, default=0, help='frames per GPU instead of the workload\'s own count (a SLICE of the clip: '
+                    'profiling aid, e.g. the cfg3 PMC passes; the line says so)')
     ap.add_argument('--cpu-frames', type=int, default=300, help='frames warped by the CPU baseline (0 = skip both CPU legs)')
     # default: the whole clip, ~5-10 s of host time
     ap.add_argument('--no-faithful', action='store_true', help='skip the reference-faithful (dense / per-cell) CPU leg (~20 s)')
@@ -265,6 +267,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     H, W, per_gpu, R, C, omega, iters = WORKLOADS[args.workload]
+    sliced = args.frames > 0 and args.frames != per_gpu
+    if args.frames > 0:
+        per_gpu = args.frames
     e2e_mode = args.mode == 'e2e'
     clips_mode = (args.mode == 'clips' and world > 1) or e2e_mode
     if clips_mode:                       # every rank owns a whole clip of its own (seed = rank)
@@ -463,7 +468,7 @@ def main():
         traffic = None            # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
         try:
             with open(os.path.join(REPO, 'profiles', 'traffic.json')) as fh:
-                traffic = json.load(fh).get(args.workload, {}).get('traffic_bytes')
+                traffic = None if sliced else json.load(fh).get(args.workload, {}).get('traffic_bytes')
         except (OSError, ValueError):
             pass
         result = {
@@ -473,7 +478,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'dtype_note': 'float64 vertex paths and pixel coordinates (as the reference), integer fixed-point interpolation on uint8',
             'data': f'synthetic ({args.frames_kind} frames, injected random mesh motion, seed 0)',
-            'config': {'workload': f'{args.workload}: {W}x{H}, {per_gpu} frames/GPU ({per_gpu * world} total), {R}x{C} mesh, '
+            'config': {'workload': f'{args.workload}{" (SLICE: --frames)" if sliced else ""}: {W}x{H}, {per_gpu} frames/GPU ({per_gpu * world} total), {R}x{C} mesh, '
                                    f'omega={omega}, {iters} Jacobi sweeps, ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL',
                        'parallelism': (f'{world} independent clips, one per GPU, no collective' if clips_mode else
                                        f'frame-range shards x{world}, Jacobi replicated, 16-byte crop all-reduce')},

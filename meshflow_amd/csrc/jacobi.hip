@@ -11,6 +11,8 @@
 // back; one barrier per sweep.  Everything stays on chip for all sweeps: HBM traffic is one read of b and
 // one write of x.  This kernel is FP64-VALU / LDS bound, not HBM bound.  K is kept minimal (5 frames per thread at
 // OMEGA = 10, 10 at OMEGA = 30); clips longer than 64 K frames spread each series over 2-8 wavefronts.
+#include <stdlib.h>
+
 #include "mf_common.h"
 
 namespace mf {
@@ -76,8 +78,9 @@ __global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* _
     }
 }
 
-// Fallback for any (omega, F): one 256-thread workgroup per series, thread-per-frame loop over LDS.
-// Same summation order as the specialised kernel, so both give identical bits.
+// Fallback for any other (omega, F) -- specialised radii: 5, 10, 15, 20, 30 -- one 256-thread workgroup per series,
+// thread-per-frame loop over LDS.  Same summation order as the specialised kernel, so both give identical bits, at a tenth of
+// the speed (F = 300, 16 x 16 mesh, 100 sweeps: omega = 40: 693 us = 4.1 TFLOP/s against 48 us = 16 TFLOP/s for omega = 10).
 __global__ __launch_bounds__(256) void jacobi_generic_kernel(const double* __restrict__ b, double* __restrict__ x_out,
                                                              const double* __restrict__ taps,
                                                              const double* __restrict__ lam,
@@ -128,6 +131,16 @@ int launch_jacobi(const double* b, double* x, const double* taps, const double* 
     // the fewest frames per thread that covers the clip: a long clip spreads each series over up to 8 wavefronts
     // (measured faster than more frames per lane even when there are more series than SIMDs: tools/time_jacobi.py)
 #define MF_JACOBI(O, K, WV) return launch_wave<O, K, WV>(b, x, taps, lam, inv_on, F, S, iters, st)
+    // Far fewer series than SIMDs (1024): one wavefront per series leaves most SIMDs idle -- split each series over more
+    // wavefronts with fewer frames per lane.  Measured (F = 300, 100 sweeps): 162 series (8 x 8 mesh) 40.7 us with one wavefront
+    // per series, 31.8 with two, 30.4 with four; 578 series (16 x 16) 48.1 / 49.1 / 50.4 -- there the workgroup barrier of
+    // a split series costs what the shorter per-lane loop saves, so the split starts below 512 series.
+    static const int split = [] { const char* v = getenv("MF_JACOBI_SPLIT"); return v && *v ? atoi(v) : -1; }();   // tuning aid
+    const int want = split > 0 ? split : (S < 256 ? 4 : S < 512 ? 2 : 1);
+    if (omega == 10 && want > 1) {
+        if (F <= 256 * 2 && want >= 4) MF_JACOBI(10, 2, 4);
+        if (F <= 128 * 3) MF_JACOBI(10, 3, 2);
+    }
     if (omega == 10) {
         if (F <= 64 * 5) MF_JACOBI(10, 5, 1);
         if (F <= 128 * 5) MF_JACOBI(10, 5, 2);
@@ -135,6 +148,21 @@ int launch_jacobi(const double* b, double* x, const double* taps, const double* 
         if (F <= 512 * 5) MF_JACOBI(10, 5, 8);
         if (F <= 512 * 10) MF_JACOBI(10, 10, 8);
         if (F <= 512 * 19) MF_JACOBI(10, 19, 8);
+    } else if (omega == 5) {
+        if (F <= 64 * 5) MF_JACOBI(5, 5, 1);
+        if (F <= 128 * 5) MF_JACOBI(5, 5, 2);
+        if (F <= 256 * 5) MF_JACOBI(5, 5, 4);
+        if (F <= 512 * 5) MF_JACOBI(5, 5, 8);
+    } else if (omega == 15) {
+        if (F <= 64 * 8) MF_JACOBI(15, 8, 1);
+        if (F <= 128 * 8) MF_JACOBI(15, 8, 2);
+        if (F <= 256 * 8) MF_JACOBI(15, 8, 4);
+        if (F <= 512 * 8) MF_JACOBI(15, 8, 8);
+    } else if (omega == 20) {
+        if (F <= 64 * 8) MF_JACOBI(20, 8, 1);
+        if (F <= 128 * 8) MF_JACOBI(20, 8, 2);
+        if (F <= 256 * 8) MF_JACOBI(20, 8, 4);
+        if (F <= 512 * 8) MF_JACOBI(20, 8, 8);
     } else if (omega == 30) {
         if (F <= 64 * 10) MF_JACOBI(30, 10, 1);
         if (F <= 128 * 10) MF_JACOBI(30, 10, 2);

@@ -40,7 +40,10 @@ def _hip_jacobi(dev, b, taps, lam, inv_on, omega, iters):
 
 @pytest.mark.parametrize('F,S,omega', [(641, 6, 10), (1280, 5, 10), (2400, 7, 10), (2561, 3, 10), (5120, 2, 10), (9000, 2, 10),
                                        (700, 4, 30), (2400, 3, 30), (5000, 2, 30), (9728, 1, 30), (10100, 1, 30),
-                                       (1300, 1100, 10)])
+                                       (1300, 1100, 10),
+                                       (300, 6, 5), (700, 3, 5), (2600, 2, 5), (300, 5, 15), (1100, 4, 15), (4000, 2, 15), (4200, 1, 15),
+                                       (300, 5, 20), (2100, 3, 20), (4000, 2, 20),
+                                       (300, 100, 10), (380, 300, 10), (500, 200, 10), (300, 578, 10), (300, 6, 40)])
 def test_jacobi_long_clips_every_variant_vs_c_oracle(dev, F, S, omega):
     """Few series + long clips spread a series over 2-8 wavefronts (the replicated sweep of a multi-GPU run); many series
     keep one wavefront per series; beyond the specialised sizes the generic kernel takes over.  All bit-identical."""

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp; W=${WORKLOAD:-cfg2}
 for set in "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum" "TCC_EA0_RDREQ_128B_sum" "WRITE_SIZE"; do
   rm -rf /tmp/tr
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/tr -o r -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-e2e --workload $W > /tmp/tr.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/tr -o r -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-e2e --workload $W ${FRAMES:+--frames $FRAMES} > /tmp/tr.log 2>&1
   python3 - "$W" <<'PY'
 import csv, collections, sys
 rows = collections.defaultdict(list)
