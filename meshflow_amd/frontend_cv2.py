@@ -128,9 +128,14 @@ def cropping_and_distortion(tracker, unstabilized_frames, cropped_frames, worker
     the cropped frame; ratio = 1 / (h00 * h11), distortion = ratio of the two largest eigenvalue magnitudes of its
     affine part; float32 mean of the ratios, float32 MINIMUM of the distortions (the reference's choice)."""
     tracked = tracker.track_pairs(unstabilized_frames, cropped_frames, workers)
-    ratios = np.empty(len(tracked), dtype=np.float32)
-    distortions = np.empty(len(tracked), dtype=np.float32)
-    for i, (_, _, h) in enumerate(tracked):
+    return cropping_and_distortion_from_homographies([h for _, _, h in tracked])
+
+
+def cropping_and_distortion_from_homographies(homographies):
+    """The arithmetic of mfs.py:1196-1212 on the per-frame (unstabilized -> cropped) homographies."""
+    ratios = np.empty(len(homographies), dtype=np.float32)
+    distortions = np.empty(len(homographies), dtype=np.float32)
+    for i, h in enumerate(homographies):
         ratios[i] = 1 / (h[0][0] * h[1][1])        # h is None when tracking failed: TypeError, like the reference
         affine = np.copy(h)
         affine[2] = [0, 0, 1]

@@ -73,11 +73,13 @@ class ChunkedTransfer:
         self.out_pool = ThreadPoolExecutor(max_workers=len(self.out_streams), thread_name_prefix='mf-d2h')
         self.pending = []
 
-    def upload_all(self, clip, d_frames, ranges, after):
-        """`after`: event on the stream that allocated d_frames (the copy streams must not run ahead of it)."""
+    def upload(self, clip, d_frames, i0, i1, after, k):
+        """Queues the copy of clip frames i0..i1-1 into d_frames[i0:i1] on copy stream k (mod the pool); returns a
+        future whose result is the event that marks its end.  `after`: event on the stream that allocated d_frames
+        (the copy streams must not run ahead of it)."""
         import torch
 
-        def task(k, i0, i1):
+        def task():
             stream = self.in_streams[k % len(self.in_streams)]
             with torch.cuda.device(self.device), torch.cuda.stream(stream):
                 stream.wait_event(after)
@@ -86,7 +88,10 @@ class ChunkedTransfer:
                 ev.record(stream)
             return ev
 
-        return [self.in_pool.submit(task, k, i0, i1) for k, (i0, i1) in enumerate(ranges)]
+        return self.in_pool.submit(task)
+
+    def upload_all(self, clip, d_frames, ranges, after):
+        return [self.upload(clip, d_frames, i0, i1, after, k) for k, (i0, i1) in enumerate(ranges)]
 
     def download(self, d_src, host_dst, after, k):
         import torch

@@ -99,6 +99,10 @@ class MeshFlowStabilizer:
         self._check_definition(adaptive_weights_definition)
         from . import frontend_cv2
         cv2 = frontend_cv2.require_cv2()
+        if self.overlap_video_io and not self._boundary_overridden(self._BOUNDARY_METHODS + self._OPENCV_METHODS):
+            # nothing replaced: decode || track || upload, then the device path, then download || encode || scores
+            from . import streaming
+            return streaming.stabilize_streamed(self, cv2, input_path, output_path, adaptive_weights_definition)
         unstabilized_frames, num_frames, frames_per_second, codec = self._get_unstabilized_frames_and_video_features(input_path)
         disp, homographies = self._get_unstabilized_vertex_displacements_and_homographies(num_frames, unstabilized_frames)
         if self._boundary_overridden():
@@ -124,10 +128,15 @@ class MeshFlowStabilizer:
     _BOUNDARY_METHODS = ('_get_stabilized_vertex_displacements', '_get_stabilized_frames_and_crop_boundaries',
                          '_crop_frames', '_compute_stability_score')
 
-    def _boundary_overridden(self):
+    _OPENCV_METHODS = ('_get_unstabilized_frames_and_video_features', '_get_unstabilized_vertex_displacements_and_homographies',
+                       '_get_matched_features_and_homography', '_compute_cropping_ratio_and_distortion_score',
+                       '_write_stabilized_video')
+    overlap_video_io = True      # False: `stabilize` runs its stages one after the other, like the reference
+
+    def _boundary_overridden(self, names=None):
         """True when one of the reference's boundary methods (called at mfs.py:150-162) is not this class's
         own implementation: overridden in a subclass or patched on the instance."""
-        for name in self._BOUNDARY_METHODS:
+        for name in names or self._BOUNDARY_METHODS:
             if name in vars(self) or getattr(type(self), name) is not getattr(MeshFlowStabilizer, name):
                 return True
         return False

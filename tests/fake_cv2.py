@@ -2,6 +2,8 @@
 orchestration of `MeshFlowStabilizer.stabilize(input_path, output_path)` can be exercised where OpenCV is not
 installed.  It is NOT an OpenCV restatement: the "detector" returns a fixed lattice of points, the "optical flow"
 moves them by a shift registered for the late frame, the "homography" is a plain least-squares DLT."""
+import threading
+import time
 import types
 
 import numpy as np
@@ -9,6 +11,14 @@ import numpy as np
 VIDEOS = {}      # path -> dict(frames=[...], fps=float, fourcc=int, claimed=int or None)
 WRITTEN = {}     # path -> dict(frames=[...], fps, fourcc, size)
 MOTION = {}      # id(frame array) -> (dx, dy) applied by calcOpticalFlowPyrLK when that frame is the late one
+EVENTS = []      # ('read', i) / ('write', i) in the order they happened (tests append their own kinds through `log`)
+READ_DELAY = [0.0]   # seconds a decode of one frame takes
+_LOCK = threading.Lock()
+
+
+def log(kind, index):
+    with _LOCK:
+        EVENTS.append((kind, index))
 
 
 class _Capture:
@@ -23,7 +33,10 @@ class _Capture:
     def read(self):
         if self.pos >= len(self.video['frames']):
             return False, None
+        if READ_DELAY[0]:
+            time.sleep(READ_DELAY[0])
         self.pos += 1
+        log('read', self.pos - 1)
         return True, self.video['frames'][self.pos - 1]
 
     def release(self):
@@ -35,6 +48,7 @@ class _Writer:
         self.rec = WRITTEN[path] = dict(frames=[], fps=fps, fourcc=fourcc, size=size)
 
     def write(self, frame):
+        log('write', len(self.rec['frames']))
         self.rec['frames'].append(np.array(frame, copy=True))
 
     def release(self):

@@ -16,7 +16,8 @@ torch = pytest.importorskip('torch')
 def cv2_stub(monkeypatch):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import fake_cv2
-    fake_cv2.VIDEOS.clear(); fake_cv2.WRITTEN.clear(); fake_cv2.MOTION.clear()
+    fake_cv2.VIDEOS.clear(); fake_cv2.WRITTEN.clear(); fake_cv2.MOTION.clear(); fake_cv2.EVENTS.clear()
+    fake_cv2.READ_DELAY[0] = 0.0
     monkeypatch.setitem(sys.modules, 'cv2', fake_cv2.module())
     return fake_cv2
 
@@ -105,3 +106,81 @@ def test_stabilize_honours_overridden_boundary_methods(cv2_stub):
     s = MeshFlowStabilizer(**kw)
     s._compute_stability_score = lambda num_frames, stab: 0.25
     assert s._boundary_overridden() and s.stabilize('in.m4v', 'patched.m4v')[2] == 0.25
+
+
+KW = dict(mesh_row_count=4, mesh_col_count=4, mesh_outlier_subframe_row_count=2, mesh_outlier_subframe_col_count=2,
+          feature_ellipse_row_count=3, feature_ellipse_col_count=3, temporal_smoothing_radius=3, optimization_num_iterations=10)
+
+
+@pytest.mark.parametrize('F', [1 + 16, 40, 48])
+def test_streamed_stabilize_equals_the_staged_sequence(cv2_stub, F):
+    """the overlapped `stabilize` (streaming.py) against the stage-after-stage one (the reference's order,
+    mfs.py:148-167): same return tuple, same encoded frames -- with a ragged last chunk, and with whole chunks only."""
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    _make_video(cv2_stub, 'in.m4v', F=F)
+    staged = MeshFlowStabilizer(**KW)
+    staged.overlap_video_io = False
+    want = staged.stabilize('in.m4v', 'staged.m4v', MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL)
+    got = MeshFlowStabilizer(**KW).stabilize('in.m4v', 'streamed.m4v', MeshFlowStabilizer.ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL)
+    assert got == want and all(type(a) is type(b) for a, b in zip(got, want))
+    a, b = cv2_stub.WRITTEN['streamed.m4v'], cv2_stub.WRITTEN['staged.m4v']
+    assert len(a['frames']) == F and (a['fps'], a['fourcc'], a['size']) == (b['fps'], b['fourcc'], b['size'])
+    np.testing.assert_array_equal(np.stack(a['frames']), np.stack(b['frames']))
+
+
+def test_streamed_stabilize_overlaps_io_with_the_stages_around_it(cv2_stub, monkeypatch):
+    """The order of events, not their speed: with a decoder that takes 2 ms per frame, the first chunk's tracking and upload must
+    have started before the last frame is decoded; with downloads that finish 20 ms apart, the encoder must have been handed
+    frames before the last chunk is back; and the frames reach the encoder in order."""
+    import time
+    from meshflow_amd import pipeline
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    F = 40
+    frames = _make_video(cv2_stub, 'in.m4v', F=F)
+    cv2_stub.READ_DELAY[0] = 0.002
+    first_pair = id(frames[1])
+    real_upload, real_flow = pipeline.ChunkedTransfer.upload, sys.modules['cv2'].calcOpticalFlowPyrLK
+
+    def upload(self, clip, d_frames, i0, i1, after, k):
+        cv2_stub.log('upload', k)
+        return real_upload(self, clip, d_frames, i0, i1, after, k)
+
+    def download(self, d_src, host_dst, after, k):
+        def task():
+            time.sleep(0.02 * k)
+            stream = self.out_streams[k % len(self.out_streams)]
+            with torch.cuda.device(self.device), torch.cuda.stream(stream):
+                stream.wait_event(after)
+                torch.from_numpy(host_dst).copy_(d_src)
+            cv2_stub.log('download', k)
+        self.pending.append(self.out_pool.submit(task))
+
+    def flow(early, late, points, nxt):
+        cv2_stub.log('track', 0)
+        return real_flow(early, late, points, nxt)
+
+    monkeypatch.setattr(pipeline.ChunkedTransfer, 'upload', upload)
+    monkeypatch.setattr(pipeline.ChunkedTransfer, 'download', download)
+    monkeypatch.setattr(sys.modules['cv2'], 'calcOpticalFlowPyrLK', flow)
+    MeshFlowStabilizer(**KW).stabilize('in.m4v', 'out.m4v')
+    ev = list(cv2_stub.EVENTS)
+    last_read = ev.index(('read', F - 1))
+    assert ev.index(('upload', 0)) < last_read and ev.index(('upload', 1)) < last_read
+    assert ev.index(('track', 0)) < last_read
+    assert ev.index(('write', 0)) < ev.index(('download', 2))
+    assert [i for kind, i in ev if kind == 'write'] == list(range(F))
+    assert ev.index(('download', 0)) < ev.index(('write', 0))
+
+
+def test_streamed_stabilize_is_bypassed_when_an_opencv_side_method_is_replaced(cv2_stub):
+    """A subclass that replaces the decoder, tracker, score or encoder method keeps being called."""
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    _make_video(cv2_stub, 'in.m4v')
+    seen = []
+
+    class Custom(MeshFlowStabilizer):
+        def _write_stabilized_video(self, output_path, num_frames, frames_per_second, codec, stabilized_frames):
+            seen.append((output_path, num_frames, len(stabilized_frames)))
+
+    Custom(**KW).stabilize('in.m4v', 'never.m4v')
+    assert seen == [('never.m4v', 10, 10)] and 'never.m4v' not in cv2_stub.WRITTEN
