@@ -36,9 +36,10 @@
 //      per candidate, scalar base address); a pixel's owner is kept as the byte offset of its matrix row, and "no owner"
 //      is a ninth row holding the matrix that maps every pixel to (W+1, H+1) -- the coordinate code has no special case.
 //   5. cv2.remap: sx = rint(32u) via one fma against 1.5*2^23; taps = three dword LDS reads per pixel and row +
-//      v_alignbyte_b32 (gfx950 does read LDS at unaligned addresses, but 1.4x slower overall), horizontal lerps
-//      v_dot4_u32_u8 with the weight pairs built by v_mad_u32_u24, vertical lerp two chained v_mad_u32_u24 scaled so
-//      that the rounded byte lands in byte 2, nine v_perm_b32 gather the lane's 12 output bytes.  Footprints the plan
+//      v_alignbyte_b32 (gfx950 does read LDS at unaligned addresses, but 1.4x slower overall); per channel v_perm_b32 puts
+//      the two horizontal neighbours into 16-bit fields, v_mul_u32_u24 + v_mad_u32_u24 lerp both fields vertically at
+//      once, v_dot2_u32_u16 lerps horizontally with weights scaled so that the rounded byte lands in byte 2; six v_perm_b32
+//      + three v_or_b32 gather the lane's 12 output bytes.  Footprints the plan
 //      could not certify (frame border, uncovered pixels, oversized or unaligned windows) check per pixel and use either
 //      two unaligned 8-byte global loads per pixel or the per-tap path with border colour and crop flags.
 // Algorithmic HBM traffic: 2*H*W*3 bytes per frame (each source byte read once, each output byte written
@@ -87,6 +88,16 @@ __device__ __forceinline__ uint32_t umad24(uint32_t a, uint32_t b, uint32_t c)
 {
     asm("" : "+v"(c));
     return __umul24(a, b) + c;
+}
+
+// bits [5..28] of the raw float 32u + 1.5*2^23 are (sx >> 5) + MAGIC_HI for 0 <= sx < 2^22
+constexpr uint32_t MAGIC_HI = (0x4B400000u >> 5) & 0xFFFFFFu;
+
+// a.lo * b.lo + a.hi * b.hi + c on 16-bit halves (v_dot2_u32_u16)
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
+{
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
 }
 
 __device__ __forceinline__ int cv_round_f32(float v)
@@ -581,8 +592,10 @@ __global__ __launch_bounds__(64 * WG_WAVES) MF_WARP_ATTR void warp_kernel(const 
                 // shifted down by the byte misalignment (v_alignbyte takes the low two bits of the address)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const uint32_t at = umad24(__builtin_amdgcn_ubfe(by[j], 5, 17), (uint32_t)LDS_PITCH,
-                                               umad24(__builtin_amdgcn_ubfe(bx[j], 5, 17), 3u, 0u - lds_origin));
+                    // ix = bits[5..21] of the raw float; bits[22..28] (the 1.5*2^23 pattern, constant) ride along in the 24-bit
+                    // multiplier operand and are taken out again through the origin: one v_lshrrev (half the issue cost of v_bfe)
+                    const uint32_t at = umad24(by[j] >> 5, (uint32_t)LDS_PITCH,
+                                               umad24(bx[j] >> 5, 3u, 0u - lds_origin - MAGIC_HI * (3u + (uint32_t)LDS_PITCH)));
                     const uint32_t* __restrict__ p = (const uint32_t*)(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(at & ~3u);
                     const uint32_t t0 = p[0], t1 = p[1], t2 = p[2];
                     const uint32_t u0 = p[LDS_PITCH / 4], u1 = p[LDS_PITCH / 4 + 1], u2 = p[LDS_PITCH / 4 + 2];
@@ -606,30 +619,30 @@ __global__ __launch_bounds__(64 * WG_WAVES) MF_WARP_ATTR void warp_kernel(const 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // a[j].x = B0 G0 R0 B1, a[j].y = G1 R1 . .   (pixel ix, pixel ix+1 of row iy; b: row iy+1)
+                // per channel the two horizontal neighbours side by side in 16-bit fields: X0 | X1 << 16
+                const uint32_t Ba = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C030C00u), Bb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C030C00u);
+                const uint32_t Ga = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C040C01u), Gb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C040C01u);
+                const uint32_t Ra = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C050C02u), Rb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C050C02u);
+                // vertical lerp of both fields at once (each <= 255 * 32: no carry between them)
+                const uint32_t fy = by[j] & 31u, wy = 32u - fy;
+                const uint32_t vB = umad24(Bb, fy, __umul24(Ba, wy));
+                const uint32_t vG = umad24(Gb, fy, __umul24(Ga, wy));
+                const uint32_t vR = umad24(Rb, fy, __umul24(Ra, wy));
+                // horizontal lerp: v_dot2_u32_u16 with the weight pair (32 - fx, fx) scaled by 64, so that ((sum + 512) >> 10)
+                // lands in byte 2:  (sum + 512) * 64 < 2^24
                 const uint32_t fx = bx[j] & 31u;
-                // weight pairs (32 - fx, fx) placed on the bytes they multiply, one v_mad_u32_u24 each:
-                // (32 - fx) | fx << 24 = 32 + fx (2^24 - 1), (32 - fx) | fx << 8 = 32 + 255 fx, and that << 16
-                const uint32_t wb = umad24(fx, 0xFFFFFFu, 32u);         // bytes 0 and 3 of .x  (B0, B1)
-                const uint32_t wg = umad24(fx, 255u, 32u);              // bytes 0, 1 of the permuted dword (G0, G1)
-                const uint32_t wr = umad24(fx, 0xFF0000u, 0x200000u);   // bytes 2, 3 (R0, R1)
-                const uint32_t pa = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x05020401u);   // G0 G1 R0 R1
-                const uint32_t pb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x05020401u);
-                // horizontal lerps (<= 255*32), v_dot4_u32_u8
-                const uint32_t hBa = __builtin_amdgcn_udot4(a[j].x, wb, 0u, false), hBb = __builtin_amdgcn_udot4(b[j].x, wb, 0u, false);
-                const uint32_t hGa = __builtin_amdgcn_udot4(pa, wg, 0u, false), hGb = __builtin_amdgcn_udot4(pb, wg, 0u, false);
-                const uint32_t hRa = __builtin_amdgcn_udot4(pa, wr, 0u, false), hRb = __builtin_amdgcn_udot4(pb, wr, 0u, false);
-                // vertical lerp scaled by 64 so that ((sum + 512) >> 10) lands in byte 2:  (sum + 512) * 64 < 2^24
-                const uint32_t fy6 = (by[j] << 6) & 0x7C0u, wy6 = 2048u - fy6;
-                oB[j] = umad24(wy6, hBa, umad24(fy6, hBb, 32768u));
-                oG[j] = umad24(wy6, hGa, umad24(fy6, hGb, 32768u));
-                oR[j] = umad24(wy6, hRa, umad24(fy6, hRb, 32768u));
+                const uint32_t wq = umad24(fx, 0x3FFFC0u, 2048u);       // 64 (32 - fx) | 64 fx << 16
+                oB[j] = udot2(vB, wq, 32768u);
+                oG[j] = udot2(vG, wq, 32768u);
+                oR[j] = udot2(vR, wq, 32768u);
             }
-            // the 12 result bytes sit in byte 2 of the 12 sums: 9 v_perm_b32 gather them into B0 G0 R0 B1 | G1 R1 B2 G2 |
-            // R2 B3 G3 R3  (pair = byte 2 of `lo` then byte 2 of `hi`; join = two low bytes of each pair)
-            const uint32_t pair = 0x0C0C0602u, join = 0x05040100u;
-            d.x = __builtin_amdgcn_perm(__builtin_amdgcn_perm(oB[1], oR[0], pair), __builtin_amdgcn_perm(oG[0], oB[0], pair), join);
-            d.y = __builtin_amdgcn_perm(__builtin_amdgcn_perm(oG[2], oB[2], pair), __builtin_amdgcn_perm(oR[1], oG[1], pair), join);
-            d.z = __builtin_amdgcn_perm(__builtin_amdgcn_perm(oR[3], oG[3], pair), __builtin_amdgcn_perm(oB[3], oR[2], pair), join);
+            // the 12 result bytes sit in byte 2 of the 12 sums: 6 v_perm_b32 + 3 v_or_b32 gather them into B0 G0 R0 B1 | G1 R1 B2 G2 |
+            // R2 B3 G3 R3  (pair = byte 2 of `lo` then byte 2 of `hi` in the two low bytes, zeros above)
+            const uint32_t pair = 0x0C0C0602u;
+            const uint32_t pair_hi = 0x06020C0Cu;                         // the same pair in the two high bytes: v_or joins them
+            d.x = __builtin_amdgcn_perm(oB[1], oR[0], pair_hi) | __builtin_amdgcn_perm(oG[0], oB[0], pair);
+            d.y = __builtin_amdgcn_perm(oG[2], oB[2], pair_hi) | __builtin_amdgcn_perm(oR[1], oG[1], pair);
+            d.z = __builtin_amdgcn_perm(oR[3], oG[3], pair_hi) | __builtin_amdgcn_perm(oB[3], oR[2], pair);
             }
         } else {
             // generic path: frame borders, uncovered pixels, crop flags, out-of-range coordinates
