@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
 template <typename EdgeOf, typename HiOf>
 __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, const int* s_gx, const int* s_gy, int xa, int xb,
                                                    int ya, int yb, int rxlo, int rylo, int rxhi, int ryhi, int W, int H, int R,
-                                                   int C, FootPlan& p, uint32_t& region)
+                                                   int C, FootPlan& p, FootRegion& region)
 {
     // cells whose grid rect, widened by the frame's reach, meets the footprint (contiguous index ranges)
     // (start from the uniform-grid estimate, then walk the exact vertex coordinates: a step or two)
@@ -376,7 +376,8 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
         const float gmin = (fminf(a * cxs[0], a * cxs[1]) + fminf(b * cys[0], b * cys[1])) + c;
         covered = gmin > 2.0f * ((float)(W > H ? W : H) * (1.0f / 16384.0f)) + 1.0f;
     }
-    region = 0;
+    region.flags_origin = 0;
+    region.src_dwords = 0;
     if (sane && cnt > 0 && !overflow && (W & 3) == 0 && 3 * W >= MF_STAGE_PITCH && H > MF_STAGE_ROWS &&
         umin > -4.0f && vmin > -4.0f && umax < 40000.0f && vmax < 40000.0f) {
         // taps of a pixel at (u, v): columns floor(u) .. floor(u)+1 up to 1/64 px of rounding -> one pixel of slack
@@ -384,8 +385,16 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
         const int iy_lo = (int)floorf(vmin) - 1, iy_hi = (int)floorf(vmax) + 2;
         const int sx0 = min(max(ix_lo, 0), (3 * W - MF_STAGE_PITCH) / 3), sy0 = min(max(iy_lo, 0), H - MF_STAGE_ROWS - 1);
         if (ix_lo >= sx0 && ix_hi <= sx0 + MF_STAGE_COLS - 1 && iy_lo >= sy0 && iy_hi <= sy0 + MF_STAGE_ROWS - 1)
-            region = MF_REGION_STAGED | ((uint32_t)sy0 << 15) | (uint32_t)sx0 |
-                     (covered && ix_lo >= 2 && ix_hi <= W - 3 && iy_lo >= 2 && iy_hi <= H - 3 ? MF_REGION_DEEP : 0u);
+        {
+            // DEEP also asks for a whole footprint (all 256 pixels inside the frame): its lanes are then all active
+            const bool whole = xb - xa == MF_FOOT_W - 1 && yb - ya == MF_FOOT_H - 1;
+            const bool deep = covered && whole && ix_lo >= 2 && ix_hi <= W - 3 && iy_lo >= 2 && iy_hi <= H - 3;
+            const uint32_t bs = (3u * (uint32_t)sx0) & ~3u;
+            region.flags_origin = MF_REGION_STAGED | (deep ? MF_REGION_DEEP : 0u) | ((uint32_t)sy0 * MF_STAGE_PITCH + bs);
+            region.src_dwords = ((uint32_t)sy0 * (3u * (uint32_t)W) + bs) >> 2;
+            if (deep && p.e[1] == (uint16_t)MF_PLAN_UNIT && (p.e[0] & (MF_PLAN_VALID | MF_PLAN_IN)) == (MF_PLAN_VALID | MF_PLAN_IN))
+                p.e[1] = (uint16_t)(MF_PLAN_UNIT | MF_PLAN_HOT);
+        }
     }
 }
 
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
                                                              const double* __restrict__ records,
                                                              const int32_t* __restrict__ reach,
                                                              const int32_t* __restrict__ grid, int n, int W, int H, int R,
-                                                             int C, FootPlan* __restrict__ plan, uint32_t* __restrict__ regions)
+                                                             int C, FootPlan* __restrict__ plan, FootRegion* __restrict__ regions)
 {
     __shared__ int s_gx[66], s_gy[66];
     __shared__ float s_edge[kPlanStageCells * MF_EDGE_FLOATS];
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     const int xa = fx * MF_FOOT_W, xb = min(xa + MF_FOOT_W - 1, W - 1);
     const int ya = fy * MF_FOOT_H, yb = min(ya + MF_FOOT_H - 1, H - 1);
     FootPlan p;
-    uint32_t region;
+    FootRegion region;
     if (staged) {
         const int k0 = rb_lo * C;
         plan_one_footprint([&](int k) { return (const float*)&s_edge[(k - k0) * MF_EDGE_FLOATS]; },

@@ -22,14 +22,14 @@ struct alignas(8) CellBox { int16_t x0, y0, x1, y1; };
 
 inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 
-// Layout of the cell table blob (mf_cell_table_bytes): records | boxes | edges | plan | reach | grid.
+// Layout of the cell table blob (mf_cell_table_bytes): records | boxes | edges | plan | regions | reach | grid.
 //   records: n*R*C x MF_CELL_DOUBLES float64      (ABI, include/meshflow_hip.h)
 //   boxes:   n*R*C x CellBox                      compact copy of the record's bbox
 //   edges:   n*R*C x MF_EDGE_FLOATS float32       4 affine edge functions {a, b, c} (cell_table.hip)
 //   plan:    n x ceil(H/8) x ceil(W/32) x 16 B    per 32x8-pixel footprint: candidate cells, descending
+//   regions: n x ceil(H/8) x ceil(W/32) x 8 B     per footprint: source region the warp kernel stages in LDS
 //   reach:   n x 4 int32                          per-frame max extent of a box beyond its grid rect
 //   grid:    (C+1) + (R+1) int32                  vertex x / y pixel coordinates
-//   regions: n x ceil(H/8) x ceil(W/32) x 4 B     per footprint: source region the warp kernel stages in LDS
 #define MF_EDGE_FLOATS 12
 #define MF_FOOT_W 32
 #define MF_FOOT_H 8
@@ -48,12 +48,22 @@ inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 // denominator on this footprint: 0.52 < w < 1.9 at the four corners (hence on every pixel: w is affine) and |h6| <= 0.9 * 2.5e-4 *
 // min(w)^2, the condition of the warp kernel's reciprocal guess -- the kernel skips both per-pixel tests.
 #define MF_PLAN_UNIT 0x0001u
+// ... and MF_PLAN_HOT (only with UNIT) that the footprint needs nothing else either: it lies completely inside the frame and its source
+// region is STAGED and DEEP (below).  The warp kernel then runs its straight-line path: no lane masks, no per-pixel checks.
+// (bit 13: clear in every valid entry -- cell indices take bits 0-11 -- and in the raw row / column numbers of an overflow list, so
+// the kernel tests this one bit without looking at the rest of the list)
+#define MF_PLAN_HOT 0x2000u
 struct alignas(16) FootPlan { uint16_t e[8]; };
-// Source region of a footprint (uint32): bits 0-14 first source column sx0, bits 15-29 first source row sy0,
-// bit 31 = STAGED: every bilinear tap of every pixel of the footprint lies in columns sx0 .. sx0+MF_STAGE_COLS-1 and
-// rows sy0 .. sy0+MF_STAGE_ROWS-1, and rows sy0 .. sy0+MF_STAGE_ROWS are inside the frame.  The warp kernel then
-// copies MF_STAGE_CHUNKS 16-byte chunks (rows of MF_STAGE_PITCH bytes starting at the dword holding column sx0) into
-// LDS with two global->LDS loads per lane and reads the taps from there.
+// Source region of a footprint (FootRegion).  STAGED: every bilinear tap of every pixel of the footprint lies in columns sx0 ..
+// sx0+MF_STAGE_COLS-1 and rows sy0 .. sy0+MF_STAGE_ROWS-1 of the source frame, and rows sy0 .. sy0+MF_STAGE_ROWS are inside the
+// frame.  The warp kernel then copies MF_STAGE_CHUNKS 16-byte chunks (rows of MF_STAGE_PITCH bytes starting at the dword that
+// holds column sx0, byte bs = 3 sx0 & ~3 of the row) into LDS with two global->LDS loads per lane and reads the taps from there.
+// What the kernel needs is stored ready-made (the scalar unit is as busy as the vector unit there):
+//   flags_origin: bit 31 STAGED, bit 30 DEEP, bits 0-22 origin = MF_STAGE_PITCH sy0 + bs  (tap (ix, iy) sits at LDS byte
+//                 MF_STAGE_PITCH iy + 3 ix - origin of the window)
+//   src_dwords:   (row_bytes sy0 + bs) / 4, the window's first dword in the frame (a frame is below 4 GB)
+struct alignas(8) FootRegion { uint32_t flags_origin, src_dwords; };
+#define MF_REGION_ORIGIN_MASK 0x007FFFFFu
 #define MF_STAGE_PITCH 160
 #define MF_STAGE_ROWS 12
 #define MF_STAGE_COLS 52
@@ -64,7 +74,7 @@ struct alignas(16) FootPlan { uint16_t e[8]; };
 #define MF_REGION_DEEP 0x40000000u
 #define MF_STAGE_CHUNKS 128            // two 16-byte chunks per lane: 12 rows x 10 chunks + 8 chunks of a 13th row (unused)
 struct TableView {
-    double* records; CellBox* boxes; float* edges; FootPlan* plan; int32_t* reach; int32_t* grid; uint32_t* regions;
+    double* records; CellBox* boxes; float* edges; FootPlan* plan; FootRegion* regions; int32_t* reach; int32_t* grid;
 };
 inline size_t plan_count(int n, int W, int H)
 {
@@ -77,7 +87,7 @@ inline size_t plan_offset(int n, int R, int C)
 }
 inline size_t table_bytes(int n, int W, int H, int R, int C)
 {
-    return plan_offset(n, R, C) + plan_count(n, W, H) * (sizeof(FootPlan) + sizeof(uint32_t)) +
+    return plan_offset(n, R, C) + plan_count(n, W, H) * (sizeof(FootPlan) + sizeof(FootRegion)) +
            (size_t)n * 4 * sizeof(int32_t) + (size_t)(R + C + 2) * sizeof(int32_t);
 }
 inline TableView table_view(void* blob, int n, int W, int H, int R, int C)
@@ -88,9 +98,9 @@ inline TableView table_view(void* blob, int n, int W, int H, int R, int C)
     v.boxes = (CellBox*)(v.records + nrec * MF_CELL_DOUBLES);
     v.edges = (float*)(v.boxes + nrec);
     v.plan = (FootPlan*)((char*)blob + plan_offset(n, R, C));
-    v.reach = (int32_t*)(v.plan + plan_count(n, W, H));
+    v.regions = (FootRegion*)(v.plan + plan_count(n, W, H));
+    v.reach = (int32_t*)(v.regions + plan_count(n, W, H));
     v.grid = v.reach + (size_t)n * 4;
-    v.regions = (uint32_t*)(v.grid + (R + C + 2));
     return v;
 }
 
@@ -142,6 +152,17 @@ inline bool make_tile_order(int tiles_x, int tiles_y, int n, TileOrder& o)
 }
 
 
+
+// Launch constants of the warp kernel (host-made: the kernel's scalar unit has none to spare).  Grid = (8 * per_xcd, frames): the
+// workgroups of a frame go to the 8 XCDs round-robin by blockIdx.x, workgroup L takes footprint (L % 8) * per_xcd + L / 8, so
+// every XCD sweeps one contiguous eighth of each frame in raster order.  All table offsets are 32-bit: launch_warp cuts a clip
+// that would overflow them into several launches.
+struct WarpGeom {
+    uint32_t per_frame, per_xcd, nfx;            // footprints per frame, per XCD and frame, per row
+    uint32_t div_m, div_s, div_pass;             // t / nfx = (mulhi(t, div_m) + (t & div_pass)) >> div_s
+    uint32_t frame_bytes, row_bytes;             // 3 W H, 3 W
+    uint32_t rec_frame_bytes, edge_frame_bytes;  // R C records / edge sets of one frame
+};
 
 // Launchers (defined next to their kernels).
 int launch_jacobi(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,

@@ -51,7 +51,7 @@
 // At most 80 scalar registers: a CU admits min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) workgroups of 256 threads
 // (MI355X_MICROARCH.md), i.e. 7 with the 94 the compiler would take and 8 with 80 (the excess is kept in VGPR lanes, the kernel
 // stays at 64 VGPRs): -1.7 % kernel time.
-#define MF_WARP_ATTR __attribute__((amdgpu_num_sgpr(80)))
+#define MF_WARP_ATTR __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
 
 namespace mf {
 
@@ -65,14 +65,10 @@ typedef const __attribute__((address_space(4))) float* cedge_t;
 // a multi-wave workgroup keeps the slots of its finished wavefronts until the slowest one -- often on a slower ownership
 // path -- is done: 4 x 1 wavefronts 1.516 ms (cfg2) / 3.410 (cfg3), 2 x 1: 1.505 / 3.392, 1 x 1: 1.492 / 3.326; 4 x 2 and 4 x 4
 // (fewer dispatches) 1.65 / 1.89.
-constexpr int WAVES_X = 1;      // wavefronts side by side in a workgroup
-constexpr int TILE_W = 32 * WAVES_X;
+// More than one footprint per wavefront (a vertical stack, or a run along x with the next footprint's plan and window prefetched
+// into a second LDS buffer behind counted vmcnt waits) is slower as well: 2 per wavefront +4 %, 4 per wavefront +9 %.
 constexpr int FOOT_W = MF_FOOT_W;   // 8 lanes x 4 pixels
 constexpr int FOOT_H = MF_FOOT_H;   // 64 lanes / 8
-constexpr int FOOTS = 1;        // footprints per wavefront (1 measured best: 1.83 ms vs 2.01 at 2, 1.95 at 4)
-constexpr int WAVES_Y = 1;      // wavefront rows per workgroup
-constexpr int WG_WAVES = WAVES_X * WAVES_Y;
-constexpr int TILE_H = FOOT_H * FOOTS * WAVES_Y;
 constexpr int MAX_MESH = 64;    // R, C <= 64
 // A pixel's owner is kept as the byte offset of the owner's row in the wavefront's s_hi block (80-byte rows, one per list
 // entry).  Row 8 holds the matrix {0, 0, W+1; 0, 0, H+1; 0, 0, 1}: a pixel no cell covers runs through the same arithmetic and
@@ -107,15 +103,15 @@ __device__ __forceinline__ int cv_round_f32(float v)
 }
 
 // One source pixel as B | G << 8 | R << 16, or the border colour when (tx, ty) is outside the frame.
-// `limit` = bytes from the frame base to the end of the whole frame stack, so the 4-byte load of the
+// `limit` = bytes from the frame base to the end of the whole frame stack (saturated to 32 bits), so the 4-byte load of the
 // very last pixel is shifted back by one byte instead of running past the allocation.
 __device__ __forceinline__ uint32_t fetch_bgr(const uint8_t* __restrict__ frame, int W, int H, int tx, int ty,
-                                              uint32_t border, size_t limit)
+                                              uint32_t border, uint32_t limit)
 {
     if ((unsigned)tx < (unsigned)W && (unsigned)ty < (unsigned)H) {
         const uint32_t o = ((uint32_t)ty * (uint32_t)W + (uint32_t)tx) * 3u;
         uint32_t v;
-        if ((size_t)o + 4 <= limit) {
+        if (o + 4u <= limit) {
             __builtin_memcpy(&v, frame + o, 4);
         } else {
             __builtin_memcpy(&v, frame + o - 1, 4);
@@ -288,80 +284,177 @@ __device__ __forceinline__ uint32_t cell_mask_test(crec_t rec, double xs0, doubl
     return ok & unowned;
 }
 
-__global__ __launch_bounds__(64 * WG_WAVES) MF_WARP_ATTR void warp_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out,
-                                                   const double* __restrict__ records,
-                                                   const float* __restrict__ edges,
-                                                   const FootPlan* __restrict__ plan, const uint32_t* __restrict__ regions,
-                                                   int stage_ok, float edge_margin, TileOrder order, int n, int W, int H, int R, int C,
-                                                   uint32_t border, int32_t* __restrict__ crop)
+// cv2.remap's fixed point: sx = rint(32 u) by the 1.5*2^23 trick -- the fma rounds 32u + magic once, to nearest even, and the integer
+// sits in the low mantissa bits (valid for |32u| < 2^22; anything else lands far outside the "deep interior" window and is redone
+// exactly by the generic path).  Raw float bits of 32u + 1.5*2^23: the low 22 bits hold sx for 0 <= sx < 2^22.
+__device__ __forceinline__ void fixed_point(const float (&u)[4], const float (&v)[4], uint32_t (&bx)[4], uint32_t (&by)[4])
 {
-    // inverse homographies of a footprint's candidate cells, per wavefront: [entry][Hi0..Hi8, pad] (80-byte rows)
-    __shared__ __attribute__((aligned(16))) double s_hi[WG_WAVES][9][10];        // row 8: the "no cell" matrix, see OWN_NONE
-    // source region of the footprint, per wavefront: MF_STAGE_ROWS rows of MF_STAGE_PITCH bytes (+ slack for the
-    // third dword of the last tap)
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[WG_WAVES][LDS_WINDOW_BYTES + 64];
-    // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2: with the
-    // natural order the four neighbours of a tile -- whose staged source windows overlap this tile's by 60 % -- would
-    // all run on other XCDs and each L2 would fetch the shared rows again.  Workgroup L therefore takes tile
-    // (L % 8) * ceil(T / 8) + L / 8: every XCD sweeps one contiguous eighth of the clip in raster order.
-    // (divisions by multiply-high with host-made constants: everything stays on the scalar unit)
-    int f, tile_y, tile_x;
-    if (!order.decode(blockIdx.x, f, tile_y, tile_x)) return;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps plan/record loads scalar
-    const int lane = threadIdx.x & 63;
-    const int wave_x = wave % WAVES_X, wave_y = wave / WAVES_X;
-    const int xa = tile_x * TILE_W + wave_x * FOOT_W;                // footprint x range starts here
-    if (xa >= W) return;                                                 // whole wave outside the frame
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bx[j] = __float_as_uint(__builtin_fmaf(u[j], 32.0f, 12582912.0f));
+        by[j] = __float_as_uint(__builtin_fmaf(v[j], 32.0f, 12582912.0f));
+    }
+}
+
+// The 2 x 2 taps of the lane's four pixels from the staged window: a[j] = B0 G0 R0 B1 | G1 R1 . . of row iy (pixel ix, pixel ix+1),
+// b[j] the same of row iy + 1.  `lds_origin`: LDS byte address of tap (ix, iy) = LDS_PITCH iy + 3 ix - lds_origin.
+__device__ __forceinline__ void gather_staged(const uint32_t (&bx)[4], const uint32_t (&by)[4], uint32_t lds_origin, uint2 (&a)[4], uint2 (&b)[4])
+{
+    // taps from the staged region: three dwords around byte 160 iy + 3 ix of each of the two rows,
+    // shifted down by the byte misalignment (v_alignbyte takes the low two bits of the address)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // ix = bits[5..21] of the raw float; bits[22..28] (the 1.5*2^23 pattern, constant) ride along in the 24-bit
+        // multiplier operand and are taken out again through the origin: one v_lshrrev (half the issue cost of v_bfe)
+        const uint32_t at = umad24(by[j] >> 5, (uint32_t)LDS_PITCH,
+                                   umad24(bx[j] >> 5, 3u, 0u - lds_origin - MAGIC_HI * (3u + (uint32_t)LDS_PITCH)));
+        const uint32_t* __restrict__ p = (const uint32_t*)(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(at & ~3u);
+        const uint32_t t0 = p[0], t1 = p[1], t2 = p[2];
+        const uint32_t u0 = p[LDS_PITCH / 4], u1 = p[LDS_PITCH / 4 + 1], u2 = p[LDS_PITCH / 4 + 2];
+        a[j].x = __builtin_amdgcn_alignbyte(t1, t0, at);
+        a[j].y = __builtin_amdgcn_alignbyte(t2, t1, at);
+        b[j].x = __builtin_amdgcn_alignbyte(u1, u0, at);
+        b[j].y = __builtin_amdgcn_alignbyte(u2, u1, at);
+    }
+}
+
+// The same straight from the frame (two unaligned 8-byte loads per pixel), for footprints without a staged window.
+__device__ __forceinline__ void gather_global(const uint32_t (&bx)[4], const uint32_t (&by)[4], const uint8_t* __restrict__ src, int W, uint2 (&a)[4], uint2 (&b)[4])
+{
+    const uint8_t* __restrict__ src1 = src + 3u * (uint32_t)W;   // row iy + 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // ix = sx >> 5 = bits[5..21] (0x4B400000 >> 5 has no low 17 bits), same for iy
+        const uint32_t t = umad24(__builtin_amdgcn_ubfe(by[j], 5, 17), (uint32_t)W, __builtin_amdgcn_ubfe(bx[j], 5, 17));
+        const uint32_t o = t + (t << 1);
+        __builtin_memcpy(&a[j], src + o, 8);
+        __builtin_memcpy(&b[j], src1 + o, 8);
+    }
+}
+
+// cv2.remap's bilinear blend (integer, 1/32-pixel weights) of the lane's four pixels: the 12 output bytes B0 G0 R0 B1 | G1 R1 B2 G2 |
+// R2 B3 G3 R3.
+__device__ __forceinline__ uint3 blend(const uint32_t (&bx)[4], const uint32_t (&by)[4], const uint2 (&a)[4], const uint2 (&b)[4])
+{
+    uint3 d;
+    uint32_t oB[4], oG[4], oR[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // a[j].x = B0 G0 R0 B1, a[j].y = G1 R1 . .   (pixel ix, pixel ix+1 of row iy; b: row iy+1)
+        // per channel the two horizontal neighbours side by side in 16-bit fields: X0 | X1 << 16
+        const uint32_t Ba = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C030C00u), Bb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C030C00u);
+        const uint32_t Ga = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C040C01u), Gb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C040C01u);
+        const uint32_t Ra = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C050C02u), Rb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C050C02u);
+        // vertical lerp of both fields at once (each <= 255 * 32: no carry between them)
+        const uint32_t fy = by[j] & 31u, wy = 32u - fy;
+        const uint32_t vB = umad24(Bb, fy, __umul24(Ba, wy));
+        const uint32_t vG = umad24(Gb, fy, __umul24(Ga, wy));
+        const uint32_t vR = umad24(Rb, fy, __umul24(Ra, wy));
+        // horizontal lerp: v_dot2_u32_u16 with the weight pair (32 - fx, fx) scaled by 64, so that ((sum + 512) >> 10)
+        // lands in byte 2:  (sum + 512) * 64 < 2^24
+        const uint32_t fx = bx[j] & 31u;
+        const uint32_t wq = umad24(fx, 0x3FFFC0u, 2048u);       // 64 (32 - fx) | 64 fx << 16
+        oB[j] = udot2(vB, wq, 32768u);
+        oG[j] = udot2(vG, wq, 32768u);
+        oR[j] = udot2(vR, wq, 32768u);
+    }
+    // the 12 result bytes sit in byte 2 of the 12 sums: 6 v_perm_b32 + 3 v_or_b32 gather them into B0 G0 R0 B1 | G1 R1 B2 G2 |
+    // R2 B3 G3 R3  (pair = byte 2 of `lo` then byte 2 of `hi` in the two low bytes, zeros above)
+    const uint32_t pair = 0x0C0C0602u;
+    const uint32_t pair_hi = 0x06020C0Cu;                         // the same pair in the two high bytes: v_or joins them
+    d.x = __builtin_amdgcn_perm(oB[1], oR[0], pair_hi) | __builtin_amdgcn_perm(oG[0], oB[0], pair);
+    d.y = __builtin_amdgcn_perm(oG[2], oB[2], pair_hi) | __builtin_amdgcn_perm(oR[1], oG[1], pair);
+    d.z = __builtin_amdgcn_perm(oR[3], oG[3], pair_hi) | __builtin_amdgcn_perm(oB[3], oR[2], pair);
+    return d;
+}
+
+// STAGE_OK: the clip is 4-byte aligned, so the plan's STAGED windows can be copied by 16-byte global->LDS loads (always the case
+// for buffers from hipMalloc / torch; the other instantiation ignores the windows).
+template <bool STAGE_OK>
+__global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out,
+                                                               const double* __restrict__ records, const float* __restrict__ edges,
+                                                               const FootPlan* __restrict__ plan, const FootRegion* __restrict__ regions,
+                                                               float edge_margin, WarpGeom g, int n, int W, int H, int C,
+                                                               uint32_t border, int32_t* __restrict__ crop)
+{
+    // inverse homographies of the footprint's candidate cells: [entry][Hi0..Hi8, pad] (80-byte rows)
+    __shared__ __attribute__((aligned(16))) double s_hi[1][9][10];                // row 8: the "no cell" matrix, see OWN_NONE
+    // source region of the footprint: MF_STAGE_ROWS rows of MF_STAGE_PITCH bytes (+ slack for the third dword of the last tap)
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[LDS_WINDOW_BYTES + 64];
+    constexpr int wave = 0;
+    // XCD-aware footprint order.  Workgroups go to the 8 XCDs round-robin by linear id (blockIdx.x first: gridDim.x is a multiple of
+    // 8), and each XCD has its own L2: in raster order the four neighbours of a footprint -- whose staged windows overlap its own
+    // by 60 % -- would all run on other XCDs and each L2 would fetch the shared rows again.  Workgroup L of frame blockIdx.y
+    // therefore takes footprint (L % 8) * per_xcd + L / 8: every XCD sweeps one contiguous eighth of each frame in raster order.
+    // (Everything up to the plan is scalar, with host-made constants and 32-bit offsets: the scalar unit is as loaded as the vector
+    // unit in this kernel -- profiles/README.md -- and every s_ instruction here is paid by each of the 2.4 M wavefronts of a clip.)
+    const uint32_t f = blockIdx.y;
+    const uint32_t t = (blockIdx.x & 7u) * g.per_xcd + (blockIdx.x >> 3);
+    if (t >= g.per_frame) return;
+    const uint32_t ty = (__umulhi(t, g.div_m) + (t & g.div_pass)) >> g.div_s, tx = t - ty * g.nfx;
+    const int xa = (int)(tx * (uint32_t)FOOT_W), ya = (int)(ty * (uint32_t)FOOT_H);
+    const int lane = threadIdx.x;
+    const uint32_t fp = f * g.per_frame + t;                              // the footprint's slot in plan / regions
+    typedef const __attribute__((address_space(4))) uint32_t* cword_t;
+    const cword_t pw = (cword_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(plan) + 16u * fp);
+    const cword_t rw = (cword_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(regions) + 8u * fp);
+    const uint4 pv = make_uint4(pw[0], pw[1], pw[2], pw[3]);             // wave-uniform: scalar loads
+    const uint32_t rg = rw[0], src_dwords = rw[1];
+    const uint8_t* __restrict__ src = frames + (uint64_t)f * g.frame_bytes;
+    const bool staged = STAGE_OK && (rg & MF_REGION_STAGED) != 0;
+    if (staged) {
+        // Source region -> LDS, asynchronously (global_load_lds: no VGPRs, no ds_write): lane i fetches the i-th and (64+i)-th
+        // 16-byte chunk of the window (10 chunks = 160 bytes per row), which land at LDS offsets 16 i and 1024 + 16 i.
+        // chunk i sits at row i / 10, byte 16 (i % 10) of the window = byte (i / 10) (row_bytes - 160) + 16 i from gbase;
+        // uniform base + opaque 32-bit lane offset keeps the address arithmetic 32-bit (saddr + voffset form)
+        const uint8_t* __restrict__ gbase = src + ((uint64_t)src_dwords << 2);
+        uint32_t o0 = __umul24(((uint32_t)lane * 205u) >> 11, g.row_bytes - (uint32_t)MF_STAGE_PITCH) + ((uint32_t)lane << 4);
+        uint32_t o1 = __umul24((((uint32_t)lane + 64u) * 205u) >> 11, g.row_bytes - (uint32_t)MF_STAGE_PITCH) +
+                      (((uint32_t)lane << 4) + 1024u);
+        asm("" : "+v"(o0));
+        asm("" : "+v"(o1));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o0),
+                                         (__attribute__((address_space(3))) void*)&s_src[0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o1),
+                                         (__attribute__((address_space(3))) void*)&s_src[1024], 16, 0, 0);
+    }
+    // taps are addressed by absolute LDS byte address (= LDS_PITCH iy + 3 ix - lds_origin): the window base is folded in
+    const uint32_t lds_origin = (rg & MF_REGION_ORIGIN_MASK) - (uint32_t)(uintptr_t)&s_src[0];
+    const crec_t frec = (crec_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(records) + f * g.rec_frame_bytes);
+    const int y = ya + (lane >> 3);
     const int x0 = xa + (lane & 7) * 4;                                  // first of this lane's 4 pixels
-    const int ncell = R * C;
-    const int nfx = (W + FOOT_W - 1) / FOOT_W, nfy = (H + FOOT_H - 1) / FOOT_H;
+    const double xs0 = (double)x0, yy = (double)y;
 
-    const size_t frame_bytes = (size_t)W * H * 3;
-    const uint8_t* __restrict__ src = frames + (size_t)f * frame_bytes;
-    uint8_t* __restrict__ dst = out + (size_t)f * frame_bytes;
-    const size_t limit = (size_t)(n - f) * frame_bytes;
-    const crec_t frec = (crec_t)(uintptr_t)(records + (size_t)f * ncell * MF_CELL_DOUBLES);
-    const cedge_t fedge = (cedge_t)(uintptr_t)(edges + (size_t)f * ncell * MF_EDGE_FLOATS);
-    const uint4* __restrict__ fplan = reinterpret_cast<const uint4*>(plan) + ((size_t)f * nfy * nfx + (tile_x * (TILE_W / FOOT_W) + wave_x));
-    const uint32_t* __restrict__ fregion = regions + ((size_t)f * nfy * nfx + (tile_x * (TILE_W / FOOT_W) + wave_x));
+    if (STAGE_OK && (pv.x & (MF_PLAN_HOT << 16)) != 0) {
+        // The plan certifies everything (~2/3 of the footprints at config-2 geometry): ONE cell owns all 256 pixels, its
+        // denominator allows the trimmed reciprocal (UNIT), the footprint lies inside the frame, its window is staged and every
+        // tap is at least two pixels inside the frame (DEEP: no crop flag either).  Straight-line code, all lanes active.
+        float u[4], v[4];
+        cell_coords<false>(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy, x0, 0xFu, u, v, true);
+        uint32_t bx[4], by[4];
+        fixed_point(u, v, bx, by);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the window has landed in LDS
+        uint2 a[4], b[4];
+        gather_staged(bx, by, lds_origin, a, b);
+        const uint3 d = blend(bx, by, a, b);
+        uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
+        *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;     // (STAGED implies W % 4 == 0)
+        return;
+    }
 
+    // Everything else: several candidate cells, uncertified denominators, frame borders, uncovered pixels.
+    uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
+    const uint32_t limit = (int)f == n - 1 ? g.frame_bytes : 0xFFFFFFFFu;   // only the last frame has nothing behind it
+    const cedge_t fedge = (cedge_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(edges) + f * g.edge_frame_bytes);
     const float fWm1 = (float)(W - 1), fHm1 = (float)(H - 1);
     const bool fast_store = (W & 3) == 0;
-    const double xs0 = (double)x0;
-
-#pragma unroll 1
-    for (int q = 0; q < FOOTS; ++q) {
-        const int ya = tile_y * TILE_H + (wave_y * FOOTS + q) * FOOT_H;
-        if (ya >= H) break;
-        const int y = ya + (lane >> 3);
-        const double yy = (double)y;
-        const uint4 pv = fplan[(size_t)((tile_y * WAVES_Y + wave_y) * FOOTS + q) * nfx];   // wave-uniform: scalar load
-        const uint32_t rg = fregion[(size_t)((tile_y * WAVES_Y + wave_y) * FOOTS + q) * nfx];
-        // Source region -> LDS, asynchronously (global_load_lds: no VGPRs, no ds_write): lane i fetches the i-th and
-        // (64+i)-th 16-byte chunk of the window (10 chunks = 160 bytes per row), which land at LDS offsets 16 i and
-        // 1024 + 16 i.
-        const bool staged = (rg & MF_REGION_STAGED) != 0 && stage_ok != 0;
-        uint32_t lds_origin = 0;                                          // LDS byte address = LDS_PITCH iy + 3 ix - lds_origin
-        if (staged) {
-            const uint32_t sx0 = rg & 0x7FFFu, sy0 = (rg >> 15) & 0x7FFFu;
-            const uint32_t bs = (3u * sx0) & ~3u;                         // dword holding the first column
-            const uint32_t row_bytes = 3u * (uint32_t)W;
-            const uint8_t* __restrict__ gbase = src + (size_t)sy0 * row_bytes + bs;
-            // chunk i sits at row i / 10, byte 16 (i % 10) of the window = byte (i / 10) (row_bytes - 160) + 16 i from gbase;
-            // uniform base + opaque 32-bit lane offset keeps the address arithmetic 32-bit (saddr + voffset form)
-            uint32_t o0 = __umul24(((uint32_t)lane * 205u) >> 11, row_bytes - (uint32_t)MF_STAGE_PITCH) + ((uint32_t)lane << 4);
-            uint32_t o1 = __umul24((((uint32_t)lane + 64u) * 205u) >> 11, row_bytes - (uint32_t)MF_STAGE_PITCH) +
-                          (((uint32_t)lane << 4) + 1024u);
-            asm("" : "+v"(o0));
-            asm("" : "+v"(o1));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o0),
-                                             (__attribute__((address_space(3))) void*)&s_src[wave][0], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o1),
-                                             (__attribute__((address_space(3))) void*)&s_src[wave][1024], 16, 0, 0);
-            // taps are addressed by absolute LDS byte address: the wavefront's window base is folded into the origin
-            lds_origin = sy0 * (uint32_t)LDS_PITCH + bs - (uint32_t)(uintptr_t)&s_src[wave][0];
-        }
-
+    // active = y < H && x0 < W, built on the scalar unit as a lane mask (rows_in rows of the footprint, and in each the first
+    // cols_in groups of four pixels, start inside the frame) and turned into the branch condition without a v_cmp
+    const int rows_in = min(FOOT_H, H - ya), cols_in = min(FOOT_W / 4, (W - xa + 3) >> 2);
+    const uint32_t row_bits = ((1u << cols_in) - 1u) * 0x01010101u;
+    const uint64_t lanes_in = (((uint64_t)row_bits << 32) | row_bits) & (~0ull >> (64 - 8 * rows_in));
+    const bool active = __builtin_amdgcn_inverse_ballot_w64(lanes_in);
+    {
         // Source coordinates of the lane's 4 pixels; (W+1, H+1) = "no cell covers it" (mfs.py:983-984).
         float u[4], v[4];
         if ((pv.x & (MF_PLAN_IN | MF_PLAN_VALID)) == (MF_PLAN_IN | MF_PLAN_VALID) && (pv.w >> 16) != MF_PLAN_OVERFLOW) {
@@ -370,10 +463,12 @@ __global__ __launch_bounds__(64 * WG_WAVES) MF_WARP_ATTR void warp_kernel(const 
         } else if ((pv.w >> 16) == MF_PLAN_OVERFLOW) {
             // more than 8 candidate cells: test every cell of the recorded range, last cell first
             uint32_t unowned = 0;
+            int Wp = W + 1, Hp = H + 1;                      // (opaque: keeps the conversions inside this rare branch)
+            asm volatile("" : "+s"(Wp), "+s"(Hp));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                u[j] = (float)(W + 1);
-                v[j] = (float)(H + 1);
+                u[j] = (float)Wp;
+                v[j] = (float)Hp;
                 if (x0 + j < W && y < H) unowned |= 1u << j;
             }
             const int r_lo = pv.x & 0xFFFF, c_lo = pv.y & 0xFFFF, c_hi = pv.y >> 16;
@@ -415,8 +510,11 @@ __global__ __launch_bounds__(64 * WG_WAVES) MF_WARP_ATTR void warp_kernel(const 
                 }
             }
             uint32_t own[4];                                            // byte offset of the owner's matrix row (OWN_ROW * entry)
-            if (!(rg & MF_REGION_DEEP) && lane < 10)                    // only uncertified footprints can have uncovered pixels
-                s_hi[wave][8][lane] = lane == 2 ? (double)(W + 1) : lane == 5 ? (double)(H + 1) : lane == 8 ? 1.0 : 0.0;
+            if (!(rg & MF_REGION_DEEP) && lane < 10) {                  // only uncertified footprints can have uncovered pixels
+                int Wp = W + 1, Hp = H + 1;                              // (opaque: keeps the conversions inside this branch)
+                asm volatile("" : "+s"(Wp), "+s"(Hp));
+                s_hi[wave][8][lane] = lane == 2 ? (double)Wp : lane == 5 ? (double)Hp : lane == 8 ? 1.0 : 0.0;
+            }
             const float yf = (float)y, xf0 = (float)x0;
             // The common shape -- exactly two cells, each with ONE mask edge crossing the footprint (a footprint on the
             // border between two cells): one fma per pixel and cell decides, straight-line.
@@ -446,7 +544,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) MF_WARP_ATTR void warp_kernel(const 
                         near = fminf(near, fabsf(g));
                     }
                 }
-                general = __ballot(!(near > edge_margin) && y < H && x0 < W) != 0;
+                general = __ballot(!(near > edge_margin) && active) != 0;
             }
             if (pair) {
                 const cedge_t eb = fedge + (pv.x & 0xFFFu) * MF_EDGE_FLOATS + 3u * cd0;            // later cell: wins
@@ -461,7 +559,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) MF_WARP_ATTR void warp_kernel(const 
                     near = fminf(near, fminf(fabsf(gb), fabsf(ga)));
                 }
                 // a pixel inside the float32 error band of a mask edge (or NaN coefficients): the general path decides exactly
-                general = __ballot(!(near > edge_margin) && y < H && x0 < W) != 0;
+                general = __ballot(!(near > edge_margin) && active) != 0;
             }
             if (general) {
             uint32_t unowned = 0;
@@ -550,28 +648,13 @@ __global__ __launch_bounds__(64 * WG_WAVES) MF_WARP_ATTR void warp_kernel(const 
         }
 
         // cv2.remap: 1/32-pixel fixed point (round half to even), bilinear gather, store.
-        const bool active = y < H && x0 < W;
-        // sx = rint(32 u) by the 1.5*2^23 trick: fma rounds 32u + magic once, to nearest even, and the
-        // integer sits in the low mantissa bits (valid for |32u| < 2^22; anything else lands far outside
-        // the "deep interior" window below and is redone exactly by the generic path).
-        // Raw float bits of 32u + 1.5*2^23: the low 22 bits hold sx = rint(32u) for 0 <= sx < 2^22.
         uint32_t bx[4], by[4];
-        bool fast;
-        if (staged && (rg & MF_REGION_DEEP)) {
-            // the plan certifies that every pixel has an owner and every tap lies at least two pixels inside the
-            // frame (hence no crop flag either): nothing to check
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bx[j] = __float_as_uint(__builtin_fmaf(u[j], 32.0f, 12582912.0f));
-                by[j] = __float_as_uint(__builtin_fmaf(v[j], 32.0f, 12582912.0f));
-            }
-            fast = true;
-        } else {
+        fixed_point(u, v, bx, by);
+        bool fast = true;
+        if (!(staged && (rg & MF_REGION_DEEP))) {        // (DEEP: every pixel has an owner and every tap is deep inside: nothing to check)
             uint32_t dxm = 0, dym = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                bx[j] = __float_as_uint(__builtin_fmaf(u[j], 32.0f, 12582912.0f));
-                by[j] = __float_as_uint(__builtin_fmaf(v[j], 32.0f, 12582912.0f));
                 dxm = max(dxm, bx[j] - (0x4B400000u + 64u));
                 dym = max(dym, by[j] - (0x4B400000u + 64u));
             }
@@ -582,67 +665,14 @@ __global__ __launch_bounds__(64 * WG_WAVES) MF_WARP_ATTR void warp_kernel(const 
             fast = __ballot(active && !deep) == 0;
         }
         uint3 d;                                                        // the lane's 12 output bytes
-        if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the region has landed in LDS
+        if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window has landed in LDS
         if (fast) {
             // fast path (wave-uniform): every pixel of the footprint samples the deep interior
             if (active) {
-            uint2 a[4], b[4];
-            if (staged) {
-                // taps from the staged region: three dwords around byte 160 iy + 3 ix of each of the two rows,
-                // shifted down by the byte misalignment (v_alignbyte takes the low two bits of the address)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // ix = bits[5..21] of the raw float; bits[22..28] (the 1.5*2^23 pattern, constant) ride along in the 24-bit
-                    // multiplier operand and are taken out again through the origin: one v_lshrrev (half the issue cost of v_bfe)
-                    const uint32_t at = umad24(by[j] >> 5, (uint32_t)LDS_PITCH,
-                                               umad24(bx[j] >> 5, 3u, 0u - lds_origin - MAGIC_HI * (3u + (uint32_t)LDS_PITCH)));
-                    const uint32_t* __restrict__ p = (const uint32_t*)(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(at & ~3u);
-                    const uint32_t t0 = p[0], t1 = p[1], t2 = p[2];
-                    const uint32_t u0 = p[LDS_PITCH / 4], u1 = p[LDS_PITCH / 4 + 1], u2 = p[LDS_PITCH / 4 + 2];
-                    a[j].x = __builtin_amdgcn_alignbyte(t1, t0, at);
-                    a[j].y = __builtin_amdgcn_alignbyte(t2, t1, at);
-                    b[j].x = __builtin_amdgcn_alignbyte(u1, u0, at);
-                    b[j].y = __builtin_amdgcn_alignbyte(u2, u1, at);
-                }
-            } else {
-                const uint8_t* __restrict__ src1 = src + 3u * (uint32_t)W;   // row iy + 1
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // ix = sx >> 5 = bits[5..21] (0x4B400000 >> 5 has no low 17 bits), same for iy
-                    const uint32_t t = umad24(__builtin_amdgcn_ubfe(by[j], 5, 17), (uint32_t)W, __builtin_amdgcn_ubfe(bx[j], 5, 17));
-                    const uint32_t o = t + (t << 1);
-                    __builtin_memcpy(&a[j], src + o, 8);
-                    __builtin_memcpy(&b[j], src1 + o, 8);
-                }
-            }
-            uint32_t oB[4], oG[4], oR[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // a[j].x = B0 G0 R0 B1, a[j].y = G1 R1 . .   (pixel ix, pixel ix+1 of row iy; b: row iy+1)
-                // per channel the two horizontal neighbours side by side in 16-bit fields: X0 | X1 << 16
-                const uint32_t Ba = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C030C00u), Bb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C030C00u);
-                const uint32_t Ga = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C040C01u), Gb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C040C01u);
-                const uint32_t Ra = __builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C050C02u), Rb = __builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C050C02u);
-                // vertical lerp of both fields at once (each <= 255 * 32: no carry between them)
-                const uint32_t fy = by[j] & 31u, wy = 32u - fy;
-                const uint32_t vB = umad24(Bb, fy, __umul24(Ba, wy));
-                const uint32_t vG = umad24(Gb, fy, __umul24(Ga, wy));
-                const uint32_t vR = umad24(Rb, fy, __umul24(Ra, wy));
-                // horizontal lerp: v_dot2_u32_u16 with the weight pair (32 - fx, fx) scaled by 64, so that ((sum + 512) >> 10)
-                // lands in byte 2:  (sum + 512) * 64 < 2^24
-                const uint32_t fx = bx[j] & 31u;
-                const uint32_t wq = umad24(fx, 0x3FFFC0u, 2048u);       // 64 (32 - fx) | 64 fx << 16
-                oB[j] = udot2(vB, wq, 32768u);
-                oG[j] = udot2(vG, wq, 32768u);
-                oR[j] = udot2(vR, wq, 32768u);
-            }
-            // the 12 result bytes sit in byte 2 of the 12 sums: 6 v_perm_b32 + 3 v_or_b32 gather them into B0 G0 R0 B1 | G1 R1 B2 G2 |
-            // R2 B3 G3 R3  (pair = byte 2 of `lo` then byte 2 of `hi` in the two low bytes, zeros above)
-            const uint32_t pair = 0x0C0C0602u;
-            const uint32_t pair_hi = 0x06020C0Cu;                         // the same pair in the two high bytes: v_or joins them
-            d.x = __builtin_amdgcn_perm(oB[1], oR[0], pair_hi) | __builtin_amdgcn_perm(oG[0], oB[0], pair);
-            d.y = __builtin_amdgcn_perm(oG[2], oB[2], pair_hi) | __builtin_amdgcn_perm(oR[1], oG[1], pair);
-            d.z = __builtin_amdgcn_perm(oR[3], oG[3], pair_hi) | __builtin_amdgcn_perm(oB[3], oR[2], pair);
+                uint2 a[4], b[4];
+                if (staged) gather_staged(bx, by, lds_origin, a, b);
+                else gather_global(bx, by, src, W, a, b);
+                d = blend(bx, by, a, b);
             }
         } else {
             // generic path: frame borders, uncovered pixels, crop flags, out-of-range coordinates
@@ -706,7 +736,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) MF_WARP_ATTR void warp_kernel(const 
         }
         if (active) {                                                   // the lane's 12 output bytes
             const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
-            if (fast_store && x0 + 3 < W) {
+            if (fast_store) {                                           // W % 4 == 0: an active lane's four pixels are all inside
                 *reinterpret_cast<uint3*>(dst + o) = d;
             } else {
                 const int nb = 3 * min(4, W - x0);                       // W % 4 != 0: byte by byte, up to the row end
@@ -772,20 +802,46 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
         set_error("mf_warp_u8c3: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
         return MF_ERR_INVALID_ARG;
     }
-    TileOrder order;
-    if (!make_tile_order((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H, n, order)) {
-        set_error("mf_warp_u8c3: too many tiles");
+    WarpGeom g;
+    const uint32_t nfx = (uint32_t)((W + FOOT_W - 1) / FOOT_W), nfy = (uint32_t)((H + FOOT_H - 1) / FOOT_H);
+    const FastDiv by_row = make_fast_div(nfx);
+    g.per_frame = nfx * nfy;
+    g.per_xcd = (g.per_frame + 7u) / 8u;
+    g.nfx = nfx;
+    g.div_m = by_row.m; g.div_s = by_row.s; g.div_pass = nfx == 1u ? 0xFFFFFFFFu : 0u;
+    g.frame_bytes = 3u * (uint32_t)W * (uint32_t)H;
+    g.row_bytes = 3u * (uint32_t)W;
+    g.rec_frame_bytes = (uint32_t)(R * C) * (uint32_t)(MF_CELL_DOUBLES * sizeof(double));
+    g.edge_frame_bytes = (uint32_t)(R * C) * (uint32_t)(MF_EDGE_FLOATS * sizeof(float));
+    // frames per launch: the grid's y extent, and 32-bit byte offsets into the plan (16 B per footprint) and the records
+    const uint64_t cap = 0xFFFFFFFFull;
+    uint64_t per_launch = 65535;
+    per_launch = per_launch < cap / (16ull * g.per_frame) ? per_launch : cap / (16ull * g.per_frame);
+    per_launch = per_launch < cap / g.rec_frame_bytes ? per_launch : cap / g.rec_frame_bytes;
+    if (per_launch == 0) {
+        set_error("mf_warp_u8c3: frame too large");
         return MF_ERR_INVALID_ARG;
     }
-    const dim3 grid(order.per_xcd * 8u);                          // one workgroup per 128 x 8 tile, XCD-swizzled in the kernel
     // staging reads dword-aligned 16-byte chunks: needs a 4-byte aligned clip (W % 4 == 0 is checked by the plan)
-    const int stage_ok = ((uintptr_t)frames & 3u) == 0 ? 1 : 0;
+    const bool stage_ok = ((uintptr_t)frames & 3u) == 0;
     // float32 edge functions (cell_table.hip) reach |g| <= V = 32 max(W, H) (1/32-px units); two fmas and three rounded
     // coefficients put the evaluation within 2.5 V 2^-23 of the exact value.  The kernel trusts the float32 sign only
     // beyond six times that, max(W, H) 2^-14 (0.12 at 1080p), and decides in float64 inside the band.
     const float edge_margin = (float)(W > H ? W : H) * (1.0f / 16384.0f);
-    hipLaunchKernelGGL(warp_kernel, grid, dim3(64 * WG_WAVES), 0, st, frames, out, tv.records, tv.edges, tv.plan, tv.regions, stage_ok, edge_margin, order, n, W, H, R, C, border,
-                       crop);
+    for (int f0 = 0; f0 < n; f0 += (int)per_launch) {
+        const int m = n - f0 < (int)per_launch ? n - f0 : (int)per_launch;
+        const dim3 grid(g.per_xcd * 8u, (uint32_t)m);                  // one wavefront per 32 x 8 footprint
+        const uint8_t* fr = frames + (size_t)f0 * g.frame_bytes;
+        uint8_t* o = out + (size_t)f0 * g.frame_bytes;
+        const double* rec = tv.records + (size_t)f0 * R * C * MF_CELL_DOUBLES;
+        const float* ed = tv.edges + (size_t)f0 * R * C * MF_EDGE_FLOATS;
+        const FootPlan* pl = tv.plan + (size_t)f0 * g.per_frame;
+        const FootRegion* rgn = tv.regions + (size_t)f0 * g.per_frame;
+        if (stage_ok)
+            hipLaunchKernelGGL(warp_kernel<true>, grid, dim3(64), 0, st, fr, o, rec, ed, pl, rgn, edge_margin, g, m, W, H, C, border, crop + 4 * (size_t)f0);
+        else
+            hipLaunchKernelGGL(warp_kernel<false>, grid, dim3(64), 0, st, fr, o, rec, ed, pl, rgn, edge_margin, g, m, W, H, C, border, crop + 4 * (size_t)f0);
+    }
     return hip_fail(hipGetLastError(), "warp_kernel launch");
 }
 

@@ -21,8 +21,8 @@ plan_off = (nrec * (32 * 8 + 8 + 12 * 4) + 15) & ~15
 nfx, nfy = (W + 31) // 32, (H + 7) // 8
 npl = n * nfx * nfy
 plan = buf[plan_off:plan_off + npl * 16].view(np.uint16).reshape(npl, 8)
-reg_off = plan_off + npl * 16 + n * 16 + (R + C + 2) * 4
-regions = buf[reg_off:reg_off + npl * 4].view(np.uint32)
+reg_off = plan_off + npl * 16                                   # regions follow the plan: 8 bytes per footprint, word 0 = flags | origin
+regions = buf[reg_off:reg_off + npl * 8].view(np.uint32)[0::2]
 valid = (plan & 0x4000) != 0
 overflow = plan[:, 7] == 0xFFFF
 ne = np.where(overflow, 9, valid[:, :4].sum(1) + np.where(valid[:, :4].all(1), valid[:, 4:].sum(1), 0))
@@ -45,4 +45,5 @@ g2 = general & (ne == 2)
 print(f'general by shape: ne=1 {(general & (ne == 1)).mean():.4f}  ne=2 {g2.mean():.4f} (of which closed by an IN cell {(g2 & inn[:, 1]).mean():.4f}, '
       f'two-edge codes {(g2 & ~inn[:, 1] & (((cd[:, 0] | cd[:, 1]) & 8) != 0)).mean():.4f})  ne=3 {(general & (ne == 3)).mean():.4f}  '
       f'ne=4 {(general & (ne == 4)).mean():.4f}  ne>4 {(general & (ne > 4)).mean():.4f}')
-print(f'staged {((regions >> 31) & 1).mean():.4f}  certified interior {((regions >> 30) & 1).mean():.4f}')
+hot = (plan[:, 1] & 0x6000) == 0x2000                          # MF_PLAN_HOT without VALID: the warp kernel's straight-line path
+print(f'staged {((regions >> 31) & 1).mean():.4f}  certified interior {((regions >> 30) & 1).mean():.4f}  hot (single + unit + deep + whole) {hot.mean():.4f}')
