@@ -368,14 +368,15 @@ __device__ __forceinline__ uint3 blend(const uint32_t (&bx)[4], const uint32_t (
     return d;
 }
 
+
 // STAGE_OK: the clip is 4-byte aligned, so the plan's STAGED windows can be copied by 16-byte global->LDS loads (always the case
 // for buffers from hipMalloc / torch; the other instantiation ignores the windows).
 template <bool STAGE_OK>
-__global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out,
-                                                               const double* __restrict__ records, const float* __restrict__ edges,
-                                                               const FootPlan* __restrict__ plan, const FootRegion* __restrict__ regions,
-                                                               float edge_margin, WarpGeom g, int n, int W, int H, int C,
-                                                               uint32_t border, int32_t* __restrict__ crop)
+__global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* __restrict__ plan, const FootRegion* __restrict__ regions,
+                                                               WarpGeom g, const uint8_t* __restrict__ frames,
+                                                               const double* __restrict__ records, uint8_t* __restrict__ out,
+                                                               const float* __restrict__ edges, float edge_margin, int n, int W,
+                                                               int H, int C, uint32_t border, int32_t* __restrict__ crop)
 {
     // inverse homographies of the footprint's candidate cells: [entry][Hi0..Hi8, pad] (80-byte rows)
     __shared__ __attribute__((aligned(16))) double s_hi[1][9][10];                // row 8: the "no cell" matrix, see OWN_NONE
@@ -838,9 +839,9 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
         const FootPlan* pl = tv.plan + (size_t)f0 * g.per_frame;
         const FootRegion* rgn = tv.regions + (size_t)f0 * g.per_frame;
         if (stage_ok)
-            hipLaunchKernelGGL(warp_kernel<true>, grid, dim3(64), 0, st, fr, o, rec, ed, pl, rgn, edge_margin, g, m, W, H, C, border, crop + 4 * (size_t)f0);
+            hipLaunchKernelGGL(warp_kernel<true>, grid, dim3(64), 0, st, pl, rgn, g, fr, rec, o, ed, edge_margin, m, W, H, C, border, crop + 4 * (size_t)f0);
         else
-            hipLaunchKernelGGL(warp_kernel<false>, grid, dim3(64), 0, st, fr, o, rec, ed, pl, rgn, edge_margin, g, m, W, H, C, border, crop + 4 * (size_t)f0);
+            hipLaunchKernelGGL(warp_kernel<false>, grid, dim3(64), 0, st, pl, rgn, g, fr, rec, o, ed, edge_margin, m, W, H, C, border, crop + 4 * (size_t)f0);
     }
     return hip_fail(hipGetLastError(), "warp_kernel launch");
 }
@@ -877,3 +878,4 @@ int launch_crop_reduce(const int32_t* crop, int n, int W, int H, int32_t* bounds
 }
 
 }  // namespace mf
+
