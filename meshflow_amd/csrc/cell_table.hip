@@ -313,6 +313,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
     float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
     bool sane = true;
     float wlo = 1e30f, whi = -1e30f, h6_first = 0.0f;          // denominator range of the FIRST listed cell over the footprint
+    float wlo_all = 1e30f, whi_all = -1e30f;                   // ... and of every listed cell
     float single_edge[2][3] = { { 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f } };   // the one uncertain edge of the first two entries
     bool single_ok[2] = { false, false };
     for (int r = r_hi; r >= r_lo && !closed && !overflow; --r)
@@ -350,6 +351,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
                 const float w = h[6] * cx + h[7] * cy + h[8];
                 sane = sane && w > 0.25f && w < 4.0f;                     // (NaN fails)
                 if (cnt == 1) { wlo = fminf(wlo, w); whi = fmaxf(whi, w); h6_first = h[6]; }
+                wlo_all = fminf(wlo_all, w); whi_all = fmaxf(whi_all, w);
                 const float iw = 1.0f / w;
                 const float u = (h[0] * cx + h[1] * cy + h[2]) * iw, v = (h[3] * cx + h[4] * cy + h[5]) * iw;
                 umin = fminf(umin, u); umax = fmaxf(umax, u);
@@ -394,6 +396,9 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
             region.src_dwords = ((uint32_t)sy0 * (3u * (uint32_t)W) + bs) >> 2;
             if (deep && p.e[1] == (uint16_t)MF_PLAN_UNIT && (p.e[0] & (MF_PLAN_VALID | MF_PLAN_IN)) == (MF_PLAN_VALID | MF_PLAN_IN))
                 p.e[1] = (uint16_t)(MF_PLAN_UNIT | MF_PLAN_HOT);
+            // the pair shape (`covered`: the second cell is IN, or the two single-edge masks overlap across the footprint)
+            if (deep && !overflow && cnt == 2 && single_ok[0] && !(p.e[0] & MF_PLAN_IN) && wlo_all > 0.52f && whi_all < 1.9f)
+                p.e[2] = (uint16_t)MF_PLAN_HOT;
         }
     }
 }

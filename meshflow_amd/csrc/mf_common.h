@@ -53,6 +53,11 @@ inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 // (bit 13: clear in every valid entry -- cell indices take bits 0-11 -- and in the raw row / column numbers of an overflow list, so
 // the kernel tests this one bit without looking at the rest of the list)
 #define MF_PLAN_HOT 0x2000u
+// A list of exactly TWO cells leaves entries 2 and 3 unused; MF_PLAN_HOT in entry 2 then certifies the "pair" shape: the first
+// (later, winning) cell is MIXED with ONE mask edge that can fail inside the footprint (its code in e[4]); whatever it does not take
+// belongs to the second cell (which is IN, or single-edge with the pair covering every pixel); both denominators stay in
+// (0.52, 1.9); the footprint is whole and its region STAGED and DEEP.  The kernel decides ownership with one float32 edge function
+// per pixel and never looks at the second cell's edges.
 struct alignas(16) FootPlan { uint16_t e[8]; };
 // Source region of a footprint (FootRegion).  STAGED: every bilinear tap of every pixel of the footprint lies in columns sx0 ..
 // sx0+MF_STAGE_COLS-1 and rows sy0 .. sy0+MF_STAGE_ROWS-1 of the source frame, and rows sy0 .. sy0+MF_STAGE_ROWS are inside the

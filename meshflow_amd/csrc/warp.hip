@@ -443,10 +443,61 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
         return;
     }
 
-    // Everything else: several candidate cells, uncertified denominators, frame borders, uncovered pixels.
+    const cedge_t fedge = (cedge_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(edges) + f * g.edge_frame_bytes);
+    if (STAGE_OK && (pv.y & MF_PLAN_HOT) != 0) {
+        // Two cells share the footprint and the plan certifies the rest (a quarter of the footprints at config-2 geometry, 45 % at
+        // config 3): the later cell wins wherever ONE of its mask edges passes -- one float32 fma per pixel -- and the other cell
+        // owns what is left; denominators, window and interior as on the hot path.  Both inverse homographies go to LDS by
+        // global->LDS DMA (one 80-byte load per cell, scalar base address), and every pixel reads its owner's row.
+        const uint32_t k0 = pv.x & 0xFFFu, k1 = (pv.x >> 16) & 0xFFFu;
+        if (lane < 20) {
+            const uint32_t lo4 = (uint32_t)lane << 2;
+            const uint8_t* __restrict__ g0 = (const uint8_t*)(uintptr_t)(frec + k0 * MF_CELL_DOUBLES + MF_CELL_OFF_HI);
+            const uint8_t* __restrict__ g1 = (const uint8_t*)(uintptr_t)(frec + k1 * MF_CELL_DOUBLES + MF_CELL_OFF_HI);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + lo4),
+                                             (__attribute__((address_space(3))) void*)&s_hi[0][0][0], 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g1 + lo4),
+                                             (__attribute__((address_space(3))) void*)&s_hi[0][1][0], 4, 0, 0);
+        }
+        const cedge_t eb = fedge + k0 * MF_EDGE_FLOATS + 3u * (pv.z & 3u);
+        const float rb = __builtin_fmaf(eb[1], (float)y, eb[2]), xf0 = (float)x0;
+        uint32_t own[4];
+        float near = 1e30f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gb = __builtin_fmaf(eb[0], xf0 + (float)j, rb);
+            own[j] = gb > edge_margin ? 0u : OWN_ROW;
+            near = fminf(near, fabsf(gb));
+        }
+        // (a pixel inside the float32 error band of the edge, or NaN coefficients: the general code below decides exactly)
+        if (__ballot(!(near > edge_margin)) == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // matrices and window have landed in LDS
+            float u[4], v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double* hp = reinterpret_cast<const double*>(reinterpret_cast<const uint8_t*>(&s_hi[0][0][0]) + own[j]);
+                const double2 h01 = *reinterpret_cast<const double2*>(hp), h23 = *reinterpret_cast<const double2*>(hp + 2);
+                const double2 h45 = *reinterpret_cast<const double2*>(hp + 4), h67 = *reinterpret_cast<const double2*>(hp + 6);
+                const double h8 = hp[8];
+                const double xs = xs0 + (double)j;
+                const double iw = recip_unit_range((xs * h67.x + yy * h67.y) + h8);
+                u[j] = (float)(((xs * h01.x + yy * h01.y) + h23.x) * iw);
+                v[j] = (float)(((xs * h23.y + yy * h45.x) + h45.y) * iw);
+            }
+            uint32_t bx[4], by[4];
+            fixed_point(u, v, bx, by);
+            uint2 a[4], b[4];
+            gather_staged(bx, by, lds_origin, a, b);
+            const uint3 d = blend(bx, by, a, b);
+            uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
+            *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;
+            return;
+        }
+    }
+
+    // Everything else: more candidate cells, uncertified denominators, frame borders, uncovered pixels.
     uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
     const uint32_t limit = (int)f == n - 1 ? g.frame_bytes : 0xFFFFFFFFu;   // only the last frame has nothing behind it
-    const cedge_t fedge = (cedge_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(edges) + f * g.edge_frame_bytes);
     const float fWm1 = (float)(W - 1), fHm1 = (float)(H - 1);
     const bool fast_store = (W & 3) == 0;
     // active = y < H && x0 < W, built on the scalar unit as a lane mask (rows_in rows of the footprint, and in each the first
