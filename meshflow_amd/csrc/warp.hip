@@ -47,6 +47,7 @@
 // skeleton without coordinates and blend already takes 0.77 of the 1.28 ms; the wavefronts are latency-bound, throughput
 // follows occupancy), profiles/.
 #include "mf_common.h"
+#include <stdlib.h>
 
 // At most 80 scalar registers: a CU admits min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) workgroups of 256 threads
 // (MI355X_MICROARCH.md), i.e. 7 with the 94 the compiler would take and 8 with 80 (the excess is kept in VGPR lanes, the kernel
@@ -873,6 +874,10 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
     if (per_launch == 0) {
         set_error("mf_warp_u8c3: frame too large");
         return MF_ERR_INVALID_ARG;
+    }
+    if (const char* e = getenv("MF_WARP_FRAMES_PER_LAUNCH")) {      // testing aid: forces the multi-launch split on small clips
+        const long v = atol(e);
+        if (v > 0 && (uint64_t)v < per_launch) per_launch = (uint64_t)v;
     }
     // staging reads dword-aligned 16-byte chunks: needs a 4-byte aligned clip (W % 4 == 0 is checked by the plan)
     const bool stage_ok = ((uintptr_t)frames & 3u) == 0;

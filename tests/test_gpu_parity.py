@@ -163,6 +163,8 @@ def _hip_warp(dev, frames, R, C, unstab, stab, border=(0, 0, 255)):
     (130, 260, 16, 16, dict(jitter_sigma=0.3)),                     # small cells, 256 of them
     (96, 160, 32, 32, dict(translation_sigma=1.0, field_sigma=0.3)),  # 1024 cells
     (360, 640, 16, 16, dict(translation_sigma=8.0, jitter_sigma=2.0)),   # demo-video size, strong motion
+    (272, 480, 3, 4, dict(jitter_sigma=0.5)),                       # cells of 120 x 90 pixels: mostly the plan-certified hot and pair paths
+    (272, 480, 2, 2, dict(translation_sigma=3.0, jitter_sigma=1.5)),
 ])
 def test_warp_bit_exact_vs_c_oracle(dev, H, W, R, C, kw):
     from oracle import clib
@@ -175,6 +177,22 @@ def test_warp_bit_exact_vs_c_oracle(dev, H, W, R, C, kw):
         want, want_crop = clib.warp_frame(frames[f], R, C, table)          # brute-force owner search
         np.testing.assert_array_equal(out[f], want)
         np.testing.assert_array_equal(crop[f], want_crop)
+
+
+def test_warp_clip_cut_into_several_launches(dev, monkeypatch):
+    """launch_warp cuts a clip whose table offsets would not fit 32 bits into several launches (frames, tables and crop rows
+    offset per launch); MF_WARP_FRAMES_PER_LAUNCH forces the cut on a small clip: same bytes, same crop rows."""
+    frames, disp, stab = _clip(7, 136, 256, 3, 4, seed=11, jitter_sigma=0.7)
+    whole = _hip_warp(dev, frames, 3, 4, disp, stab)
+    monkeypatch.setenv('MF_WARP_FRAMES_PER_LAUNCH', '3')
+    cut = _hip_warp(dev, frames, 3, 4, disp, stab)
+    np.testing.assert_array_equal(cut[0], whole[0])
+    np.testing.assert_array_equal(cut[1], whole[1])
+    from oracle import clib
+    want, want_crop, bad = clib.warp_clip(frames, 3, 4, disp, stab)
+    assert bad == 0
+    np.testing.assert_array_equal(cut[0], want)
+    np.testing.assert_array_equal(cut[1], want_crop)
 
 
 @pytest.mark.parametrize('H,W,R,C,sigma,seed', [
