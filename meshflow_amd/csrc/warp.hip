@@ -16,36 +16,36 @@
 // oracle (oracle/warp_oracle.c).
 //
 // Mapping (gfx950).  One wavefront = one workgroup = one 32 x 8 pixel "footprint" of one frame; a lane owns 4 consecutive pixels
-// of one row (12 contiguous output bytes -> one global_store_dwordx3).  Footprints are handed out XCD-aware (mf_common.h
-// TileOrder).  Per footprint:
-//   1. footprint_plan_kernel (cell_table.hip) wrote the wave-uniform PLAN (one scalar load): up to 8 candidate cells
-//      in descending order, each IN (all 256 pixels pass its mask test) or MIXED, with -- for short lists -- the one or two
-//      mask edges that can fail; and the footprint's SOURCE REGION, the window of the source frame that holds every
-//      bilinear tap of every pixel, with two certificates (DEEP: every pixel has an owner and every tap is interior;
-//      UNIT: the projective denominator stays in (0.52, 1.9) and varies slowly enough for the reciprocal guess).
+// of one row (12 contiguous output bytes -> one global_store_dwordx3).  Grid = (8 * per_xcd, frames): footprints are handed out
+// XCD-aware (mf_common.h WarpGeom).  Per footprint:
+//   1. footprint_plan_kernel (cell_table.hip) wrote the wave-uniform PLAN (two scalar loads): up to 8 candidate cells in
+//      descending order, each IN (all 256 pixels pass its mask test) or MIXED, with -- for short lists -- the one or two mask
+//      edges that can fail; the footprint's SOURCE REGION, the window of the source frame that holds every bilinear tap of
+//      every pixel, ready-made as LDS origin + first dword in the frame; and certificates: STAGED, DEEP (the footprint lies in
+//      the frame, every pixel has an owner and every tap is interior), UNIT (the projective denominator stays in (0.52, 1.9)
+//      and varies slowly enough for the reciprocal guess), and the two path bits HOT and PAIR.
 //   2. The window goes to LDS asynchronously: two global_load_lds_dwordx4 per lane, issued first, awaited after the
 //      coordinate arithmetic.
-//   3. One IN cell (~66 % of footprints at config-2 geometry): no per-pixel test; the cell's Hi comes in through
-//      scalar loads and the four coordinates are straight-line float64 code.  1/w: pixel 0 by v_rcp_f64 + Newton + the
-//      residual correction that makes it the IEEE quotient; pixels 1..3 start from pixel 0's reciprocal (second-order
-//      guess + ONE Newton step + the same correction: no v_rcp_f64, two fma less).
-//   4. Two cells with one uncertain edge each (~25 %): one float32 fma per pixel and cell decides ownership; the four
-//      cells around a mesh vertex: two per cell.  Otherwise the general last-cell-first loop.  A pixel inside the float32
-//      error band of an edge is decided by a division-free float64 comparison, and by OpenCV's exact arithmetic
-//      (division, rint) only within 1e-6 of the edge.  The candidates' Hi go to LDS by global->LDS DMA (one 80-byte load
-//      per candidate, scalar base address); a pixel's owner is kept as the byte offset of its matrix row, and "no owner"
-//      is a ninth row holding the matrix that maps every pixel to (W+1, H+1) -- the coordinate code has no special case.
-//   5. cv2.remap: sx = rint(32u) via one fma against 1.5*2^23; taps = three dword LDS reads per pixel and row +
-//      v_alignbyte_b32 (gfx950 does read LDS at unaligned addresses, but 1.4x slower overall); per channel v_perm_b32 puts
-//      the two horizontal neighbours into 16-bit fields, v_mul_u32_u24 + v_mad_u32_u24 lerp both fields vertically at
-//      once, v_dot2_u32_u16 lerps horizontally with weights scaled so that the rounded byte lands in byte 2; six v_perm_b32
-//      + three v_or_b32 gather the lane's 12 output bytes.  Footprints the plan
-//      could not certify (frame border, uncovered pixels, oversized or unaligned windows) check per pixel and use either
-//      two unaligned 8-byte global loads per pixel or the per-tap path with border colour and crop flags.
-// Algorithmic HBM traffic: 2*H*W*3 bytes per frame (each source byte read once, each output byte written
-// once); measured 1.02x that.  No dense contraction: no MFMA.  What bounds it: DESIGN.md section 4.3 (ablations: the
-// skeleton without coordinates and blend already takes 0.77 of the 1.28 ms; the wavefronts are latency-bound, throughput
-// follows occupancy), profiles/.
+//   3. HOT (one IN cell, everything certified; ~65 % of footprints at config-2 geometry): straight-line code.  The cell's Hi
+//      comes in through scalar loads; 1/w: pixel 0 by v_rcp_f64 + Newton + the residual correction that makes it the IEEE
+//      quotient; pixels 1..3 start from pixel 0's reciprocal (second-order guess + ONE Newton step + the same correction).
+//   4. PAIR (two cells, ~27 %): the later cell wins where ONE of its mask edges passes (one float32 fma per pixel), the other
+//      owns the rest; both Hi go to LDS by global->LDS DMA (one 80-byte load per cell, scalar base address) and a pixel's
+//      owner is the byte offset of its matrix row.  A pixel inside the float32 error band of the edge sends the wavefront to 5.
+//   5. Everything else: the general last-cell-first loop over the list.  A pixel inside the error band of an edge is decided
+//      by a division-free float64 comparison, and by OpenCV's exact arithmetic (division, rint) only within 1e-6 of the edge;
+//      "no owner" is a ninth LDS row holding the matrix that maps every pixel to (W+1, H+1) -- the coordinate code has no
+//      special case.  Footprints the plan could not certify (frame border, uncovered pixels, oversized or unaligned windows)
+//      check per pixel and use either two unaligned 8-byte global loads per pixel or the per-tap path with border colour and
+//      crop flags.
+//   6. cv2.remap: sx = rint(32u) via one fma against 1.5*2^23; taps = LDS byte loads straight into the blend's layout (the two
+//      horizontal neighbours of a channel in the 16-bit halves of a register); v_mul_u32_u24 + v_mad_u32_u24 lerp both halves
+//      vertically at once, v_dot2_u32_u16 lerps horizontally with weights scaled so that the rounded byte lands in byte 2; six
+//      v_perm_b32 + three v_or_b32 gather the lane's 12 output bytes.
+// Algorithmic HBM traffic: 2*H*W*3 bytes per frame (each source byte read once, each output byte written once); measured
+// 1.05x that.  No dense contraction: no MFMA.  What bounds it: vector AND scalar instruction issue, not HBM -- DESIGN.md
+// section 4.3, profiles/r02_phase_profile.txt.  Everything a wavefront needs before its pixels is therefore host-made
+// (WarpGeom) or plan-made (FootRegion): the hot path issues 222 vector and 74 scalar instructions per wavefront.
 #include "mf_common.h"
 #include <stdlib.h>
 
@@ -297,29 +297,83 @@ __device__ __forceinline__ void fixed_point(const float (&u)[4], const float (&v
     }
 }
 
-// The 2 x 2 taps of the lane's four pixels from the staged window: a[j] = B0 G0 R0 B1 | G1 R1 . . of row iy (pixel ix, pixel ix+1),
-// b[j] the same of row iy + 1.  `lds_origin`: LDS byte address of tap (ix, iy) = LDS_PITCH iy + 3 ix - lds_origin.
-__device__ __forceinline__ void gather_staged(const uint32_t (&bx)[4], const uint32_t (&by)[4], uint32_t lds_origin, uint2 (&a)[4], uint2 (&b)[4])
+// Taps + blend of a footprint with a staged window.  The taps come from the staged window by BYTE loads with immediate offsets, already in the
+// layout the blend wants -- per pixel and channel the two horizontal neighbours in the 16-bit halves of one register (X0 | X1 << 16),
+// for rows iy and iy + 1: ds_read_u8 delivers X0 in the low byte of one register, ds_read_u8_d16_hi X1 in bits 16-23 of another
+// (with SRAM ECC a d16 load zeroes the other half instead of preserving it: measured), and one v_or_b32 (a 2-cycle instruction) joins
+// them.  Against three ds_read2_b32 + four v_alignbyte_b32 + six v_perm_b32 per pixel that is 28 VALU issue cycles per pixel less
+// (the LDS pipe takes 12 byte loads per pixel instead; it has the room).  The compiler does not see these loads, so the waits are
+// placed here.
+struct TapRegs { uint32_t lo[6], hi[6]; };      // {B, G, R} of row iy, then of row iy + 1: X0 in lo (byte 0), X1 in hi (byte 2)
+
+__device__ __forceinline__ void taps_issue(uint32_t bxj, uint32_t byj, uint32_t lds_origin, TapRegs& t)
 {
-    // taps from the staged region: three dwords around byte 160 iy + 3 ix of each of the two rows,
-    // shifted down by the byte misalignment (v_alignbyte takes the low two bits of the address)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        // ix = bits[5..21] of the raw float; bits[22..28] (the 1.5*2^23 pattern, constant) ride along in the 24-bit
-        // multiplier operand and are taken out again through the origin: one v_lshrrev (half the issue cost of v_bfe)
-        const uint32_t at = umad24(by[j] >> 5, (uint32_t)LDS_PITCH,
-                                   umad24(bx[j] >> 5, 3u, 0u - lds_origin - MAGIC_HI * (3u + (uint32_t)LDS_PITCH)));
-        const uint32_t* __restrict__ p = (const uint32_t*)(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(at & ~3u);
-        const uint32_t t0 = p[0], t1 = p[1], t2 = p[2];
-        const uint32_t u0 = p[LDS_PITCH / 4], u1 = p[LDS_PITCH / 4 + 1], u2 = p[LDS_PITCH / 4 + 2];
-        a[j].x = __builtin_amdgcn_alignbyte(t1, t0, at);
-        a[j].y = __builtin_amdgcn_alignbyte(t2, t1, at);
-        b[j].x = __builtin_amdgcn_alignbyte(u1, u0, at);
-        b[j].y = __builtin_amdgcn_alignbyte(u2, u1, at);
-    }
+    static_assert(LDS_PITCH == 160, "the immediate offsets below are LDS_PITCH + 0..5");
+    // ix = bits[5..21] of the raw float; bits[22..28] (the 1.5*2^23 pattern, constant) ride along in the 24-bit multiplier
+    // operand and are taken out again through the origin
+    const uint32_t at = umad24(byj >> 5, (uint32_t)LDS_PITCH, umad24(bxj >> 5, 3u, 0u - lds_origin - MAGIC_HI * (3u + (uint32_t)LDS_PITCH)));
+    asm volatile("ds_read_u8 %0, %12 offset:0\n\tds_read_u8_d16_hi %1, %12 offset:3\n\t"
+                 "ds_read_u8 %2, %12 offset:1\n\tds_read_u8_d16_hi %3, %12 offset:4\n\t"
+                 "ds_read_u8 %4, %12 offset:2\n\tds_read_u8_d16_hi %5, %12 offset:5\n\t"
+                 "ds_read_u8 %6, %12 offset:160\n\tds_read_u8_d16_hi %7, %12 offset:163\n\t"
+                 "ds_read_u8 %8, %12 offset:161\n\tds_read_u8_d16_hi %9, %12 offset:164\n\t"
+                 "ds_read_u8 %10, %12 offset:162\n\tds_read_u8_d16_hi %11, %12 offset:165"
+                 : "=&v"(t.lo[0]), "=&v"(t.hi[0]), "=&v"(t.lo[1]), "=&v"(t.hi[1]), "=&v"(t.lo[2]), "=&v"(t.hi[2]),
+                   "=&v"(t.lo[3]), "=&v"(t.hi[3]), "=&v"(t.lo[4]), "=&v"(t.hi[4]), "=&v"(t.lo[5]), "=&v"(t.hi[5])
+                 : "v"(at));
 }
 
-// The same straight from the frame (two unaligned 8-byte loads per pixel), for footprints without a staged window.
+// Waits for every LDS load in flight and hands the registers of two pixels to the compiler as ready (it does not see the loads).
+__device__ __forceinline__ void taps_wait(TapRegs& t, TapRegs& u)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(t.lo[0]), "+v"(t.hi[0]), "+v"(t.lo[1]), "+v"(t.hi[1]), "+v"(t.lo[2]), "+v"(t.hi[2]),
+                   "+v"(t.lo[3]), "+v"(t.hi[3]), "+v"(t.lo[4]), "+v"(t.hi[4]), "+v"(t.lo[5]), "+v"(t.hi[5]),
+                   "+v"(u.lo[0]), "+v"(u.hi[0]), "+v"(u.lo[1]), "+v"(u.hi[1]), "+v"(u.lo[2]), "+v"(u.hi[2]),
+                   "+v"(u.lo[3]), "+v"(u.hi[3]), "+v"(u.lo[4]), "+v"(u.hi[4]), "+v"(u.lo[5]), "+v"(u.hi[5]) :: "memory");
+}
+
+__device__ __forceinline__ void blend_pixel(uint32_t bxj, uint32_t byj, const TapRegs& t, uint32_t& oB, uint32_t& oG, uint32_t& oR)
+{
+    // vertical lerp of both 16-bit fields at once (each <= 255 * 32: no carry between them)
+    const uint32_t fy = byj & 31u, wy = 32u - fy;
+    const uint32_t vB = umad24(t.lo[3] | t.hi[3], fy, __umul24(t.lo[0] | t.hi[0], wy));
+    const uint32_t vG = umad24(t.lo[4] | t.hi[4], fy, __umul24(t.lo[1] | t.hi[1], wy));
+    const uint32_t vR = umad24(t.lo[5] | t.hi[5], fy, __umul24(t.lo[2] | t.hi[2], wy));
+    // horizontal lerp: v_dot2_u32_u16 with the weight pair (32 - fx, fx) scaled by 64, so that ((sum + 512) >> 10) lands in byte 2:
+    // (sum + 512) * 64 < 2^24
+    const uint32_t fx = bxj & 31u;
+    const uint32_t wq = umad24(fx, 0x3FFFC0u, 2048u);           // 64 (32 - fx) | 64 fx << 16
+    oB = udot2(vB, wq, 32768u);
+    oG = udot2(vG, wq, 32768u);
+    oR = udot2(vR, wq, 32768u);
+}
+
+// (two pixels' loads in flight at a time: 24 registers; a software pipeline with counted lgkmcnt waits measured the same)
+__device__ __forceinline__ uint3 gather_blend_staged(const uint32_t (&bx)[4], const uint32_t (&by)[4], uint32_t lds_origin)
+{
+    uint32_t oB[4], oG[4], oR[4];
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+        TapRegs t0, t1;
+        taps_issue(bx[j], by[j], lds_origin, t0);
+        taps_issue(bx[j + 1], by[j + 1], lds_origin, t1);
+        taps_wait(t0, t1);
+        blend_pixel(bx[j], by[j], t0, oB[j], oG[j], oR[j]);
+        blend_pixel(bx[j + 1], by[j + 1], t1, oB[j + 1], oG[j + 1], oR[j + 1]);
+    }
+    // the 12 result bytes sit in byte 2 of the 12 sums: 6 v_perm_b32 + 3 v_or_b32 gather them into B0 G0 R0 B1 | G1 R1 B2 G2 |
+    // R2 B3 G3 R3
+    const uint32_t pair = 0x0C0C0602u, pair_hi = 0x06020C0Cu;
+    uint3 d;
+    d.x = __builtin_amdgcn_perm(oB[1], oR[0], pair_hi) | __builtin_amdgcn_perm(oG[0], oB[0], pair);
+    d.y = __builtin_amdgcn_perm(oG[2], oB[2], pair_hi) | __builtin_amdgcn_perm(oR[1], oG[1], pair);
+    d.z = __builtin_amdgcn_perm(oR[3], oG[3], pair_hi) | __builtin_amdgcn_perm(oB[3], oR[2], pair);
+    return d;
+}
+
+// The 2 x 2 taps of the lane's four pixels straight from the frame (two unaligned 8-byte loads per pixel), for footprints without a
+// staged window: a[j] = B0 G0 R0 B1 | G1 R1 . . of row iy (pixel ix, pixel ix+1), b[j] the same of row iy + 1.
 __device__ __forceinline__ void gather_global(const uint32_t (&bx)[4], const uint32_t (&by)[4], const uint8_t* __restrict__ src, int W, uint2 (&a)[4], uint2 (&b)[4])
 {
     const uint8_t* __restrict__ src1 = src + 3u * (uint32_t)W;   // row iy + 1
@@ -333,8 +387,8 @@ __device__ __forceinline__ void gather_global(const uint32_t (&bx)[4], const uin
     }
 }
 
-// cv2.remap's bilinear blend (integer, 1/32-pixel weights) of the lane's four pixels: the 12 output bytes B0 G0 R0 B1 | G1 R1 B2 G2 |
-// R2 B3 G3 R3.
+// cv2.remap's bilinear blend (integer, 1/32-pixel weights) of the lane's four pixels from gather_global's layout: the 12 output bytes
+// B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3.
 __device__ __forceinline__ uint3 blend(const uint32_t (&bx)[4], const uint32_t (&by)[4], const uint2 (&a)[4], const uint2 (&b)[4])
 {
     uint3 d;
@@ -436,10 +490,8 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
         uint32_t bx[4], by[4];
         fixed_point(u, v, bx, by);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the window has landed in LDS
-        uint2 a[4], b[4];
-        gather_staged(bx, by, lds_origin, a, b);
-        const uint3 d = blend(bx, by, a, b);
         uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
+        const uint3 d = gather_blend_staged(bx, by, lds_origin);
         *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;     // (STAGED implies W % 4 == 0)
         return;
     }
@@ -487,10 +539,8 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
             }
             uint32_t bx[4], by[4];
             fixed_point(u, v, bx, by);
-            uint2 a[4], b[4];
-            gather_staged(bx, by, lds_origin, a, b);
-            const uint3 d = blend(bx, by, a, b);
             uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
+            const uint3 d = gather_blend_staged(bx, by, lds_origin);
             *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;
             return;
         }
@@ -722,10 +772,13 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
         if (fast) {
             // fast path (wave-uniform): every pixel of the footprint samples the deep interior
             if (active) {
-                uint2 a[4], b[4];
-                if (staged) gather_staged(bx, by, lds_origin, a, b);
-                else gather_global(bx, by, src, W, a, b);
-                d = blend(bx, by, a, b);
+                if (staged) {
+                    d = gather_blend_staged(bx, by, lds_origin);
+                } else {
+                    uint2 a[4], b[4];
+                    gather_global(bx, by, src, W, a, b);
+                    d = blend(bx, by, a, b);
+                }
             }
         } else {
             // generic path: frame borders, uncovered pixels, crop flags, out-of-range coordinates

@@ -130,7 +130,7 @@ def test_streamed_stabilize_equals_the_staged_sequence(cv2_stub, F):
 
 def test_streamed_stabilize_overlaps_io_with_the_stages_around_it(cv2_stub, monkeypatch):
     """The order of events, not their speed: with a decoder that takes 2 ms per frame, the first chunk's tracking and upload must
-    have started before the last frame is decoded; with downloads that finish 20 ms apart, the encoder must have been handed
+    have started before the last frame is decoded; with downloads that finish 250 ms apart, the encoder must have been handed
     frames before the last chunk is back; and the frames reach the encoder in order."""
     import time
     from meshflow_amd import pipeline
@@ -147,7 +147,7 @@ def test_streamed_stabilize_overlaps_io_with_the_stages_around_it(cv2_stub, monk
 
     def download(self, d_src, host_dst, after, k):
         def task():
-            time.sleep(0.02 * k)
+            time.sleep(0.25 * k)          # (well above any one-time set-up cost of the first copy on a new stream)
             stream = self.out_streams[k % len(self.out_streams)]
             with torch.cuda.device(self.device), torch.cuda.stream(stream):
                 stream.wait_event(after)
