@@ -310,6 +310,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
     int cnt = 0;
     bool overflow = false, closed = false;
     const float cxs[2] = { (float)xa, (float)xb }, cys[2] = { (float)ya, (float)yb };
+    const float cxm = 0.5f * (cxs[0] + cxs[1]), cxh = 0.5f * (cxs[1] - cxs[0]), cym = 0.5f * (cys[0] + cys[1]), cyh = 0.5f * (cys[1] - cys[0]);
     float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
     bool sane = true;
     float wlo = 1e30f, whi = -1e30f, h6_first = 0.0f;          // denominator range of the FIRST listed cell over the footprint
@@ -323,12 +324,12 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
             bool all_in = true, any_out = false;
             int uncertain = 0, which = 0, which2 = 0;
             for (int e = 0; e < 4; ++e) {
-                // extrema of the affine function a x + b y + c over the footprint rectangle sit on its corners:
-                // min = c + min(a xa, a xb) + min(b ya, b yb), max likewise (NaN coefficients fail both tests)
-                const float ax0 = ed[3 * e] * cxs[0], ax1 = ed[3 * e] * cxs[1];
-                const float by0 = ed[3 * e + 1] * cys[0], by1 = ed[3 * e + 1] * cys[1];
-                const float gmin = (fminf(ax0, ax1) + fminf(by0, by1)) + ed[3 * e + 2];
-                const float gmax = (fmaxf(ax0, ax1) + fmaxf(by0, by1)) + ed[3 * e + 2];
+                // extrema of the affine function a x + b y + c over the footprint rectangle sit on its corners: value at the
+                // centre -/+ (|a| half width + |b| half height)  (NaN coefficients fail both tests; the float32 rounding of
+                // these few operations is ~1e-3 units against the margin of one unit)
+                const float mid = __builtin_fmaf(ed[3 * e], cxm, __builtin_fmaf(ed[3 * e + 1], cym, ed[3 * e + 2]));
+                const float half = __builtin_fmaf(fabsf(ed[3 * e]), cxh, fabsf(ed[3 * e + 1]) * cyh);
+                const float gmin = mid - half, gmax = mid + half;
                 all_in = all_in && gmin > 1.0f;
                 any_out = any_out || gmax < -1.0f;
                 if (!(gmin > 1.0f)) { ++uncertain; which2 = which; which = e; }
@@ -352,7 +353,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
                 sane = sane && w > 0.25f && w < 4.0f;                     // (NaN fails)
                 if (cnt == 1) { wlo = fminf(wlo, w); whi = fmaxf(whi, w); h6_first = h[6]; }
                 wlo_all = fminf(wlo_all, w); whi_all = fmaxf(whi_all, w);
-                const float iw = 1.0f / w;
+                const float iw = __builtin_amdgcn_rcpf(w);            // (1 ulp: the window keeps a pixel of slack)
                 const float u = (h[0] * cx + h[1] * cy + h[2]) * iw, v = (h[3] * cx + h[4] * cy + h[5]) * iw;
                 umin = fminf(umin, u); umax = fmaxf(umax, u);
                 vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
