@@ -172,7 +172,7 @@ __device__ static void cell_bbox(const double Hf[9], const double M[9], double L
 __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict__ unstab,
                                                         const double* __restrict__ stab, int n, int W, int H, int R,
                                                         int C, double* __restrict__ records,
-                                                        CellBox* __restrict__ boxes, float* __restrict__ edges,
+                                                        CellBox* __restrict__ boxes, float* __restrict__ edges, float* __restrict__ uedges,
                                                         int32_t* __restrict__ reach, int32_t* __restrict__ grid,
                                                         int32_t* __restrict__ crop, int32_t* __restrict__ status)
 {
@@ -216,8 +216,11 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
     int rxlo = 0, rylo = 0, rxhi = 0, ryhi = 0;      // how far this cell's box reaches beyond its grid rect
     bool has_reach = false;
     float* ed = edges + (size_t)cid * MF_EDGE_FLOATS;
+    float* ued = uedges + (size_t)cid * MF_UEDGE_FLOATS;
     if (!ok) {
-        for (int e = 0; e < 4; ++e) { ed[3 * e] = 0.0f; ed[3 * e + 1] = 0.0f; ed[3 * e + 2] = -1e30f; }   // never a candidate
+        for (int e = 0; e < 4; ++e) {                                     // never a candidate
+            ed[3 * e] = ued[3 * e] = 0.0f; ed[3 * e + 1] = ued[3 * e + 1] = 0.0f; ed[3 * e + 2] = ued[3 * e + 2] = -1e30f; ed[12 + e] = 1.0f;
+        }
         rec[MF_CELL_OFF_STATUS] = 1.0;
         rec[MF_CELL_OFF_BBOX + 0] = 1; rec[MF_CELL_OFF_BBOX + 1] = 1; rec[MF_CELL_OFF_BBOX + 2] = 0; rec[MF_CELL_OFF_BBOX + 3] = 0;
         box.x0 = 1; box.y0 = 1; box.x1 = 0; box.y1 = 0;
@@ -233,8 +236,13 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
         // (Xn = M0 x + M1 y + M2, Wd = M6 x + M7 y + M8 > 0 on the frame) the mask test
         // 32(L-1) < rint(X) < 32(Rt+1) is, up to rounding, gL > 0 and gR > 0 with
         //   gL = 32 Xn - (32(L-1) + 1/2) Wd,   gR = (32(Rt+1) - 1/2) Wd - 32 Xn      (same for y),
-        // each affine in (x, y), so its extrema over a pixel rectangle sit on the corners.  Stored as
-        // float32 {a, b, c}; the consumer keeps a margin of one unit (1/32 px), far above their error.
+        // each affine in (x, y), so its extrema over a pixel rectangle sit on the corners.  Stored twice as float32 {a, b, c}:
+        // `uedges` as they are (units of 1/32 pixel: what the plan kernel's classification margins are in), and `edges` SCALED by
+        // the function's own float32 evaluation error bound m for the warp kernel -- with S = |a| (W-1) + |b| (H-1) + |c|, three
+        // rounded coefficients and two fma put fma(a, x, fma(b, y, c)) within 2^-23 S of the exact value anywhere on the frame;
+        // m = 1.25 * 2^-23 S and the stored coefficients are a / m, b / m, c / m (the four m follow the twelve coefficients).  So
+        // for every edge of every cell the scaled function decides the sign of the exact one whenever its magnitude exceeds 1:
+        // one threshold for all, and min() over edges keeps its meaning.
         // A cell whose Wd is not positive on the whole frame gets NaNs: neither "all inside" nor
         // "all outside" can then be concluded and every pixel is tested.
         const double fw = (double)(W - 1), fh = (double)(H - 1);
@@ -247,7 +255,15 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
             hix * M[6] - 32.0 * M[0], hix * M[7] - 32.0 * M[1], hix * M[8] - 32.0 * M[2],
             32.0 * M[3] - loy * M[6], 32.0 * M[4] - loy * M[7], 32.0 * M[5] - loy * M[8],
             hiy * M[6] - 32.0 * M[3], hiy * M[7] - 32.0 * M[4], hiy * M[8] - 32.0 * M[5] };
-        for (int i = 0; i < 12; ++i) ed[i] = regular ? (float)co[i] : __builtin_nanf("");
+        for (int e = 0; e < 4; ++e) {
+            const double S = fabs(co[3 * e]) * fw + fabs(co[3 * e + 1]) * fh + fabs(co[3 * e + 2]);
+            const double m = 1.25 * 1.1920928955078125e-07 * S, inv = 1.0 / m;
+            for (int q = 0; q < 3; ++q) {
+                ed[3 * e + q] = regular ? (float)(co[3 * e + q] * inv) : __builtin_nanf("");
+                ued[3 * e + q] = regular ? (float)co[3 * e + q] : __builtin_nanf("");
+            }
+            ed[12 + e] = regular ? (float)m : 1.0f;
+        }
         rxlo = (int)L - box.x0; rylo = (int)T - box.y0; rxhi = box.x1 - (int)Rt; ryhi = box.y1 - (int)B;
         has_reach = live && box.x0 <= box.x1;
     }
@@ -287,8 +303,8 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
 // listed cell owns it.  If that box fits the staging window and the frame, the warp kernel fetches it once.
 // Classification + source region of ONE footprint.  `edge_of(k)` yields the 12 float32 edge coefficients of cell k of this
 // frame, `hi_of(k, out9)` its inverse homography as float32: from LDS when the workgroup staged its cell rows, else global.
-template <typename EdgeOf, typename HiOf>
-__device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, const int* s_gx, const int* s_gy, int xa, int xb,
+template <typename EdgeOf, typename HiOf, typename MarginOf>
+__device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, MarginOf margin_of, const int* s_gx, const int* s_gy, int xa, int xb,
                                                    int ya, int yb, int rxlo, int rylo, int rxhi, int ryhi, int W, int H, int R,
                                                    int C, FootPlan& p, FootRegion& region)
 {
@@ -369,15 +385,17 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, c
         p.e[4] = p.e[5] = p.e[6] = 0; p.e[7] = (uint16_t)MF_PLAN_OVERFLOW;
     }
     // Two cells that meet inside the footprint, each with ONE uncertain edge g0, g1 (the pair path of the warp kernel): a pixel
-    // without owner would fail both, g0 <= m and g1 <= m (m = the kernel's float32 margin).  g0 + g1 is affine, so if it
-    // exceeds 2 m + 1 at the four corners it does everywhere and every pixel has an owner -- the footprint can be certified
-    // like one whose list ends with an IN cell.
+    // without owner would fail both, g0 <= m0 and g1 <= m1 (the kernel's float32 error bands of the two edges).  g0 + g1 is affine,
+    // so if it exceeds m0 + m1 + 1 at the four corners it does everywhere and every pixel has an owner -- the footprint can be
+    // certified like one whose list ends with an IN cell.
     bool covered = closed;
     if (!closed && !overflow && cnt == 2 && single_ok[0] && single_ok[1]) {
         const float a = single_edge[0][0] + single_edge[1][0], b = single_edge[0][1] + single_edge[1][1];
         const float c = single_edge[0][2] + single_edge[1][2];
         const float gmin = (fminf(a * cxs[0], a * cxs[1]) + fminf(b * cys[0], b * cys[1])) + c;
-        covered = gmin > 2.0f * ((float)(W > H ? W : H) * (1.0f / 16384.0f)) + 1.0f;
+        // (the kernel's error bands of the two edges, in the same units: their cells and edge numbers are in the list)
+        const float m0 = margin_of(p.e[0] & 0xFFF, codes[0] & 3), m1 = margin_of(p.e[1] & 0xFFF, codes[1] & 3);
+        covered = gmin > m0 + m1 + 1.0f;
     }
     region.flags_origin = 0;
     region.src_dwords = 0;
@@ -409,14 +427,14 @@ constexpr int kPlanStageCells = 256;          // cells (whole mesh rows) a workg
 // grid = n * ceil(footprints per frame / 256): a workgroup handles 256 consecutive footprints of ONE frame -- a few rows of
 // footprints, which only meet a few mesh rows.  Those rows' edge functions and inverse homographies are staged in LDS once
 // (the per-footprint loops then run on LDS latency instead of dependent L2 round trips); when they do not fit, from global.
-__global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __restrict__ edges,
+__global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __restrict__ uedges, const float* __restrict__ edges,
                                                              const double* __restrict__ records,
                                                              const int32_t* __restrict__ reach,
                                                              const int32_t* __restrict__ grid, int n, int W, int H, int R,
                                                              int C, FootPlan* __restrict__ plan, FootRegion* __restrict__ regions)
 {
     __shared__ int s_gx[66], s_gy[66];
-    __shared__ float s_edge[kPlanStageCells * MF_EDGE_FLOATS];
+    __shared__ float s_edge[kPlanStageCells * MF_UEDGE_FLOATS];
     __shared__ float s_hi[kPlanStageCells * 9];
     if ((int)threadIdx.x <= C) s_gx[threadIdx.x] = grid[threadIdx.x];
     if ((int)threadIdx.x <= R) s_gy[threadIdx.x] = grid[C + 1 + threadIdx.x];
@@ -427,7 +445,8 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     if (f >= n) return;
     const int rem0 = ((int)blockIdx.x - f * blocks_per_frame) * 256, rem = rem0 + (int)threadIdx.x;
     const int rxlo = reach[4 * f + 0], rylo = reach[4 * f + 1], rxhi = reach[4 * f + 2], ryhi = reach[4 * f + 3];
-    const float* __restrict__ fedge = edges + (size_t)f * R * C * MF_EDGE_FLOATS;
+    const float* __restrict__ fedge = uedges + (size_t)f * R * C * MF_UEDGE_FLOATS;
+    const float* __restrict__ fmargin = edges + (size_t)f * R * C * MF_EDGE_FLOATS + 12;      // the scaled set's error bounds
     const double* __restrict__ frec = records + (size_t)f * R * C * MF_CELL_DOUBLES;
 
     // mesh rows the workgroup's footprints can meet (same widening by the frame's reach as per footprint)
@@ -439,7 +458,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     const bool staged = rb_hi >= rb_lo && staged_cells <= kPlanStageCells;          // (workgroup-uniform)
     if (staged) {
         const int k0 = rb_lo * C;
-        for (int i = threadIdx.x; i < staged_cells * MF_EDGE_FLOATS; i += 256) s_edge[i] = fedge[(size_t)k0 * MF_EDGE_FLOATS + i];
+        for (int i = threadIdx.x; i < staged_cells * MF_UEDGE_FLOATS; i += 256) s_edge[i] = fedge[(size_t)k0 * MF_UEDGE_FLOATS + i];
         for (int i = threadIdx.x; i < staged_cells * 9; i += 256) {
             const int cell = i / 9, j = i - 9 * cell;
             s_hi[i] = (float)frec[(size_t)(k0 + cell) * MF_CELL_DOUBLES + MF_CELL_OFF_HI + j];
@@ -454,15 +473,17 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     FootRegion region;
     if (staged) {
         const int k0 = rb_lo * C;
-        plan_one_footprint([&](int k) { return (const float*)&s_edge[(k - k0) * MF_EDGE_FLOATS]; },
+        plan_one_footprint([&](int k) { return (const float*)&s_edge[(k - k0) * MF_UEDGE_FLOATS]; },
                            [&](int k, float (&h)[9]) { for (int j = 0; j < 9; ++j) h[j] = s_hi[(k - k0) * 9 + j]; },
+                           [&](int k, int e) { return fmargin[(size_t)k * MF_EDGE_FLOATS + e]; },
                            s_gx, s_gy, xa, xb, ya, yb, rxlo, rylo, rxhi, ryhi, W, H, R, C, p, region);
     } else {
-        plan_one_footprint([&](int k) { return fedge + (size_t)k * MF_EDGE_FLOATS; },
+        plan_one_footprint([&](int k) { return fedge + (size_t)k * MF_UEDGE_FLOATS; },
                            [&](int k, float (&h)[9]) {
                                const double* __restrict__ hi = frec + (size_t)k * MF_CELL_DOUBLES + MF_CELL_OFF_HI;
                                for (int j = 0; j < 9; ++j) h[j] = (float)hi[j];
                            },
+                           [&](int k, int e) { return fmargin[(size_t)k * MF_EDGE_FLOATS + e]; },
                            s_gx, s_gy, xa, xb, ya, yb, rxlo, rylo, rxhi, ryhi, W, H, R, C, p, region);
     }
     const size_t gid = (size_t)f * per_frame + rem;
@@ -484,11 +505,11 @@ int launch_cell_table(const double* unstab, const double* stab, int n, int W, in
     if (threads < 65) threads = 65;
     const unsigned blocks = (unsigned)((threads + 63) / 64);
     hipLaunchKernelGGL(cell_table_kernel, dim3(blocks), dim3(64), 0, st, unstab, stab, n, W, H, R, C, tv.records, tv.boxes,
-                       tv.edges, tv.reach, tv.grid, crop, status);
+                       tv.edges, tv.uedges, tv.reach, tv.grid, crop, status);
     int rc = hip_fail(hipGetLastError(), "cell_table_kernel launch");
     if (rc != MF_OK) return rc;
     const size_t per_frame = plan_count(1, W, H);
-    hipLaunchKernelGGL(footprint_plan_kernel, dim3((unsigned)(((per_frame + 255) / 256) * (size_t)n)), dim3(256), 0, st, tv.edges, tv.records,
+    hipLaunchKernelGGL(footprint_plan_kernel, dim3((unsigned)(((per_frame + 255) / 256) * (size_t)n)), dim3(256), 0, st, tv.uedges, tv.edges, tv.records,
                        tv.reach, tv.grid, n, W, H, R, C, tv.plan, tv.regions);
     return hip_fail(hipGetLastError(), "footprint_plan_kernel launch");
 }

@@ -22,15 +22,17 @@ struct alignas(8) CellBox { int16_t x0, y0, x1, y1; };
 
 inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 
-// Layout of the cell table blob (mf_cell_table_bytes): records | boxes | edges | plan | regions | reach | grid.
+// Layout of the cell table blob (mf_cell_table_bytes): records | boxes | edges | uedges | plan | regions | reach | grid.
 //   records: n*R*C x MF_CELL_DOUBLES float64      (ABI, include/meshflow_hip.h)
 //   boxes:   n*R*C x CellBox                      compact copy of the record's bbox
-//   edges:   n*R*C x MF_EDGE_FLOATS float32       4 affine edge functions {a, b, c} (cell_table.hip)
+//   edges:   n*R*C x MF_EDGE_FLOATS float32       4 affine edge functions {a, b, c} scaled by their error bound, then the 4 bounds
+//   uedges:  n*R*C x MF_UEDGE_FLOATS float32      the same 4 functions in units of 1/32 pixel (what the plan kernel classifies with)
 //   plan:    n x ceil(H/8) x ceil(W/32) x 16 B    per 32x8-pixel footprint: candidate cells, descending
 //   regions: n x ceil(H/8) x ceil(W/32) x 8 B     per footprint: source region the warp kernel stages in LDS
 //   reach:   n x 4 int32                          per-frame max extent of a box beyond its grid rect
 //   grid:    (C+1) + (R+1) int32                  vertex x / y pixel coordinates
-#define MF_EDGE_FLOATS 12
+#define MF_EDGE_FLOATS 16
+#define MF_UEDGE_FLOATS 12
 #define MF_FOOT_W 32
 #define MF_FOOT_H 8
 // Plan entry (uint16): bits 0-11 cell index, bit 14 = entry valid, bit 15 = IN (every pixel of the footprint
@@ -79,7 +81,7 @@ struct alignas(8) FootRegion { uint32_t flags_origin, src_dwords; };
 #define MF_REGION_DEEP 0x40000000u
 #define MF_STAGE_CHUNKS 128            // two 16-byte chunks per lane: 12 rows x 10 chunks + 8 chunks of a 13th row (unused)
 struct TableView {
-    double* records; CellBox* boxes; float* edges; FootPlan* plan; FootRegion* regions; int32_t* reach; int32_t* grid;
+    double* records; CellBox* boxes; float* edges; float* uedges; FootPlan* plan; FootRegion* regions; int32_t* reach; int32_t* grid;
 };
 inline size_t plan_count(int n, int W, int H)
 {
@@ -88,7 +90,7 @@ inline size_t plan_count(int n, int W, int H)
 inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 inline size_t plan_offset(int n, int R, int C)
 {
-    return align16(table_records(n, R, C) * (MF_CELL_DOUBLES * sizeof(double) + sizeof(CellBox) + MF_EDGE_FLOATS * sizeof(float)));
+    return align16(table_records(n, R, C) * (MF_CELL_DOUBLES * sizeof(double) + sizeof(CellBox) + (MF_EDGE_FLOATS + MF_UEDGE_FLOATS) * sizeof(float)));
 }
 inline size_t table_bytes(int n, int W, int H, int R, int C)
 {
@@ -102,6 +104,7 @@ inline TableView table_view(void* blob, int n, int W, int H, int R, int C)
     v.records = (double*)blob;
     v.boxes = (CellBox*)(v.records + nrec * MF_CELL_DOUBLES);
     v.edges = (float*)(v.boxes + nrec);
+    v.uedges = v.edges + nrec * MF_EDGE_FLOATS;
     v.plan = (FootPlan*)((char*)blob + plan_offset(n, R, C));
     v.regions = (FootRegion*)(v.plan + plan_count(n, W, H));
     v.reach = (int32_t*)(v.regions + plan_count(n, W, H));

@@ -71,6 +71,9 @@ typedef const __attribute__((address_space(4))) float* cedge_t;
 constexpr int FOOT_W = MF_FOOT_W;   // 8 lanes x 4 pixels
 constexpr int FOOT_H = MF_FOOT_H;   // 64 lanes / 8
 constexpr int MAX_MESH = 64;    // R, C <= 64
+// The float32 edge functions are stored scaled by their own evaluation error bound (cell_table.hip): beyond +-1 their sign is the
+// exact function's sign; inside the band the float64 comparison decides.
+constexpr float EDGE_BAND = 1.0f;
 // A pixel's owner is kept as the byte offset of the owner's row in the wavefront's s_hi block (80-byte rows, one per list
 // entry).  Row 8 holds the matrix {0, 0, W+1; 0, 0, H+1; 0, 0, 1}: a pixel no cell covers runs through the same arithmetic and
 // comes out at exactly (W+1, H+1) (mfs.py:983-984) -- no special case, no select, in the coordinate code.
@@ -430,7 +433,7 @@ template <bool STAGE_OK>
 __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* __restrict__ plan, const FootRegion* __restrict__ regions,
                                                                WarpGeom g, const uint8_t* __restrict__ frames,
                                                                const double* __restrict__ records, uint8_t* __restrict__ out,
-                                                               const float* __restrict__ edges, float edge_margin, int n, int W,
+                                                               const float* __restrict__ edges, int n, int W,
                                                                int H, int C, uint32_t border, int32_t* __restrict__ crop)
 {
     // inverse homographies of the footprint's candidate cells: [entry][Hi0..Hi8, pad] (80-byte rows)
@@ -519,11 +522,11 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float gb = __builtin_fmaf(eb[0], xf0 + (float)j, rb);
-            own[j] = gb > edge_margin ? 0u : OWN_ROW;
+            own[j] = gb > EDGE_BAND ? 0u : OWN_ROW;
             near = fminf(near, fabsf(gb));
         }
         // (a pixel inside the float32 error band of the edge, or NaN coefficients: the general code below decides exactly)
-        if (__ballot(!(near > edge_margin)) == 0) {
+        if (__ballot(!(near > EDGE_BAND)) == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // matrices and window have landed in LDS
             float u[4], v[4];
 #pragma unroll
@@ -643,11 +646,11 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
                     for (int j = 0; j < 4; ++j) {
                         const float xf = xf0 + (float)j;
                         const float g = fminf(__builtin_fmaf(e1[0], xf, r1), __builtin_fmaf(e2[0], xf, r2));
-                        own[j] = g > edge_margin ? OWN_ROW * (uint32_t)i : own[j];
+                        own[j] = g > EDGE_BAND ? OWN_ROW * (uint32_t)i : own[j];
                         near = fminf(near, fabsf(g));
                     }
                 }
-                general = __ballot(!(near > edge_margin) && active) != 0;
+                general = __ballot(!(near > EDGE_BAND) && active) != 0;
             }
             if (pair) {
                 const cedge_t eb = fedge + (pv.x & 0xFFFu) * MF_EDGE_FLOATS + 3u * cd0;            // later cell: wins
@@ -658,11 +661,11 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
                 for (int j = 0; j < 4; ++j) {
                     const float xf = xf0 + (float)j;
                     const float gb = __builtin_fmaf(eb[0], xf, rb), ga = __builtin_fmaf(ea[0], xf, ra);
-                    own[j] = gb > edge_margin ? 0u : (ga > edge_margin ? OWN_ROW : OWN_NONE);
+                    own[j] = gb > EDGE_BAND ? 0u : (ga > EDGE_BAND ? OWN_ROW : OWN_NONE);
                     near = fminf(near, fminf(fabsf(gb), fabsf(ga)));
                 }
                 // a pixel inside the float32 error band of a mask edge (or NaN coefficients): the general path decides exactly
-                general = __ballot(!(near > edge_margin) && active) != 0;
+                general = __ballot(!(near > EDGE_BAND) && active) != 0;
             }
             if (general) {
             uint32_t unowned = 0;
@@ -689,8 +692,8 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float g = __builtin_fmaf(e1[0], xf0 + (float)j, rr);
-                            ok |= g > edge_margin ? (1u << j) : 0u;
-                            amb |= ((g > edge_margin) | (g < -edge_margin)) ? 0u : (1u << j);
+                            ok |= g > EDGE_BAND ? (1u << j) : 0u;
+                            amb |= ((g > EDGE_BAND) | (g < -EDGE_BAND)) ? 0u : (1u << j);
                         }
                     } else {
                         const float r0 = __builtin_fmaf(ed[1], yf, ed[2]), r1 = __builtin_fmaf(ed[4], yf, ed[5]);
@@ -700,8 +703,8 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
                             const float xf = xf0 + (float)j;
                             const float g = fminf(fminf(__builtin_fmaf(ed[0], xf, r0), __builtin_fmaf(ed[3], xf, r1)),
                                                   fminf(__builtin_fmaf(ed[6], xf, r2), __builtin_fmaf(ed[9], xf, r3)));
-                            ok |= g > edge_margin ? (1u << j) : 0u;
-                            amb |= ((g > edge_margin) | (g < -edge_margin)) ? 0u : (1u << j);     // NaN (irregular cell) -> ambiguous
+                            ok |= g > EDGE_BAND ? (1u << j) : 0u;
+                            amb |= ((g > EDGE_BAND) | (g < -EDGE_BAND)) ? 0u : (1u << j);     // NaN (irregular cell) -> ambiguous
                         }
                     }
                     amb &= unowned;
@@ -934,10 +937,6 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
     }
     // staging reads dword-aligned 16-byte chunks: needs a 4-byte aligned clip (W % 4 == 0 is checked by the plan)
     const bool stage_ok = ((uintptr_t)frames & 3u) == 0;
-    // float32 edge functions (cell_table.hip) reach |g| <= V = 32 max(W, H) (1/32-px units); two fmas and three rounded
-    // coefficients put the evaluation within 2.5 V 2^-23 of the exact value.  The kernel trusts the float32 sign only
-    // beyond six times that, max(W, H) 2^-14 (0.12 at 1080p), and decides in float64 inside the band.
-    const float edge_margin = (float)(W > H ? W : H) * (1.0f / 16384.0f);
     for (int f0 = 0; f0 < n; f0 += (int)per_launch) {
         const int m = n - f0 < (int)per_launch ? n - f0 : (int)per_launch;
         const dim3 grid(g.per_xcd * 8u, (uint32_t)m);                  // one wavefront per 32 x 8 footprint
@@ -948,9 +947,9 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
         const FootPlan* pl = tv.plan + (size_t)f0 * g.per_frame;
         const FootRegion* rgn = tv.regions + (size_t)f0 * g.per_frame;
         if (stage_ok)
-            hipLaunchKernelGGL(warp_kernel<true>, grid, dim3(64), 0, st, pl, rgn, g, fr, rec, o, ed, edge_margin, m, W, H, C, border, crop + 4 * (size_t)f0);
+            hipLaunchKernelGGL(warp_kernel<true>, grid, dim3(64), 0, st, pl, rgn, g, fr, rec, o, ed, m, W, H, C, border, crop + 4 * (size_t)f0);
         else
-            hipLaunchKernelGGL(warp_kernel<false>, grid, dim3(64), 0, st, pl, rgn, g, fr, rec, o, ed, edge_margin, m, W, H, C, border, crop + 4 * (size_t)f0);
+            hipLaunchKernelGGL(warp_kernel<false>, grid, dim3(64), 0, st, pl, rgn, g, fr, rec, o, ed, m, W, H, C, border, crop + 4 * (size_t)f0);
     }
     return hip_fail(hipGetLastError(), "warp_kernel launch");
 }

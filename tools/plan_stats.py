@@ -17,7 +17,7 @@ table = ops.cell_table(d_disp[:n], d_stab[:n], W, H, R, C)
 torch.cuda.synchronize()
 buf = table.buf.cpu().numpy()
 nrec = n * R * C
-plan_off = (nrec * (32 * 8 + 8 + 12 * 4) + 15) & ~15
+plan_off = (nrec * (32 * 8 + 8 + 28 * 4) + 15) & ~15
 nfx, nfy = (W + 31) // 32, (H + 7) // 8
 npl = n * nfx * nfy
 plan = buf[plan_off:plan_off + npl * 16].view(np.uint16).reshape(npl, 8)
