@@ -333,6 +333,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
     float wlo_all = 1e30f, whi_all = -1e30f;                   // ... and of every listed cell
     float single_edge[2][3] = { { 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f } };   // the one uncertain edge of the first two entries
     bool single_ok[2] = { false, false };
+    bool coded = true;                                         // every MIXED entry has a one- or two-edge code
     for (int r = r_hi; r >= r_lo && !closed && !overflow; --r)
         for (int c = c_hi; c >= c_lo && !closed && !overflow; --c) {
             const int k = r * C + c;
@@ -357,6 +358,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
                 for (int q = 0; q < 3; ++q) single_edge[cnt][q] = ed[3 * which + q];
             }
             codes[cnt] = (uint16_t)(MF_PLAN_CODES | (uncertain == 1 ? which : uncertain == 2 ? (8 | which2 | (which << 4)) : 4));
+            coded = coded && (all_in || uncertain == 1 || uncertain == 2);
             p.e[cnt++] = (uint16_t)(k | MF_PLAN_VALID | (all_in ? MF_PLAN_IN : 0u));
             if (all_in) closed = true;
             // source position of the four footprint corners under this cell's inverse homography (float32 is ample:
@@ -418,6 +420,10 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             // the pair shape (`covered`: the second cell is IN, or the two single-edge masks overlap across the footprint)
             if (deep && !overflow && cnt == 2 && single_ok[0] && !(p.e[0] & MF_PLAN_IN) && wlo_all > 0.52f && whi_all < 1.9f)
                 p.e[2] = (uint16_t)MF_PLAN_HOT;
+            // the multi shape: coverage is left to the kernel
+            else if (whole && ix_lo >= 2 && ix_hi <= W - 3 && iy_lo >= 2 && iy_hi <= H - 3 && !overflow && cnt >= 2 && cnt <= 4 && coded &&
+                     wlo_all > 0.52f && whi_all < 1.9f)
+                p.e[4] = (uint16_t)(p.e[4] | MF_PLAN_HOT | ((uint32_t)(cnt - 1) << MF_PLAN_COUNT_SHIFT));
         }
     }
 }

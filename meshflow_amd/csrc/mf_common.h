@@ -60,6 +60,11 @@ inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 // belongs to the second cell (which is IN, or single-edge with the pair covering every pixel); both denominators stay in
 // (0.52, 1.9); the footprint is whole and its region STAGED and DEEP.  The kernel decides ownership with one float32 edge function
 // per pixel and never looks at the second cell's edges.
+// A short list (2-4 cells) whose MIXED entries all have a one- or two-edge code carries MF_PLAN_HOT in its first edge-code word e[4]
+// (bits 6-7 of that word: entries - 1) when the footprint is whole, its region STAGED and interior (every tap two pixels inside the
+// frame) and every denominator in (0.52, 1.9): the "multi" path of the kernel -- ownership from the coded edges only, coverage
+// checked at run time (a pixel without owner sends the wavefront to the general code).
+#define MF_PLAN_COUNT_SHIFT 6
 struct alignas(16) FootPlan { uint16_t e[8]; };
 // Source region of a footprint (FootRegion).  STAGED: every bilinear tap of every pixel of the footprint lies in columns sx0 ..
 // sx0+MF_STAGE_COLS-1 and rows sy0 .. sy0+MF_STAGE_ROWS-1 of the source frame, and rows sy0 .. sy0+MF_STAGE_ROWS are inside the

@@ -549,6 +549,73 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
         }
     }
 
+    if (STAGE_OK && (pv.z & MF_PLAN_HOT) != 0) {
+        // Two to four cells, each MIXED one with one or two coded mask edges (the four cells around a mesh vertex, three of them, or a
+        // pair the pair path did not take); window, interior and denominators certified, coverage not: a pixel that no listed cell
+        // takes -- or one inside the float32 error band of an edge -- sends the wavefront to the general code.
+        const int ne = (int)((pv.z >> MF_PLAN_COUNT_SHIFT) & 3u) + 1;
+        if (lane < 20) {
+            const uint32_t lo4 = (uint32_t)lane << 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < ne) {
+                    const uint32_t k = ((i < 2 ? pv.x : pv.y) >> (16 * (i & 1))) & 0xFFFu;
+                    const uint8_t* __restrict__ gi = (const uint8_t*)(uintptr_t)(frec + k * MF_CELL_DOUBLES + MF_CELL_OFF_HI);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gi + lo4),
+                                                     (__attribute__((address_space(3))) void*)&s_hi[0][i][0], 4, 0, 0);
+                }
+            }
+        }
+        const float yf = (float)y, xf0 = (float)x0;
+        uint32_t own[4] = { OWN_NONE, OWN_NONE, OWN_NONE, OWN_NONE };
+        float near = 1e30f;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {                  // first entry last: it wins
+            if (i < ne) {
+                const uint32_t ent = (i < 2 ? pv.x : pv.y) >> (16 * (i & 1));
+                if (ent & MF_PLAN_IN) {                 // (only the last entry can be IN: it owns what the others leave)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) own[j] = OWN_ROW * (uint32_t)i;
+                } else {
+                    const uint32_t cd = ((i < 2 ? pv.z : pv.w) >> (16 * (i & 1))) & 0x3Fu;
+                    const cedge_t ed = fedge + (ent & 0xFFFu) * MF_EDGE_FLOATS;
+                    const cedge_t e1 = ed + 3u * (cd & 3u);
+                    const cedge_t e2 = ed + 3u * ((cd & 8u) ? ((cd >> 4) & 3u) : (cd & 3u));     // one-edge code: the same edge twice
+                    const float r1 = __builtin_fmaf(e1[1], yf, e1[2]), r2 = __builtin_fmaf(e2[1], yf, e2[2]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xf = xf0 + (float)j;
+                        const float gq = fminf(__builtin_fmaf(e1[0], xf, r1), __builtin_fmaf(e2[0], xf, r2));
+                        own[j] = gq > EDGE_BAND ? OWN_ROW * (uint32_t)i : own[j];
+                        near = fminf(near, fabsf(gq));
+                    }
+                }
+            }
+        }
+        const uint32_t worst = max(max(own[0], own[1]), max(own[2], own[3]));
+        if (__ballot(!(near > EDGE_BAND) || worst == OWN_NONE) == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // matrices and window have landed in LDS
+            float u[4], v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double* hp = reinterpret_cast<const double*>(reinterpret_cast<const uint8_t*>(&s_hi[0][0][0]) + own[j]);
+                const double2 h01 = *reinterpret_cast<const double2*>(hp), h23 = *reinterpret_cast<const double2*>(hp + 2);
+                const double2 h45 = *reinterpret_cast<const double2*>(hp + 4), h67 = *reinterpret_cast<const double2*>(hp + 6);
+                const double h8 = hp[8];
+                const double xs = xs0 + (double)j;
+                const double iw = recip_unit_range((xs * h67.x + yy * h67.y) + h8);
+                u[j] = (float)(((xs * h01.x + yy * h01.y) + h23.x) * iw);
+                v[j] = (float)(((xs * h23.y + yy * h45.x) + h45.y) * iw);
+            }
+            uint32_t bx[4], by[4];
+            fixed_point(u, v, bx, by);
+            uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
+            const uint3 d = gather_blend_staged(bx, by, lds_origin);
+            *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;
+            return;
+        }
+    }
+
     // Everything else: more candidate cells, uncertified denominators, frame borders, uncovered pixels.
     uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
     const uint32_t limit = (int)f == n - 1 ? g.frame_bytes : 0xFFFFFFFFu;   // only the last frame has nothing behind it

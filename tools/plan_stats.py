@@ -45,5 +45,7 @@ g2 = general & (ne == 2)
 print(f'general by shape: ne=1 {(general & (ne == 1)).mean():.4f}  ne=2 {g2.mean():.4f} (of which closed by an IN cell {(g2 & inn[:, 1]).mean():.4f}, '
       f'two-edge codes {(g2 & ~inn[:, 1] & (((cd[:, 0] | cd[:, 1]) & 8) != 0)).mean():.4f})  ne=3 {(general & (ne == 3)).mean():.4f}  '
       f'ne=4 {(general & (ne == 4)).mean():.4f}  ne>4 {(general & (ne > 4)).mean():.4f}')
+pairhot = (ne == 2) & ((plan[:, 2] & 0x6000) == 0x2000)          # MF_PLAN_HOT in the unused third entry: the pair path
+print(f'plan-certified pair path {pairhot.mean():.4f}')
 hot = (plan[:, 1] & 0x6000) == 0x2000                          # MF_PLAN_HOT without VALID: the warp kernel's straight-line path
 print(f'staged {((regions >> 31) & 1).mean():.4f}  certified interior {((regions >> 30) & 1).mean():.4f}  hot (single + unit + deep + whole) {hot.mean():.4f}')
