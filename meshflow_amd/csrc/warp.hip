@@ -32,6 +32,8 @@
 //   4. PAIR (two cells, ~27 %): the later cell wins where ONE of its mask edges passes (one float32 fma per pixel), the other
 //      owns the rest; both Hi go to LDS by global->LDS DMA (one 80-byte load per cell, scalar base address) and a pixel's
 //      owner is the byte offset of its matrix row.  A pixel inside the float32 error band of the edge sends the wavefront to 5.
+//      MULTI (two to four cells with one- or two-edge codes -- the four cells around a mesh vertex; ~3 %, 14 % with a 32 x 32
+//      mesh): the same with up to two edge functions per cell; coverage is checked at run time (a pixel without owner -> 5).
 //   5. Everything else: the general last-cell-first loop over the list.  A pixel inside the error band of an edge is decided
 //      by a division-free float64 comparison, and by OpenCV's exact arithmetic (division, rint) only within 1e-6 of the edge;
 //      "no owner" is a ninth LDS row holding the matrix that maps every pixel to (W+1, H+1) -- the coordinate code has no
@@ -45,7 +47,8 @@
 // Algorithmic HBM traffic: 2*H*W*3 bytes per frame (each source byte read once, each output byte written once); measured
 // 1.05x that.  No dense contraction: no MFMA.  What bounds it: vector AND scalar instruction issue, not HBM -- DESIGN.md
 // section 4.3, profiles/r02_phase_profile.txt.  Everything a wavefront needs before its pixels is therefore host-made
-// (WarpGeom) or plan-made (FootRegion): the hot path issues 222 vector and 74 scalar instructions per wavefront.
+// (WarpGeom) or plan-made (FootRegion): the hot path issues 222 vector and 74 scalar instructions per wavefront.  The float32
+// edge functions come scaled by their own evaluation error bound (cell_table.hip): beyond +-1 their sign is exact.
 #include "mf_common.h"
 #include <stdlib.h>
 
