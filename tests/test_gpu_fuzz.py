@@ -1,0 +1,18 @@
+"""A slice of tools/fuzz_warp.py in the suite: random frame sizes, meshes and motion strengths through cell table + plan + warp kernel
+against the C oracle, bit for bit (the tool ran 3,300 cases for the round; this keeps 120 as a regression net)."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+def test_random_geometries_bit_exact():
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: the -m gpu tests must run on an MI355X')
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import fuzz_warp
+    assert fuzz_warp.run(120, seed=20261002, verbose=False) == 0

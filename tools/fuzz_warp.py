@@ -14,49 +14,57 @@ import torch
 from meshflow_amd import ops, synthetic
 from oracle import clib
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-dev = torch.device('cuda:0')
-bad_total = 0
-for case in range(cases):
-    W = int(rng.integers(8, 120)) * 4 if rng.random() < 0.85 else int(rng.integers(30, 400))      # mostly W % 4 == 0 (staged windows)
-    H = int(rng.integers(24, 300))
-    R, C = int(rng.integers(1, 9)), int(rng.integers(1, 9))
-    if rng.random() < 0.2:
-        R, C = int(rng.integers(8, 33)), int(rng.integers(8, 33))
-    n = int(rng.integers(1, 4))
-    style = rng.random()
-    nvert = n * (R + 1) * (C + 1) * 2
-    idx = np.arange(nvert, dtype=np.int64).reshape(n, R + 1, C + 1, 2)
-    unstab = np.zeros((n, R + 1, C + 1, 2))
-    if style < 0.6:          # smooth: a translation per frame + small jitter (what a smoothed path looks like)
-        shift = rng.normal(0, rng.uniform(0.5, 6.0), size=(n, 1, 1, 2))
-        stab = shift + rng.uniform(0.05, 1.2) * synthetic.normal(idx, seed=1000 + case)
-    elif style < 0.9:        # rougher
-        stab = rng.uniform(1.0, 4.0) * synthetic.normal(idx, seed=2000 + case)
-    else:                    # wild (irregular cells, generic division, overflow lists)
-        stab = rng.uniform(5.0, 15.0) * synthetic.normal(idx, seed=3000 + case)
-    frames = synthetic.frames_numpy(n, H, W, seed=case, kind='noise')
-    want, want_crop, bad = clib.warp_clip(frames, R, C, unstab, stab)
-    d_fr = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
-    try:
-        table = ops.cell_table(torch.from_numpy(unstab).to(dev), torch.from_numpy(np.ascontiguousarray(stab)).to(dev), W, H, R, C)
-        out = ops.warp(d_fr, table, (0, 0, 255))
-        torch.cuda.synchronize()
-        table.check()
-    except ValueError as e:
-        ok = bad != 0
-        print(f'case {case}: {W}x{H} mesh {R}x{C} n={n}: degenerate ({e}) -- oracle says {bad}: {"ok" if ok else "MISMATCH"}')
-        bad_total += 0 if ok else 1
-        continue
-    if bad:
-        print(f'case {case}: oracle reports {bad} degenerate cells, the HIP path none: MISMATCH')
-        bad_total += 1
-        continue
-    diff = int((out.cpu().numpy() != want).sum())
-    cdiff = int((table.crop.cpu().numpy() != want_crop).sum())
-    if diff or cdiff:
-        bad_total += 1
-        print(f'case {case}: {W}x{H} mesh {R}x{C} n={n} style {style:.2f}: {diff} bytes, {cdiff} crop values differ  <-- MISMATCH')
-print(f'{cases} cases, {bad_total} mismatches')
-sys.exit(1 if bad_total else 0)
+
+
+def run(cases, seed, verbose=True):
+  rng = np.random.default_rng(seed)
+  dev = torch.device('cuda:0')
+  bad_total = 0
+  for case in range(cases):
+      W = int(rng.integers(8, 120)) * 4 if rng.random() < 0.85 else int(rng.integers(30, 400))      # mostly W % 4 == 0 (staged windows)
+      H = int(rng.integers(24, 300))
+      R, C = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+      if rng.random() < 0.2:
+          R, C = int(rng.integers(8, 33)), int(rng.integers(8, 33))
+      n = int(rng.integers(1, 4))
+      style = rng.random()
+      nvert = n * (R + 1) * (C + 1) * 2
+      idx = np.arange(nvert, dtype=np.int64).reshape(n, R + 1, C + 1, 2)
+      unstab = np.zeros((n, R + 1, C + 1, 2))
+      if style < 0.6:          # smooth: a translation per frame + small jitter (what a smoothed path looks like)
+          shift = rng.normal(0, rng.uniform(0.5, 6.0), size=(n, 1, 1, 2))
+          stab = shift + rng.uniform(0.05, 1.2) * synthetic.normal(idx, seed=1000 + case)
+      elif style < 0.9:        # rougher
+          stab = rng.uniform(1.0, 4.0) * synthetic.normal(idx, seed=2000 + case)
+      else:                    # wild (irregular cells, generic division, overflow lists)
+          stab = rng.uniform(5.0, 15.0) * synthetic.normal(idx, seed=3000 + case)
+      frames = synthetic.frames_numpy(n, H, W, seed=case, kind='noise')
+      want, want_crop, bad = clib.warp_clip(frames, R, C, unstab, stab)
+      d_fr = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
+      try:
+          table = ops.cell_table(torch.from_numpy(unstab).to(dev), torch.from_numpy(np.ascontiguousarray(stab)).to(dev), W, H, R, C)
+          out = ops.warp(d_fr, table, (0, 0, 255))
+          torch.cuda.synchronize()
+          table.check()
+      except ValueError as e:
+          ok = bad != 0
+          if verbose or not ok: print(f'case {case}: {W}x{H} mesh {R}x{C} n={n}: degenerate ({e}) -- oracle says {bad}: {"ok" if ok else "MISMATCH"}')
+          bad_total += 0 if ok else 1
+          continue
+      if bad:
+          print(f'case {case}: oracle reports {bad} degenerate cells, the HIP path none: MISMATCH')
+          bad_total += 1
+          continue
+      diff = int((out.cpu().numpy() != want).sum())
+      cdiff = int((table.crop.cpu().numpy() != want_crop).sum())
+      if diff or cdiff:
+          bad_total += 1
+          print(f'case {case}: {W}x{H} mesh {R}x{C} n={n} style {style:.2f}: {diff} bytes, {cdiff} crop values differ  <-- MISMATCH')
+  return bad_total
+
+
+if __name__ == '__main__':
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    n_bad = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print(f'{n_cases} cases, {n_bad} mismatches')
+    sys.exit(1 if n_bad else 0)
