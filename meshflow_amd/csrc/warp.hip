@@ -109,24 +109,22 @@ __device__ __forceinline__ int cv_round_f32(float v)
     return (r >= -2147483648.0f && r < 2147483648.0f) ? (int)r : (int)0x80000000;
 }
 
-// One source pixel as B | G << 8 | R << 16, or the border colour when (tx, ty) is outside the frame.
+// One source pixel as B | G << 8 | R << 16, or the border colour when (tx, ty) is outside the frame.  Branch-free: the load
+// goes to the clamped position and the result is replaced afterwards, so that the sixteen loads of a lane's four pixels can all be
+// in flight together (the border footprints that need this path are 5-9 % of a stabilised clip's footprints).
 // `limit` = bytes from the frame base to the end of the whole frame stack (saturated to 32 bits), so the 4-byte load of the
 // very last pixel is shifted back by one byte instead of running past the allocation.
 __device__ __forceinline__ uint32_t fetch_bgr(const uint8_t* __restrict__ frame, int W, int H, int tx, int ty,
                                               uint32_t border, uint32_t limit)
 {
-    if ((unsigned)tx < (unsigned)W && (unsigned)ty < (unsigned)H) {
-        const uint32_t o = ((uint32_t)ty * (uint32_t)W + (uint32_t)tx) * 3u;
-        uint32_t v;
-        if (o + 4u <= limit) {
-            __builtin_memcpy(&v, frame + o, 4);
-        } else {
-            __builtin_memcpy(&v, frame + o - 1, 4);
-            v >>= 8;
-        }
-        return v & 0xFFFFFFu;
-    }
-    return border;
+    const bool inside = (unsigned)tx < (unsigned)W && (unsigned)ty < (unsigned)H;
+    const uint32_t cx = (uint32_t)min(max(tx, 0), W - 1), cy = (uint32_t)min(max(ty, 0), H - 1);
+    const uint32_t o = (cy * (uint32_t)W + cx) * 3u;
+    const uint32_t back = o + 4u > limit ? 1u : 0u;
+    uint32_t v;
+    __builtin_memcpy(&v, frame + (o - back), 4);
+    v >>= 8u * back;
+    return inside ? (v & 0xFFFFFFu) : border;
 }
 
 // OpenCV's mask test, exactly (imgwarp.cpp WarpPerspectiveInvoker: 64-wide destination blocks).
@@ -858,10 +856,9 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
             int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
             if (active) {
             uint32_t px[4];
-#pragma unroll 1
+#pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float uu = j == 0 ? u[0] : j == 1 ? u[1] : j == 2 ? u[2] : u[3];
-                const float vv = j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : v[3];
+                const float uu = u[j], vv = v[j];
                 const int x = x0 + j;
                 // crop-boundary scan, mfs.py:1075-1098: |u - e| < 1.  The float32 differences are exact
                 // whenever they are smaller than 1 in magnitude (Sterbenz), so the tests are exact.
@@ -874,22 +871,21 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
                 const int sxx = cv_round_f32(uu * 32.0f), syy = cv_round_f32(vv * 32.0f);
                 const int ix = sxx >> 5, iy = syy >> 5;      // (saturation to int16 cannot change any decision below)
                 const uint32_t fx = sxx & 31, fy = syy & 31;
-                uint32_t r = border;                         // whole 2x2 footprint outside -> border colour
-                if (!(ix >= W || ix + 1 < 0 || iy >= H || iy + 1 < 0)) {
-                    const uint32_t p00 = fetch_bgr(src, W, H, ix, iy, border, limit);
-                    const uint32_t p01 = fetch_bgr(src, W, H, ix + 1, iy, border, limit);
-                    const uint32_t p10 = fetch_bgr(src, W, H, ix, iy + 1, border, limit);
-                    const uint32_t p11 = fetch_bgr(src, W, H, ix + 1, iy + 1, border, limit);
-                    const uint32_t w00 = (32u - fx) * (32u - fy), w01 = fx * (32u - fy), w10 = (32u - fx) * fy, w11 = fx * fy;
-                    r = 0;
+                // (a 2 x 2 footprint that lies outside altogether needs no special case: four border-colour taps with weights that
+                // sum to 1024 give the border colour exactly)
+                const uint32_t p00 = fetch_bgr(src, W, H, ix, iy, border, limit);
+                const uint32_t p01 = fetch_bgr(src, W, H, ix + 1, iy, border, limit);
+                const uint32_t p10 = fetch_bgr(src, W, H, ix, iy + 1, border, limit);
+                const uint32_t p11 = fetch_bgr(src, W, H, ix + 1, iy + 1, border, limit);
+                const uint32_t w00 = (32u - fx) * (32u - fy), w01 = fx * (32u - fy), w10 = (32u - fx) * fy, w11 = fx * fy;
+                uint32_t r = 0;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const uint32_t acc = w00 * ((p00 >> (8 * c)) & 255u) + w01 * ((p01 >> (8 * c)) & 255u) +
-                                             w10 * ((p10 >> (8 * c)) & 255u) + w11 * ((p11 >> (8 * c)) & 255u);
-                        r |= ((acc + 512u) >> 10) << (8 * c);
-                    }
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t acc = w00 * ((p00 >> (8 * c)) & 255u) + w01 * ((p01 >> (8 * c)) & 255u) +
+                                         w10 * ((p10 >> (8 * c)) & 255u) + w11 * ((p11 >> (8 * c)) & 255u);
+                    r |= ((acc + 512u) >> 10) << (8 * c);
                 }
-                if (j == 0) px[0] = r; else if (j == 1) px[1] = r; else if (j == 2) px[2] = r; else px[3] = r;
+                px[j] = r;
             }
             d.x = px[0] | (px[1] << 24);
             d.y = (px[1] >> 8) | (px[2] << 16);
