@@ -301,26 +301,25 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
 // maps the footprint rectangle onto a convex quadrilateral (w > 0 at the four corners), so the bounding box of the
 // mapped corners, widened by the bilinear footprint and a pixel of slack, holds every tap of every pixel whichever
 // listed cell owns it.  If that box fits the staging window and the frame, the warp kernel fetches it once.
+// Cells whose grid interval [g[i], g[i+1]], widened by the frame's reach, meets the pixel interval [a, b]: a contiguous index range
+// lo..hi of the n intervals (start from the uniform-grid estimate, then walk the exact vertex coordinates: a step or two).
+__device__ __forceinline__ void cell_range_1d(const int* g, int n, int extent, int a, int b, int reach_lo, int reach_hi, int& lo, int& hi)
+{
+    const float scale = (float)n / (float)(extent - 1);
+    lo = min(max((int)((float)(a - reach_hi) * scale) - 1, 0), n - 1);
+    hi = min(max((int)((float)(b + reach_lo) * scale) + 1, 0), n - 1);
+    while (lo > 0 && g[lo] >= a - reach_hi) --lo;                             // make sure the estimate is not too tight
+    while (hi < n - 1 && g[hi + 1] <= b + reach_lo) ++hi;
+    while (lo < n - 1 && g[lo + 1] < a - reach_hi) ++lo;                      // then tighten exactly
+    while (hi > 0 && g[hi] > b + reach_lo) --hi;
+}
+
 // Classification + source region of ONE footprint.  `edge_of(k)` yields the 12 float32 edge coefficients of cell k of this
 // frame, `hi_of(k, out9)` its inverse homography as float32: from LDS when the workgroup staged its cell rows, else global.
 template <typename EdgeOf, typename HiOf, typename MarginOf>
-__device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, MarginOf margin_of, const int* s_gx, const int* s_gy, int xa, int xb,
-                                                   int ya, int yb, int rxlo, int rylo, int rxhi, int ryhi, int W, int H, int R,
-                                                   int C, FootPlan& p, FootRegion& region)
+__device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, MarginOf margin_of, int c_lo, int c_hi, int r_lo, int r_hi,
+                                                   int xa, int xb, int ya, int yb, int W, int H, int C, FootPlan& p, FootRegion& region)
 {
-    // cells whose grid rect, widened by the frame's reach, meets the footprint (contiguous index ranges)
-    // (start from the uniform-grid estimate, then walk the exact vertex coordinates: a step or two)
-    const float cs = (float)C / (float)(W - 1), rs = (float)R / (float)(H - 1);
-    int c_lo = min(max((int)((float)(xa - rxhi) * cs) - 1, 0), C - 1), c_hi = min(max((int)((float)(xb + rxlo) * cs) + 1, 0), C - 1);
-    int r_lo = min(max((int)((float)(ya - ryhi) * rs) - 1, 0), R - 1), r_hi = min(max((int)((float)(yb + rylo) * rs) + 1, 0), R - 1);
-    while (c_lo > 0 && s_gx[c_lo] >= xa - rxhi) --c_lo;                       // make sure the estimate is not too tight
-    while (c_hi < C - 1 && s_gx[c_hi + 1] <= xb + rxlo) ++c_hi;
-    while (r_lo > 0 && s_gy[r_lo] >= ya - ryhi) --r_lo;
-    while (r_hi < R - 1 && s_gy[r_hi + 1] <= yb + rylo) ++r_hi;
-    while (c_lo < C - 1 && s_gx[c_lo + 1] < xa - rxhi) ++c_lo;                // then tighten exactly as before
-    while (c_hi > 0 && s_gx[c_hi] > xb + rxlo) --c_hi;
-    while (r_lo < R - 1 && s_gy[r_lo + 1] < ya - ryhi) ++r_lo;
-    while (r_hi > 0 && s_gy[r_hi] > yb + rylo) --r_hi;
     uint16_t codes[8];
     for (int i = 0; i < 8; ++i) { p.e[i] = 0; codes[i] = 0; }
     int cnt = 0;
@@ -470,11 +469,33 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
             s_hi[i] = (float)frec[(size_t)(k0 + cell) * MF_CELL_DOUBLES + MF_CELL_OFF_HI + j];
         }
     }
+    // candidate cell ranges per footprint column and per footprint row of this workgroup, computed once (a footprint's ranges
+    // depend only on its column and on its row) instead of eight data-dependent loops per thread: table + plan -4 % at cfg2
+    __shared__ uint32_t s_crange[256], s_rrange[258];
+    const int fy_first = rem0 / nfx;
+    const int rows_here = min(rem0 + 255, per_frame - 1) / nfx - fy_first + 1;
+    const bool col_table = nfx <= 256;
+    if (col_table)
+        for (int i = threadIdx.x; i < nfx; i += 256) {
+            int lo, hi;
+            cell_range_1d(s_gx, C, W, i * MF_FOOT_W, min(i * MF_FOOT_W + MF_FOOT_W - 1, W - 1), rxlo, rxhi, lo, hi);
+            s_crange[i] = (uint32_t)lo | (uint32_t)hi << 16;
+        }
+    for (int i = threadIdx.x; i < rows_here; i += 256) {
+        int lo, hi;
+        const int yy0 = (fy_first + i) * MF_FOOT_H;
+        cell_range_1d(s_gy, R, H, yy0, min(yy0 + MF_FOOT_H - 1, H - 1), rylo, ryhi, lo, hi);
+        s_rrange[i] = (uint32_t)lo | (uint32_t)hi << 16;
+    }
     __syncthreads();
     if (rem >= per_frame) return;
     const int fy = rem / nfx, fx = rem - fy * nfx;
     const int xa = fx * MF_FOOT_W, xb = min(xa + MF_FOOT_W - 1, W - 1);
     const int ya = fy * MF_FOOT_H, yb = min(ya + MF_FOOT_H - 1, H - 1);
+    int c_lo, c_hi;
+    if (col_table) { c_lo = (int)(s_crange[fx] & 0xFFFFu); c_hi = (int)(s_crange[fx] >> 16); }
+    else cell_range_1d(s_gx, C, W, xa, xb, rxlo, rxhi, c_lo, c_hi);
+    const int r_lo = (int)(s_rrange[fy - fy_first] & 0xFFFFu), r_hi = (int)(s_rrange[fy - fy_first] >> 16);
     FootPlan p;
     FootRegion region;
     if (staged) {
@@ -482,7 +503,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
         plan_one_footprint([&](int k) { return (const float*)&s_edge[(k - k0) * MF_UEDGE_FLOATS]; },
                            [&](int k, float (&h)[9]) { for (int j = 0; j < 9; ++j) h[j] = s_hi[(k - k0) * 9 + j]; },
                            [&](int k, int e) { return fmargin[(size_t)k * MF_EDGE_FLOATS + e]; },
-                           s_gx, s_gy, xa, xb, ya, yb, rxlo, rylo, rxhi, ryhi, W, H, R, C, p, region);
+                           c_lo, c_hi, r_lo, r_hi, xa, xb, ya, yb, W, H, C, p, region);
     } else {
         plan_one_footprint([&](int k) { return fedge + (size_t)k * MF_UEDGE_FLOATS; },
                            [&](int k, float (&h)[9]) {
@@ -490,7 +511,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
                                for (int j = 0; j < 9; ++j) h[j] = (float)hi[j];
                            },
                            [&](int k, int e) { return fmargin[(size_t)k * MF_EDGE_FLOATS + e]; },
-                           s_gx, s_gy, xa, xb, ya, yb, rxlo, rylo, rxhi, ryhi, W, H, R, C, p, region);
+                           c_lo, c_hi, r_lo, r_hi, xa, xb, ya, yb, W, H, C, p, region);
     }
     const size_t gid = (size_t)f * per_frame + rem;
     plan[gid] = p;
