@@ -147,39 +147,59 @@ __global__ __launch_bounds__(64 * kWaves) void resize_kernel(const uint8_t* __re
         // Where sx is the last column of the crop the second weight is 0, so whatever lies right of it may be read.
         const bool whole = x0 + 3 < W && ((size_t)(max(row0[q], row1[q]) + (uint32_t)cw) * 3u + 8u <= limit);
         if (staged[q] || whole) {
-            uint2 a[4], b[4];
+            // per pixel and channel (S[sx], S[sx+1]) as two uint16 in one register -- {B, G, R} of source row 0, then of row 1
+            uint32_t fld[4][6];
             if (staged[q]) {
+                // from the staged rows by byte loads with immediate offsets: ds_read_u8 puts S[sx] into the low byte of one register,
+                // ds_read_u8_d16_hi S[sx+1] into bits 16-23 of another (with SRAM ECC a d16 load zeroes the other half of its
+                // destination), one v_or_b32 joins them -- instead of three dword loads, two v_alignbyte_b32 and three v_perm_b32
+                // per pixel and row (the same scheme as the warp kernel's taps, warp.hip)
+                uint32_t lo[4][6], hi[4][6];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t rel = 3u * ((uint32_t)xt[j].ofs - sx_first);
-                    const uint32_t at0 = rel + s0[q], at1 = rel + s1[q];
-                    const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(&s_rows[wave][q][at0 & ~3u]);
-                    const uint32_t* __restrict__ r = reinterpret_cast<const uint32_t*>(&s_rows[wave][q][kRowPitch + (at1 & ~3u)]);
-                    const uint32_t t0 = p[0], t1 = p[1], t2 = p[2], u0 = r[0], u1 = r[1], u2 = r[2];
-                    a[j].x = __builtin_amdgcn_alignbyte(t1, t0, at0);
-                    a[j].y = __builtin_amdgcn_alignbyte(t2, t1, at0);
-                    b[j].x = __builtin_amdgcn_alignbyte(u1, u0, at1);
-                    b[j].y = __builtin_amdgcn_alignbyte(u2, u1, at1);
+                    const uint32_t at0 = (uint32_t)(uintptr_t)&s_rows[wave][q][0] + rel + s0[q];
+                    const uint32_t at1 = (uint32_t)(uintptr_t)&s_rows[wave][q][kRowPitch] + rel + s1[q];
+                    asm volatile("ds_read_u8 %0, %6 offset:0\n\tds_read_u8_d16_hi %1, %6 offset:3\n\t"
+                                 "ds_read_u8 %2, %6 offset:1\n\tds_read_u8_d16_hi %3, %6 offset:4\n\t"
+                                 "ds_read_u8 %4, %6 offset:2\n\tds_read_u8_d16_hi %5, %6 offset:5"
+                                 : "=&v"(lo[j][0]), "=&v"(hi[j][0]), "=&v"(lo[j][1]), "=&v"(hi[j][1]), "=&v"(lo[j][2]), "=&v"(hi[j][2])
+                                 : "v"(at0));
+                    asm volatile("ds_read_u8 %0, %6 offset:0\n\tds_read_u8_d16_hi %1, %6 offset:3\n\t"
+                                 "ds_read_u8 %2, %6 offset:1\n\tds_read_u8_d16_hi %3, %6 offset:4\n\t"
+                                 "ds_read_u8 %4, %6 offset:2\n\tds_read_u8_d16_hi %5, %6 offset:5"
+                                 : "=&v"(lo[j][3]), "=&v"(hi[j][3]), "=&v"(lo[j][4]), "=&v"(hi[j][4]), "=&v"(lo[j][5]), "=&v"(hi[j][5])
+                                 : "v"(at1));
+                    if (j & 1) {
+                        // the compiler does not see these loads: wait here (two pixels' worth in flight) and hand the registers over
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(lo[j - 1][0]), "+v"(hi[j - 1][0]), "+v"(lo[j - 1][1]), "+v"(hi[j - 1][1]), "+v"(lo[j - 1][2]), "+v"(hi[j - 1][2]),
+                                       "+v"(lo[j - 1][3]), "+v"(hi[j - 1][3]), "+v"(lo[j - 1][4]), "+v"(hi[j - 1][4]), "+v"(lo[j - 1][5]), "+v"(hi[j - 1][5]),
+                                       "+v"(lo[j][0]), "+v"(hi[j][0]), "+v"(lo[j][1]), "+v"(hi[j][1]), "+v"(lo[j][2]), "+v"(hi[j][2]),
+                                       "+v"(lo[j][3]), "+v"(hi[j][3]), "+v"(lo[j][4]), "+v"(hi[j][4]), "+v"(lo[j][5]), "+v"(hi[j][5]) :: "memory");
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) { fld[j - 1][c] = lo[j - 1][c] | hi[j - 1][c]; fld[j][c] = lo[j][c] | hi[j][c]; }
+                    }
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    __builtin_memcpy(&a[j], src + (row0[q] + (uint32_t)xt[j].ofs) * 3u, 8);
-                    __builtin_memcpy(&b[j], src + (row1[q] + (uint32_t)xt[j].ofs) * 3u, 8);
+                    uint2 a, b;                                              // bytes: B0 G0 R0 B1 | G1 R1 . .
+                    __builtin_memcpy(&a, src + (row0[q] + (uint32_t)xt[j].ofs) * 3u, 8);
+                    __builtin_memcpy(&b, src + (row1[q] + (uint32_t)xt[j].ofs) * 3u, 8);
+                    fld[j][0] = __builtin_amdgcn_perm(a.y, a.x, 0x0C030C00u); fld[j][3] = __builtin_amdgcn_perm(b.y, b.x, 0x0C030C00u);
+                    fld[j][1] = __builtin_amdgcn_perm(a.y, a.x, 0x0C040C01u); fld[j][4] = __builtin_amdgcn_perm(b.y, b.x, 0x0C040C01u);
+                    fld[j][2] = __builtin_amdgcn_perm(a.y, a.x, 0x0C050C02u); fld[j][5] = __builtin_amdgcn_perm(b.y, b.x, 0x0C050C02u);
                 }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                // bytes: B0 G0 R0 B1 | G1 R1 . .  -> (S[sx], S[sx+1]) as two uint16 per channel, then v_dot2_u32_u16 with
-                // the weights pre-scaled by 16: T = 16 t < 2^24, T & ~255 = 256 (t >> 4), and (b * (t >> 4)) >> 16 is the
-                // high half of the 24 x 24-bit product (256 b) * (256 (t >> 4)): one v_and + one v_mul_hi_u32_u24 per term
+                // v_dot2_u32_u16 with the weights pre-scaled by 16: T = 16 t < 2^24, T & ~255 = 256 (t >> 4), and
+                // (b * (t >> 4)) >> 16 is the high half of the 24 x 24-bit product (256 b) * (256 (t >> 4)): one v_and + one
+                // v_mul_hi_u32_u24 per term
                 const uint32_t w = xt[j].w;                                        // 16 a0 | 16 a1 << 16
-                const uint32_t tB0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C030C00u), w, 0u);
-                const uint32_t tG0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C040C01u), w, 0u);
-                const uint32_t tR0 = udot2(__builtin_amdgcn_perm(a[j].y, a[j].x, 0x0C050C02u), w, 0u);
-                const uint32_t tB1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C030C00u), w, 0u);
-                const uint32_t tG1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C040C01u), w, 0u);
-                const uint32_t tR1 = udot2(__builtin_amdgcn_perm(b[j].y, b[j].x, 0x0C050C02u), w, 0u);
+                const uint32_t tB0 = udot2(fld[j][0], w, 0u), tG0 = udot2(fld[j][1], w, 0u), tR0 = udot2(fld[j][2], w, 0u);
+                const uint32_t tB1 = udot2(fld[j][3], w, 0u), tG1 = udot2(fld[j][4], w, 0u), tR1 = udot2(fld[j][5], w, 0u);
                 const uint32_t vB = (mulhi_u24(b0s[q], tB0 & ~255u) + mulhi_u24(b1s[q], tB1 & ~255u) + 2u) >> 2;
                 const uint32_t vG = (mulhi_u24(b0s[q], tG0 & ~255u) + mulhi_u24(b1s[q], tG1 & ~255u) + 2u) >> 2;
                 const uint32_t vR = (mulhi_u24(b0s[q], tR0 & ~255u) + mulhi_u24(b1s[q], tR1 & ~255u) + 2u) >> 2;
