@@ -109,24 +109,6 @@ __device__ __forceinline__ int cv_round_f32(float v)
     return (r >= -2147483648.0f && r < 2147483648.0f) ? (int)r : (int)0x80000000;
 }
 
-// One source pixel as B | G << 8 | R << 16, or the border colour when (tx, ty) is outside the frame.  Branch-free: the load
-// goes to the clamped position and the result is replaced afterwards, so that the sixteen loads of a lane's four pixels can all be
-// in flight together (the border footprints that need this path are 5-9 % of a stabilised clip's footprints).
-// `limit` = bytes from the frame base to the end of the whole frame stack (saturated to 32 bits), so the 4-byte load of the
-// very last pixel is shifted back by one byte instead of running past the allocation.
-__device__ __forceinline__ uint32_t fetch_bgr(const uint8_t* __restrict__ frame, int W, int H, int tx, int ty,
-                                              uint32_t border, uint32_t limit)
-{
-    const bool inside = (unsigned)tx < (unsigned)W && (unsigned)ty < (unsigned)H;
-    const uint32_t cx = (uint32_t)min(max(tx, 0), W - 1), cy = (uint32_t)min(max(ty, 0), H - 1);
-    const uint32_t o = (cy * (uint32_t)W + cx) * 3u;
-    const uint32_t back = o + 4u > limit ? 1u : 0u;
-    uint32_t v;
-    __builtin_memcpy(&v, frame + (o - back), 4);
-    v >>= 8u * back;
-    return inside ? (v & 0xFFFFFFu) : border;
-}
-
 // OpenCV's mask test, exactly (imgwarp.cpp WarpPerspectiveInvoker: 64-wide destination blocks).
 __device__ __forceinline__ bool mask_test_exact(const double* __restrict__ M, int lo_x, int hi_x, int lo_y, int hi_y,
                                              int x, int y)
@@ -852,10 +834,19 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
                 }
             }
         } else {
-            // generic path: frame borders, uncovered pixels, crop flags, out-of-range coordinates
+            // generic path: frame borders, uncovered pixels, crop flags, out-of-range coordinates (3 % of a stabilised clip's
+            // footprints -- the ring along the frame border whose pixels sample outside the frame)
             int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
             if (active) {
-            uint32_t px[4];
+            // sx = rint(32 u) sits in the low bits of fixed_point's raw floats while |sx| < 2^22; coordinates beyond that (a cell far
+            // from affine) take cv2's own rounding with its saturation
+            uint32_t spread = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                spread = max(spread, max(bx[j] - (0x4B400000u - 0x200000u), by[j] - (0x4B400000u - 0x200000u)));
+            const bool narrow = __ballot(spread >= 0x400000u) == 0;
+            const bool has_tail = limit != 0xFFFFFFFFu;      // last frame of the stack: the 4-byte load of its last pixel is shifted back
+            uint32_t oB[4], oG[4], oR[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float uu = u[j], vv = v[j];
@@ -868,28 +859,50 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
                     if (fabsf(vv) < 1.0f) c_top = max(c_top, y);
                     if (fabsf(vv - fHm1) < 1.0f) c_bottom = min(c_bottom, y);
                 }
-                const int sxx = cv_round_f32(uu * 32.0f), syy = cv_round_f32(vv * 32.0f);
+                const int sxx = narrow ? (int)(bx[j] - 0x4B400000u) : cv_round_f32(uu * 32.0f);
+                const int syy = narrow ? (int)(by[j] - 0x4B400000u) : cv_round_f32(vv * 32.0f);
                 const int ix = sxx >> 5, iy = syy >> 5;      // (saturation to int16 cannot change any decision below)
-                const uint32_t fx = sxx & 31, fy = syy & 31;
-                // (a 2 x 2 footprint that lies outside altogether needs no special case: four border-colour taps with weights that
-                // sum to 1024 give the border colour exactly)
-                const uint32_t p00 = fetch_bgr(src, W, H, ix, iy, border, limit);
-                const uint32_t p01 = fetch_bgr(src, W, H, ix + 1, iy, border, limit);
-                const uint32_t p10 = fetch_bgr(src, W, H, ix, iy + 1, border, limit);
-                const uint32_t p11 = fetch_bgr(src, W, H, ix + 1, iy + 1, border, limit);
-                const uint32_t w00 = (32u - fx) * (32u - fy), w01 = fx * (32u - fy), w10 = (32u - fx) * fy, w11 = fx * fy;
-                uint32_t r = 0;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const uint32_t acc = w00 * ((p00 >> (8 * c)) & 255u) + w01 * ((p01 >> (8 * c)) & 255u) +
-                                         w10 * ((p10 >> (8 * c)) & 255u) + w11 * ((p11 >> (8 * c)) & 255u);
-                    r |= ((acc + 512u) >> 10) << (8 * c);
+                // The four taps, branch-free: each load goes to the position clamped into the frame and the tap is replaced by the
+                // border colour afterwards when it lies outside (a 2 x 2 footprint outside altogether needs no special case: four
+                // border-colour taps with weights that sum to 1024 give the border colour exactly).  All sixteen loads of the lane
+                // are in flight together.
+                const bool in_x0 = (unsigned)ix < (unsigned)W, in_x1 = (unsigned)(ix + 1) < (unsigned)W;
+                const bool in_y0 = (unsigned)iy < (unsigned)H, in_y1 = (unsigned)(iy + 1) < (unsigned)H;
+                const uint32_t cx0 = (uint32_t)min(max(ix, 0), W - 1), cx1 = (uint32_t)min(max(ix + 1, 0), W - 1);
+                const uint32_t r0 = (uint32_t)min(max(iy, 0), H - 1) * (uint32_t)W, r1 = (uint32_t)min(max(iy + 1, 0), H - 1) * (uint32_t)W;
+                const uint32_t o00 = (r0 + cx0) * 3u, o01 = (r0 + cx1) * 3u, o10 = (r1 + cx0) * 3u, o11 = (r1 + cx1) * 3u;
+                uint32_t p00, p01, p10, p11;                 // B | G << 8 | R << 16 | (next byte) << 24
+                if (has_tail) {
+                    const uint32_t k00 = o00 + 4u > limit, k01 = o01 + 4u > limit, k10 = o10 + 4u > limit, k11 = o11 + 4u > limit;
+                    __builtin_memcpy(&p00, src + (o00 - k00), 4); p00 >>= 8u * k00;
+                    __builtin_memcpy(&p01, src + (o01 - k01), 4); p01 >>= 8u * k01;
+                    __builtin_memcpy(&p10, src + (o10 - k10), 4); p10 >>= 8u * k10;
+                    __builtin_memcpy(&p11, src + (o11 - k11), 4); p11 >>= 8u * k11;
+                } else {
+                    __builtin_memcpy(&p00, src + o00, 4);
+                    __builtin_memcpy(&p01, src + o01, 4);
+                    __builtin_memcpy(&p10, src + o10, 4);
+                    __builtin_memcpy(&p11, src + o11, 4);
                 }
-                px[j] = r;
+                p00 = in_x0 && in_y0 ? p00 : border;
+                p01 = in_x1 && in_y0 ? p01 : border;
+                p10 = in_x0 && in_y1 ? p10 : border;
+                p11 = in_x1 && in_y1 ? p11 : border;
+                // the blend of the fast path: per channel the two horizontal neighbours in 16-bit fields, both lerped vertically at
+                // once, then v_dot2_u32_u16 horizontally (byte 3 of the taps is never selected)
+                const uint32_t fy = (uint32_t)syy & 31u, wy = 32u - fy;
+                const uint32_t vB = umad24(__builtin_amdgcn_perm(p11, p10, 0x0C040C00u), fy, __umul24(__builtin_amdgcn_perm(p01, p00, 0x0C040C00u), wy));
+                const uint32_t vG = umad24(__builtin_amdgcn_perm(p11, p10, 0x0C050C01u), fy, __umul24(__builtin_amdgcn_perm(p01, p00, 0x0C050C01u), wy));
+                const uint32_t vR = umad24(__builtin_amdgcn_perm(p11, p10, 0x0C060C02u), fy, __umul24(__builtin_amdgcn_perm(p01, p00, 0x0C060C02u), wy));
+                const uint32_t wq = umad24((uint32_t)sxx & 31u, 0x3FFFC0u, 2048u);          // 64 (32 - fx) | 64 fx << 16
+                oB[j] = udot2(vB, wq, 32768u);
+                oG[j] = udot2(vG, wq, 32768u);
+                oR[j] = udot2(vR, wq, 32768u);
             }
-            d.x = px[0] | (px[1] << 24);
-            d.y = (px[1] >> 8) | (px[2] << 16);
-            d.z = (px[2] >> 16) | (px[3] << 8);
+            const uint32_t pair = 0x0C0C0602u, pair_hi = 0x06020C0Cu;       // byte 2 of each sum, as in gather_blend_staged
+            d.x = __builtin_amdgcn_perm(oB[1], oR[0], pair_hi) | __builtin_amdgcn_perm(oG[0], oB[0], pair);
+            d.y = __builtin_amdgcn_perm(oG[2], oB[2], pair_hi) | __builtin_amdgcn_perm(oR[1], oG[1], pair);
+            d.z = __builtin_amdgcn_perm(oR[3], oG[3], pair_hi) | __builtin_amdgcn_perm(oB[3], oR[2], pair);
             }
             // Crop bounds (only this path can set one): wave reduction, then at most one atomic per bound and wavefront.
             const bool any = c_left != 0 || c_top != 0 || c_right != W - 1 || c_bottom != H - 1;
