@@ -488,7 +488,7 @@ def main():
                          'traffic': traffic, 'traffic_source': 'profiles/traffic.json (PMC: size-resolved TCC_EA0_RDREQ read requests + WRITE_SIZE)'
                          if traffic else None,
                          'algorithmic_bytes_per_launch': algo_bytes, 'avg_launch_ms': warp_ms,
-                         'note': 'VALU-issue bound (float64 coordinate arithmetic), not HBM bound: see DESIGN.md'},
+                         'note': 'bound by vector and scalar instruction issue (float64 coordinates, integer blend, one wavefront per 32x8 footprint), not by HBM: DESIGN.md 4.3'},
             'jacobi': {'avg_ms_incl_host_setup': jac_ms, 'kernel_ms': jac_kernel_ms, 'series': int(d_disp[0].numel()), 'frames': F,
                        'bound': 'fp64 vector ALU + LDS (the state never leaves the chip)', 'achieved': jac_flops / (jac_kernel_ms * 1e-3) / 1e12,
                        'peak': 78.6, 'unit': 'TFLOP/s', 'frac': jac_flops / (jac_kernel_ms * 1e-3) / 78.6e12},
