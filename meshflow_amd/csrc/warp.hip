@@ -39,7 +39,7 @@
 //      "no owner" is a ninth LDS row holding the matrix that maps every pixel to (W+1, H+1) -- the coordinate code has no
 //      special case.  Footprints the plan could not certify (frame border, uncovered pixels, oversized or unaligned windows)
 //      check per pixel and use either two unaligned 8-byte global loads per pixel or the per-tap path with border colour and
-//      crop flags.
+//      crop flags (branch-free: loads at positions clamped into the frame, border colour selected afterwards).
 //   6. cv2.remap: sx = rint(32u) via one fma against 1.5*2^23; taps = LDS byte loads straight into the blend's layout (the two
 //      horizontal neighbours of a channel in the 16-bit halves of a register); v_mul_u32_u24 + v_mad_u32_u24 lerp both halves
 //      vertically at once, v_dot2_u32_u16 lerps horizontally with weights scaled so that the rounded byte lands in byte 2; six
