@@ -441,7 +441,9 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
     const cword_t pw = (cword_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(plan) + 16u * fp);
     const cword_t rw = (cword_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(regions) + 8u * fp);
     const uint4 pv = make_uint4(pw[0], pw[1], pw[2], pw[3]);             // wave-uniform: scalar loads
-    const uint32_t rg = rw[0], src_dwords = rw[1];
+    typedef const __attribute__((address_space(4))) uint64_t* cword2_t;
+    const uint64_t region = *(cword2_t)rw;                               // both words in one load (the second is needed right after the first)
+    const uint32_t rg = (uint32_t)region, src_dwords = (uint32_t)(region >> 32);
     const uint8_t* __restrict__ src = frames + (uint64_t)f * g.frame_bytes;
     const bool staged = STAGE_OK && (rg & MF_REGION_STAGED) != 0;
     if (staged) {
@@ -455,10 +457,10 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
                       (((uint32_t)lane << 4) + 1024u);
         asm("" : "+v"(o0));
         asm("" : "+v"(o1));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o0),
-                                         (__attribute__((address_space(3))) void*)&s_src[0], 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o1),
-                                         (__attribute__((address_space(3))) void*)&s_src[1024], 16, 0, 0);
+        // (one generic -> LDS conversion: each comes with a null check)
+        __attribute__((address_space(3))) uint8_t* const window = (__attribute__((address_space(3))) uint8_t*)&s_src[0];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o0), (__attribute__((address_space(3))) void*)window, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o1), (__attribute__((address_space(3))) void*)(window + 1024), 16, 0, 0);
     }
     // taps are addressed by absolute LDS byte address (= LDS_PITCH iy + 3 ix - lds_origin): the window base is folded in
     const uint32_t lds_origin = (rg & MF_REGION_ORIGIN_MASK) - (uint32_t)(uintptr_t)&s_src[0];
