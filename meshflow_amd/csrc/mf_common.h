@@ -184,6 +184,7 @@ int launch_cell_table(const double* unstab, const double* stab, int n, int W, in
                       const TableView& tv, int32_t* crop, int32_t* status, hipStream_t st);
 int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n, int W, int H, int R, int C,
                 uint32_t border, int32_t* crop, hipStream_t st);
+int check_d16_zero_fill(hipStream_t st);          // warp.hip: one-time device check the byte-tap kernels rely on
 int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t st);
 size_t crop_resize_workspace_bytes(int W, int H);
 int launch_crop_resize(const uint8_t* frames, uint8_t* out, int n, int W, int H, int left, int top, int right,

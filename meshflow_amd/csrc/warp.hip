@@ -984,9 +984,41 @@ int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigne
     return hip_fail(hipGetLastError(), "selftest_recip_kernel launch");
 }
 
+// The byte taps (gather_blend_staged here, the staged rows in resize.hip) rely on ds_read_u8_d16_hi ZEROING the low half of its
+// destination, which is what a device with SRAM ECC does (every MI300-class part; measured on the MI355X) -- without SRAM ECC the
+// low half would be preserved.  Checked once per process on the device in use; a device that behaves differently is refused.
+__device__ int d16_probe_result;
+__global__ void d16_probe_kernel()
+{
+    __shared__ uint8_t s[8];
+    if (threadIdx.x < 8) s[threadIdx.x] = (uint8_t)(0x11 * (threadIdx.x + 1));
+    __syncthreads();
+    uint32_t r = 0xFFFFFFFFu;
+    const uint32_t at = (uint32_t)(uintptr_t)&s[0];
+    asm volatile("ds_read_u8_d16_hi %0, %1 offset:3\n\ts_waitcnt lgkmcnt(0)" : "+v"(r) : "v"(at) : "memory");
+    if (threadIdx.x == 0) d16_probe_result = r == 0x00440000u ? 1 : -1;
+}
+int check_d16_zero_fill(hipStream_t st)
+{
+    static int state = 0;                       // 0 unknown, 1 fine, -1 refused  (benign race: every thread computes the same)
+    if (state == 0) {
+        int h = 0;
+        hipLaunchKernelGGL(d16_probe_kernel, dim3(1), dim3(64), 0, st);
+        if (hipStreamSynchronize(st) != hipSuccess || hipMemcpyFromSymbol(&h, HIP_SYMBOL(d16_probe_result), sizeof h) != hipSuccess)
+            return hip_fail(hipGetLastError(), "d16 probe");
+        state = h == 1 ? 1 : -1;
+    }
+    if (state != 1) {
+        set_error("this device preserves the other half of a d16 LDS load (no SRAM ECC): the byte-tap kernels are not built for it");
+        return MF_ERR_INVALID_ARG;
+    }
+    return MF_OK;
+}
+
 int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n, int W, int H, int R, int C,
                 uint32_t border, int32_t* crop, hipStream_t st)
 {
+    if (const int rc = check_d16_zero_fill(st)) return rc;
     if (n <= 0 || n > 65535 || W < 2 || H < 2 || W > 32767 || H > 32767 || R <= 0 || C <= 0 || R > MAX_MESH ||
         C > MAX_MESH) {
         set_error("mf_warp_u8c3: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
