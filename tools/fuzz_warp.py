@@ -2,7 +2,7 @@
 tests/: random frame sizes, mesh shapes and motion strengths, including geometries where most footprints take the plan-certified
 hot / pair / multi paths (large cells) and ones that stress the general path (small cells, strong jitter).
 
-    python tools/fuzz_warp.py [cases] [seed]        (needs an MI355X; every case must be bit-identical)
+    python tools/fuzz_warp.py [cases] [seed] [large]        (needs an MI355X; every case must be bit-identical)
 """
 import os
 import sys
@@ -16,13 +16,15 @@ from oracle import clib
 
 
 
-def run(cases, seed, verbose=True):
+def run(cases, seed, verbose=True, large=False):
   rng = np.random.default_rng(seed)
   dev = torch.device('cuda:0')
   bad_total = 0
   for case in range(cases):
       W = int(rng.integers(8, 120)) * 4 if rng.random() < 0.85 else int(rng.integers(30, 400))      # mostly W % 4 == 0 (staged windows)
       H = int(rng.integers(24, 300))
+      if large:                                                 # up to 1280 x 720: cells large enough for long runs of certified footprints
+          W, H = int(rng.integers(100, 321)) * 4, int(rng.integers(200, 721))
       R, C = int(rng.integers(1, 9)), int(rng.integers(1, 9))
       if rng.random() < 0.2:
           R, C = int(rng.integers(8, 33)), int(rng.integers(8, 33))
@@ -65,6 +67,6 @@ def run(cases, seed, verbose=True):
 
 if __name__ == '__main__':
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    n_bad = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    n_bad = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0, large='large' in sys.argv[3:])
     print(f'{n_cases} cases, {n_bad} mismatches')
     sys.exit(1 if n_bad else 0)
