@@ -145,6 +145,13 @@ int mf_selftest_sqrt(uint64_t n, uint64_t seed, uint64_t* mismatches);
  * n hashed inputs; *mismatches receives the number of differing bit patterns (must be 0). Synchronous. */
 int mf_selftest_recip(uint64_t n, uint64_t seed, uint64_t* mismatches);
 
+/* Device self-test: the warp kernel's cheap float64 coordinate chain + float32-midpoint guard (hot footprints)
+ * against cv2.perspectiveTransform's own arithmetic on n hashed (matrix, position) cases that satisfy the plan's premises.
+ * counters[0] = float32 coordinates that differ from the exact chain's WITHOUT the guard raising its flag (must be 0),
+ * counters[1] = values the guard flagged (each sends its wavefront to the exact chain), counters[2] = values tested.
+ * Synchronous. */
+int mf_selftest_fast64(uint64_t n, uint64_t seed, uint64_t counters[3]);
+
 /* ---- host-buffer convenience wrappers (synchronous; H2D, kernels, D2H on an internal stream) ----
  * These are what a ctypes stub inside the reference's two methods would call.
  * kernel_ms (optional) receives the device time of the kernels alone, measured with HIP events. */

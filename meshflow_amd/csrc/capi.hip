@@ -173,6 +173,18 @@ int mf_selftest_recip(uint64_t n, uint64_t seed, uint64_t* mismatches)
     return run_selftest(launch_selftest_recip, n, seed, mismatches);
 }
 
+int mf_selftest_fast64(uint64_t n, uint64_t seed, uint64_t* counters)
+{
+    if (!counters) { set_error("mf_selftest_fast64: null"); return MF_ERR_INVALID_ARG; }
+    void* d = nullptr;
+    MF_HIP_TRY(hipMalloc(&d, 3 * sizeof(uint64_t)));
+    hipError_t e = hipMemset(d, 0, 3 * sizeof(uint64_t));
+    int rc = e == hipSuccess ? launch_selftest_fast64(n, seed, (unsigned long long*)d, nullptr) : hip_fail(e, "hipMemset");
+    if (rc == MF_OK) rc = hip_fail(hipMemcpy(counters, d, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy");
+    (void)hipFree(d);
+    return rc;
+}
+
 // ---- host-buffer wrappers ------------------------------------------------------------------------
 
 namespace {

@@ -361,17 +361,18 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             p.e[cnt++] = (uint16_t)(k | MF_PLAN_VALID | (all_in ? MF_PLAN_IN : 0u));
             if (all_in) closed = true;
             // source position of the four footprint corners under this cell's inverse homography (float32 is ample:
-            // the window keeps a pixel of slack, the float32 error at coordinates below 32768 is below 0.01)
+            // the window keeps 1/16 pixel of slack, the float32 error at coordinates up to 8192 is below 0.01)
             float h[9];
             hi_of(k, h);
             for (int q = 0; q < 4; ++q) {
                 const float cx = cxs[q & 1], cy = cys[q >> 1];
                 const float w = h[6] * cx + h[7] * cy + h[8];
                 sane = sane && w > 0.25f && w < 4.0f;                     // (NaN fails)
+                const float nx = h[0] * cx + h[1] * cy + h[2], ny = h[3] * cx + h[4] * cy + h[5];
                 if (cnt == 1) { wlo = fminf(wlo, w); whi = fmaxf(whi, w); h6_first = h[6]; }
                 wlo_all = fminf(wlo_all, w); whi_all = fmaxf(whi_all, w);
-                const float iw = __builtin_amdgcn_rcpf(w);            // (1 ulp: the window keeps a pixel of slack)
-                const float u = (h[0] * cx + h[1] * cy + h[2]) * iw, v = (h[3] * cx + h[4] * cy + h[5]) * iw;
+                const float iw = __builtin_amdgcn_rcpf(w);            // (1 ulp: the window keeps a sixteenth of a pixel of slack)
+                const float u = nx * iw, v = ny * iw;
                 umin = fminf(umin, u); umax = fmaxf(umax, u);
                 vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
             }
@@ -402,26 +403,57 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
     region.src_dwords = 0;
     if (sane && cnt > 0 && !overflow && (W & 3) == 0 && 3 * W >= MF_STAGE_PITCH && H > MF_STAGE_ROWS &&
         umin > -4.0f && vmin > -4.0f && umax < 40000.0f && vmax < 40000.0f) {
-        // taps of a pixel at (u, v): columns floor(u) .. floor(u)+1 up to 1/64 px of rounding -> one pixel of slack
-        const int ix_lo = (int)floorf(umin) - 1, ix_hi = (int)floorf(umax) + 2;
-        const int iy_lo = (int)floorf(vmin) - 1, iy_hi = (int)floorf(vmax) + 2;
+        // Taps of a pixel at (u, v): columns ix, ix + 1 with ix = rint(32 u) >> 5 in [floor(u - 1/64), floor(u + 1/64)], same for
+        // rows.  u and v over the footprint stay between their corner values (ratios of affine functions, w > 0), and the corner
+        // values here are float32 evaluations: error below 0.01 at coordinates up to 8192 (a few operations at 2^-24 relative,
+        // the reciprocal to 1 ulp).  So a slack of 1/16 pixel covers both (1/64 + 0.01 < 1/16); a whole pixel on larger frames.
+        const float slack = (W <= 8192 && H <= 8192) ? 0.0625f : 1.0f;
+        const int ix_lo = (int)floorf(umin - slack), ix_hi = (int)floorf(umax + slack) + 1;
+        const int iy_lo = (int)floorf(vmin - slack), iy_hi = (int)floorf(vmax + slack) + 1;
         const int sx0 = min(max(ix_lo, 0), (3 * W - MF_STAGE_PITCH) / 3), sy0 = min(max(iy_lo, 0), H - MF_STAGE_ROWS - 1);
         if (ix_lo >= sx0 && ix_hi <= sx0 + MF_STAGE_COLS - 1 && iy_lo >= sy0 && iy_hi <= sy0 + MF_STAGE_ROWS - 1)
         {
-            // DEEP also asks for a whole footprint (all 256 pixels inside the frame): its lanes are then all active
+            // DEEP also asks for a whole footprint (all 256 pixels inside the frame): its lanes are then all active.
+            // Interior: every tap inside the frame (ix_lo >= 0, ix_hi <= W - 1) and no crop flag possible -- |u| < 1 needs
+            // u < 1 but u >= ix_lo + 1/16 - 1/100; |u - (W-1)| < 1 needs u > W - 2 but u < ix_hi - 1/16 + 1/100 (mfs.py:1075-1098).
             const bool whole = xb - xa == MF_FOOT_W - 1 && yb - ya == MF_FOOT_H - 1;
-            const bool deep = covered && whole && ix_lo >= 2 && ix_hi <= W - 3 && iy_lo >= 2 && iy_hi <= H - 3;
+            const bool interior = whole && ix_lo >= 1 && ix_hi <= W - 2 && iy_lo >= 1 && iy_hi <= H - 2;
+            const bool deep = covered && interior;
             const uint32_t bs = (3u * (uint32_t)sx0) & ~3u;
             region.flags_origin = MF_REGION_STAGED | (deep ? MF_REGION_DEEP : 0u) | ((uint32_t)sy0 * MF_STAGE_PITCH + bs);
             region.src_dwords = ((uint32_t)sy0 * (3u * (uint32_t)W) + bs) >> 2;
-            if (deep && p.e[1] == (uint16_t)MF_PLAN_UNIT && (p.e[0] & (MF_PLAN_VALID | MF_PLAN_IN)) == (MF_PLAN_VALID | MF_PLAN_IN))
-                p.e[1] = (uint16_t)(MF_PLAN_UNIT | MF_PLAN_HOT);
+            if (deep && p.e[1] == (uint16_t)MF_PLAN_UNIT && (p.e[0] & (MF_PLAN_VALID | MF_PLAN_IN)) == (MF_PLAN_VALID | MF_PLAN_IN)) {
+                // FAST64: no cancellation in the numerators (sum of the terms' magnitudes at most 8 x the value, everywhere on
+                // the footprint: the former grows with x and y, the latter is smallest at a corner), denominator terms bounded --
+                // the premises of the warp kernel's error bound for its cheap coordinate chain (warp.hip, cell_coords_fast)
+                // (evaluated here, for hot footprints only, from the cell's matrix read again: keeps the candidate loop's registers)
+                float h[9];
+                hi_of(p.e[0] & 0xFFFu, h);
+                float nx_lo = 1e30f, ny_lo = 1e30f;
+                for (int q = 0; q < 4; ++q) {
+                    const float cx = cxs[q & 1], cy = cys[q >> 1];
+                    nx_lo = fminf(nx_lo, h[0] * cx + h[1] * cy + h[2]);
+                    ny_lo = fminf(ny_lo, h[3] * cx + h[4] * cy + h[5]);
+                }
+                // (sums of magnitudes: largest at the far corner, x, y >= 0)
+                const float nabs_x = fabsf(h[0]) * cxs[1] + fabsf(h[1]) * cys[1] + fabsf(h[2]);
+                const float nabs_y = fabsf(h[3]) * cxs[1] + fabsf(h[4]) * cys[1] + fabsf(h[5]);
+                const float wabs = fabsf(h[6]) * cxs[1] + fabsf(h[7]) * cys[1] + fabsf(h[8]);
+                const bool fast64 = nx_lo > 0.0f && ny_lo > 0.0f && nabs_x <= 7.9f * nx_lo && nabs_y <= 7.9f * ny_lo && wabs <= 2.45f;
+                p.e[1] = (uint16_t)(MF_PLAN_UNIT | MF_PLAN_HOT | (fast64 ? MF_PLAN_FAST64 : 0u));
+                // COMPACT window: 9 rows x 112 bytes hold every tap -> one global->LDS load instead of two
+                const uint32_t cbs = (3u * (uint32_t)ix_lo) & ~3u;
+                if (iy_hi - iy_lo + 1 <= MF_COMPACT_ROWS && 3u * (uint32_t)ix_hi + 3u <= cbs + MF_COMPACT_PITCH &&
+                    iy_lo + MF_COMPACT_ROWS <= H - 1) {                     // (the load's 64th chunk: first of row sy0 + 9)
+                    region.flags_origin = MF_REGION_STAGED | MF_REGION_DEEP | MF_REGION_COMPACT | ((uint32_t)iy_lo * MF_COMPACT_PITCH + cbs);
+                    region.src_dwords = ((uint32_t)iy_lo * (3u * (uint32_t)W) + cbs) >> 2;
+                }
+            }
             // the pair shape (`covered`: the second cell is IN, or the two single-edge masks overlap across the footprint)
             if (deep && !overflow && cnt == 2 && single_ok[0] && !(p.e[0] & MF_PLAN_IN) && wlo_all > 0.52f && whi_all < 1.9f)
                 p.e[2] = (uint16_t)MF_PLAN_HOT;
             // the multi shape: coverage is left to the kernel
-            else if (whole && ix_lo >= 2 && ix_hi <= W - 3 && iy_lo >= 2 && iy_hi <= H - 3 && !overflow && cnt >= 2 && cnt <= 4 && coded &&
-                     wlo_all > 0.52f && whi_all < 1.9f)
+            else if (interior && !overflow && cnt >= 2 && cnt <= 4 && coded && wlo_all > 0.52f && whi_all < 1.9f)
                 p.e[4] = (uint16_t)(p.e[4] | MF_PLAN_HOT | ((uint32_t)(cnt - 1) << MF_PLAN_COUNT_SHIFT));
         }
     }

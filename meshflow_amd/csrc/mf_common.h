@@ -55,6 +55,10 @@ inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 // (bit 13: clear in every valid entry -- cell indices take bits 0-11 -- and in the raw row / column numbers of an overflow list, so
 // the kernel tests this one bit without looking at the rest of the list)
 #define MF_PLAN_HOT 0x2000u
+// ... and MF_PLAN_FAST64 (only with HOT) the premises of the warp kernel's cheap float64 coordinate chain (warp.hip,
+// cell_coords_fast): at every pixel of the footprint |h0| x + |h1| y + |h2| <= 8 (h0 x + h1 y + h2), the same for the second row,
+// and |h6| x + |h7| y + |h8| <= 2.5.
+#define MF_PLAN_FAST64 0x0002u
 // A list of exactly TWO cells leaves entries 2 and 3 unused; MF_PLAN_HOT in entry 2 then certifies the "pair" shape: the first
 // (later, winning) cell is MIXED with ONE mask edge that can fail inside the footprint (its code in e[4]); whatever it does not take
 // belongs to the second cell (which is IN, or single-edge with the pair covering every pixel); both denominators stay in
@@ -84,6 +88,12 @@ struct alignas(8) FootRegion { uint32_t flags_origin, src_dwords; };
 // provably overlap across the footprint (either way every pixel has an owner), and the region
 // stays two pixels inside the frame, so the warp kernel needs neither the interior check nor the crop flags.
 #define MF_REGION_DEEP 0x40000000u
+// bit 29 = COMPACT (only on HOT footprints, with STAGED and DEEP): every tap lies in MF_COMPACT_ROWS rows of MF_COMPACT_PITCH bytes
+// starting at the dword that holds column sx0 of row sy0 -- 63 chunks of 16 bytes, ONE global->LDS load per wavefront; origin and
+// src_dwords then refer to that layout (origin = MF_COMPACT_PITCH sy0 + bs).
+#define MF_REGION_COMPACT 0x20000000u
+#define MF_COMPACT_PITCH 112
+#define MF_COMPACT_ROWS 9
 #define MF_STAGE_CHUNKS 128            // two 16-byte chunks per lane: 12 rows x 10 chunks + 8 chunks of a 13th row (unused)
 struct TableView {
     double* records; CellBox* boxes; float* edges; float* uedges; FootPlan* plan; FootRegion* regions; int32_t* reach; int32_t* grid;
@@ -186,6 +196,7 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
                 uint32_t border, int32_t* crop, hipStream_t st);
 int check_d16_zero_fill(hipStream_t st);          // warp.hip: one-time device check the byte-tap kernels rely on
 int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t st);
+int launch_selftest_fast64(unsigned long long n, unsigned long long seed, unsigned long long* d_counters, hipStream_t st);
 size_t crop_resize_workspace_bytes(int W, int H);
 int launch_crop_resize(const uint8_t* frames, uint8_t* out, int n, int W, int H, int left, int top, int right,
                        int bottom, void* work, hipStream_t st);

@@ -227,6 +227,59 @@ __device__ __forceinline__ void cell_coords(crec_t rec, double xs0, double yy, i
     }
 }
 
+#ifndef MF_NO_FAST64
+// FAST COORDINATES.  cv2.perspectiveTransform's float64 chain -- (x h0 + y h1) + h2 with every product and sum rounded, the
+// correctly rounded 1 / w, the rounded product -- only matters through its float32 conversion.  A cheaper float64 chain (fused
+// affine forms, a reciprocal good to an ulp) lands within a few dozen float64 ulps of the exact chain's value (bound: DESIGN.md
+// section 4.3, certified per footprint by the plan: MF_PLAN_FAST64), so both convert to the SAME float32 unless the cheap value lies
+// within that distance of a float32 rounding midpoint, i.e. unless the low 29 mantissa bits are within FAST64_WINDOW of 0x10000000.
+// midpoint_key() is 0 exactly then (one add + one and on the low dword); a wavefront with any such value redoes its
+// coordinates with the exact chain (about one wavefront in 2,000 at config-2 geometry).
+constexpr uint32_t FAST64_WINDOW = 256u;
+__device__ __forceinline__ uint32_t midpoint_key(double a)
+{
+    return ((uint32_t)__double_as_longlong(a) + (0x10000000u + FAST64_WINDOW)) & (0x1FFFFFFFu & ~(2u * FAST64_WINDOW - 1u));
+}
+
+// The hot path's coordinates by the cheap chain; false (wave-uniform) when some value is too close to a float32 midpoint.
+// `keys` (self-test only): the eight midpoint keys, u then v per pixel.
+__device__ __forceinline__ bool coords_fast(const double (&Hi)[9], double xs0, double yy, float (&u)[4], float (&v)[4], uint32_t* keys = nullptr)
+{
+    const double c0 = __builtin_fma(yy, Hi[1], Hi[2]), c3 = __builtin_fma(yy, Hi[4], Hi[5]), c6 = __builtin_fma(yy, Hi[7], Hi[8]);
+    const double w0 = __builtin_fma(xs0, Hi[6], c6);
+    double r0 = __builtin_amdgcn_rcp(w0);
+    double e = __builtin_fma(-w0, r0, 1.0);
+    r0 = __builtin_fma(r0, e, r0);
+    e = __builtin_fma(-w0, r0, 1.0);
+    r0 = __builtin_fma(r0, e, r0);
+    const double c1 = Hi[6] * (r0 * r0), c2 = (Hi[6] * c1) * r0;
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double xs = xs0 + (double)j;
+        double g = r0;
+        if (j > 0) {
+            const double wj = __builtin_fma(xs, Hi[6], c6);
+            g = recip_guess(r0, c1, c2, (double)j);
+            g = __builtin_fma(g, __builtin_fma(-wj, g, 1.0), g);
+        }
+        const double a = __builtin_fma(xs, Hi[0], c0) * g, b = __builtin_fma(xs, Hi[3], c3) * g;
+        u[j] = (float)a;
+        v[j] = (float)b;
+        key = min(key, min(midpoint_key(a), midpoint_key(b)));
+        if (keys) { keys[2 * j] = midpoint_key(a); keys[2 * j + 1] = midpoint_key(b); }
+    }
+    return __ballot(key == 0u) == 0;
+}
+__device__ __forceinline__ bool cell_coords_fast(crec_t rec, double xs0, double yy, float (&u)[4], float (&v)[4])
+{
+    double Hi[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Hi[i] = rec[MF_CELL_OFF_HI + i];
+    return coords_fast(Hi, xs0, yy, u, v);
+}
+#endif
+
 // Per-pixel mask test of a MIXED cell for the lane's four pixels; returns the 4-bit pass mask.
 // Division-free decision: with Xn = M0 x + M1 y + M2 and Wd = M6 x + M7 y + M8 > 0, OpenCV's
 // fX = fl(Xn * fl(32/Wd)) differs from 32 Xn / Wd by < 1e-9 relative, and rint(fX) > lo <=> fX > lo + 1/2
@@ -292,21 +345,21 @@ __device__ __forceinline__ void fixed_point(const float (&u)[4], const float (&v
 // placed here.
 struct TapRegs { uint32_t lo[6], hi[6]; };      // {B, G, R} of row iy, then of row iy + 1: X0 in lo (byte 0), X1 in hi (byte 2)
 
+template <int PITCH>
 __device__ __forceinline__ void taps_issue(uint32_t bxj, uint32_t byj, uint32_t lds_origin, TapRegs& t)
 {
-    static_assert(LDS_PITCH == 160, "the immediate offsets below are LDS_PITCH + 0..5");
     // ix = bits[5..21] of the raw float; bits[22..28] (the 1.5*2^23 pattern, constant) ride along in the 24-bit multiplier
     // operand and are taken out again through the origin
-    const uint32_t at = umad24(byj >> 5, (uint32_t)LDS_PITCH, umad24(bxj >> 5, 3u, 0u - lds_origin - MAGIC_HI * (3u + (uint32_t)LDS_PITCH)));
+    const uint32_t at = umad24(byj >> 5, (uint32_t)PITCH, umad24(bxj >> 5, 3u, 0u - lds_origin - MAGIC_HI * (3u + (uint32_t)PITCH)));
     asm volatile("ds_read_u8 %0, %12 offset:0\n\tds_read_u8_d16_hi %1, %12 offset:3\n\t"
                  "ds_read_u8 %2, %12 offset:1\n\tds_read_u8_d16_hi %3, %12 offset:4\n\t"
                  "ds_read_u8 %4, %12 offset:2\n\tds_read_u8_d16_hi %5, %12 offset:5\n\t"
-                 "ds_read_u8 %6, %12 offset:160\n\tds_read_u8_d16_hi %7, %12 offset:163\n\t"
-                 "ds_read_u8 %8, %12 offset:161\n\tds_read_u8_d16_hi %9, %12 offset:164\n\t"
-                 "ds_read_u8 %10, %12 offset:162\n\tds_read_u8_d16_hi %11, %12 offset:165"
+                 "ds_read_u8 %6, %12 offset:%13\n\tds_read_u8_d16_hi %7, %12 offset:%16\n\t"
+                 "ds_read_u8 %8, %12 offset:%14\n\tds_read_u8_d16_hi %9, %12 offset:%17\n\t"
+                 "ds_read_u8 %10, %12 offset:%15\n\tds_read_u8_d16_hi %11, %12 offset:%18"
                  : "=&v"(t.lo[0]), "=&v"(t.hi[0]), "=&v"(t.lo[1]), "=&v"(t.hi[1]), "=&v"(t.lo[2]), "=&v"(t.hi[2]),
                    "=&v"(t.lo[3]), "=&v"(t.hi[3]), "=&v"(t.lo[4]), "=&v"(t.hi[4]), "=&v"(t.lo[5]), "=&v"(t.hi[5])
-                 : "v"(at));
+                 : "v"(at), "n"(PITCH), "n"(PITCH + 1), "n"(PITCH + 2), "n"(PITCH + 3), "n"(PITCH + 4), "n"(PITCH + 5));
 }
 
 // Waits for every LDS load in flight and hands the registers of two pixels to the compiler as ready (it does not see the loads).
@@ -336,14 +389,15 @@ __device__ __forceinline__ void blend_pixel(uint32_t bxj, uint32_t byj, const Ta
 }
 
 // (two pixels' loads in flight at a time: 24 registers; a software pipeline with counted lgkmcnt waits measured the same)
+template <int PITCH = LDS_PITCH>
 __device__ __forceinline__ uint3 gather_blend_staged(const uint32_t (&bx)[4], const uint32_t (&by)[4], uint32_t lds_origin)
 {
     uint32_t oB[4], oG[4], oR[4];
 #pragma unroll
     for (int j = 0; j < 4; j += 2) {
         TapRegs t0, t1;
-        taps_issue(bx[j], by[j], lds_origin, t0);
-        taps_issue(bx[j + 1], by[j + 1], lds_origin, t1);
+        taps_issue<PITCH>(bx[j], by[j], lds_origin, t0);
+        taps_issue<PITCH>(bx[j + 1], by[j + 1], lds_origin, t1);
         taps_wait(t0, t1);
         blend_pixel(bx[j], by[j], t0, oB[j], oG[j], oR[j]);
         blend_pixel(bx[j + 1], by[j + 1], t1, oB[j + 1], oG[j + 1], oR[j + 1]);
@@ -431,7 +485,14 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
     // (Everything up to the plan is scalar, with host-made constants and 32-bit offsets: the scalar unit is as loaded as the vector
     // unit in this kernel -- profiles/README.md -- and every s_ instruction here is paid by each of the 2.4 M wavefronts of a clip.)
     const uint32_t f = blockIdx.y;
+#ifndef MF_NO_ROT
+    // The eighth an XCD sweeps ROTATES with the frame: the footprints along the top and bottom frame border are the expensive ones
+    // (per-tap path, crop flags: 2.5 x the average), and with a fixed assignment they all land on XCD 0 and XCD 7, which then
+    // finish 9 % after the others (-2.1 % kernel time at config 2, -4 % on the all-hot probe).
+    const uint32_t t = ((blockIdx.x + f) & 7u) * g.per_xcd + (blockIdx.x >> 3);
+#else
     const uint32_t t = (blockIdx.x & 7u) * g.per_xcd + (blockIdx.x >> 3);
+#endif
     if (t >= g.per_frame) return;
     const uint32_t ty = (__umulhi(t, g.div_m) + (t & g.div_pass)) >> g.div_s, tx = t - ty * g.nfx;
     const int xa = (int)(tx * (uint32_t)FOOT_W), ya = (int)(ty * (uint32_t)FOOT_H);
@@ -447,20 +508,32 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
     const uint8_t* __restrict__ src = frames + (uint64_t)f * g.frame_bytes;
     const bool staged = STAGE_OK && (rg & MF_REGION_STAGED) != 0;
     if (staged) {
-        // Source region -> LDS, asynchronously (global_load_lds: no VGPRs, no ds_write): lane i fetches the i-th and (64+i)-th
-        // 16-byte chunk of the window (10 chunks = 160 bytes per row), which land at LDS offsets 16 i and 1024 + 16 i.
-        // chunk i sits at row i / 10, byte 16 (i % 10) of the window = byte (i / 10) (row_bytes - 160) + 16 i from gbase;
+        // Source region -> LDS, asynchronously (global_load_lds: no VGPRs, no ds_write).  Two layouts, chosen by the plan:
+        //   COMPACT (hot footprints whose taps fit 9 rows x 112 bytes: ~3/4 of them): ONE load, lane i fetches the i-th 16-byte
+        //           chunk (7 chunks per row), which lands at LDS offset 16 i.  (Lane 63 fetches the first chunk of a tenth row: unused,
+        //           inside the frame because the region is DEEP.)
+        //   wide    (12 rows x 160 bytes): lane i fetches the i-th and (64+i)-th chunk (10 chunks per row) -> LDS 16 i, 1024 + 16 i.
+        // chunk i sits at row i / P, byte 16 (i % P) of the window = byte (i / P) (row_bytes - 16 P) + 16 i from gbase;
         // uniform base + opaque 32-bit lane offset keeps the address arithmetic 32-bit (saddr + voffset form)
         const uint8_t* __restrict__ gbase = src + ((uint64_t)src_dwords << 2);
+        // (one generic -> LDS conversion: each comes with a null check)
+        __attribute__((address_space(3))) uint8_t* const window = (__attribute__((address_space(3))) uint8_t*)&s_src[0];
+#ifndef MF_NO_COMPACT
+        if (rg & MF_REGION_COMPACT) {
+            uint32_t o0 = __umul24(((uint32_t)lane * 37u) >> 8, g.row_bytes - (uint32_t)MF_COMPACT_PITCH) + ((uint32_t)lane << 4);
+            asm("" : "+v"(o0));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o0), (__attribute__((address_space(3))) void*)window, 16, 0, 0);
+        } else
+#endif
+        {
         uint32_t o0 = __umul24(((uint32_t)lane * 205u) >> 11, g.row_bytes - (uint32_t)MF_STAGE_PITCH) + ((uint32_t)lane << 4);
         uint32_t o1 = __umul24((((uint32_t)lane + 64u) * 205u) >> 11, g.row_bytes - (uint32_t)MF_STAGE_PITCH) +
                       (((uint32_t)lane << 4) + 1024u);
         asm("" : "+v"(o0));
         asm("" : "+v"(o1));
-        // (one generic -> LDS conversion: each comes with a null check)
-        __attribute__((address_space(3))) uint8_t* const window = (__attribute__((address_space(3))) uint8_t*)&s_src[0];
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o0), (__attribute__((address_space(3))) void*)window, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o1), (__attribute__((address_space(3))) void*)(window + 1024), 16, 0, 0);
+        }
     }
     // taps are addressed by absolute LDS byte address (= LDS_PITCH iy + 3 ix - lds_origin): the window base is folded in
     const uint32_t lds_origin = (rg & MF_REGION_ORIGIN_MASK) - (uint32_t)(uintptr_t)&s_src[0];
@@ -474,12 +547,19 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
         // denominator allows the trimmed reciprocal (UNIT), the footprint lies inside the frame, its window is staged and every
         // tap is at least two pixels inside the frame (DEEP: no crop flag either).  Straight-line code, all lanes active.
         float u[4], v[4];
+#ifndef MF_NO_FAST64
+        if (!((pv.x >> 16) & MF_PLAN_FAST64) || !cell_coords_fast(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy, u, v))
+#endif
         cell_coords<false>(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy, x0, 0xFu, u, v, true);
         uint32_t bx[4], by[4];
         fixed_point(u, v, bx, by);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the window has landed in LDS
         uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
+#ifndef MF_NO_COMPACT
+        const uint3 d = (rg & MF_REGION_COMPACT) ? gather_blend_staged<MF_COMPACT_PITCH>(bx, by, lds_origin) : gather_blend_staged(bx, by, lds_origin);
+#else
         const uint3 d = gather_blend_staged(bx, by, lds_origin);
+#endif
         *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;     // (STAGED implies W % 4 == 0)
         return;
     }
@@ -982,6 +1062,63 @@ int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigne
 {
     hipLaunchKernelGGL(selftest_recip_kernel, dim3(2048), dim3(256), 0, st, n, seed, d_mismatches);
     return hip_fail(hipGetLastError(), "selftest_recip_kernel launch");
+}
+
+// Self-test of the cheap coordinate chain (coords_fast) against cv2.perspectiveTransform's own arithmetic on hashed matrices
+// and positions that satisfy the plan's MF_PLAN_FAST64 / UNIT / DEEP premises: `missed` counts float32 results that differ from
+// the exact chain's WITHOUT their midpoint key raising the flag (must be 0), `flagged` the values whose key did (the fallback rate).
+__global__ void selftest_fast64_kernel(unsigned long long n, unsigned long long seed, unsigned long long* counters)
+{
+    unsigned long long missed = 0, flagged = 0, tested = 0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long z = (i + seed) * 0x9E3779B97F4A7C15ull;
+        double r[11];
+        for (int q = 0; q < 11; ++q) {                          // eleven uniform draws in (-1, 1)
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            r[q] = (double)(long long)(z >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+            z += 0x9E3779B97F4A7C15ull;
+        }
+        // near-identity inverse homography with shift, shear and perspective terms up to what the certificates admit
+        const double amp = (i & 3) == 0 ? 1.0 : 0.1;             // a quarter of the cases at the limits
+        double Hi[9] = { 1.0 + 0.2 * amp * r[0], 0.2 * amp * r[1], 80.0 * r[2], 0.2 * amp * r[3], 1.0 + 0.2 * amp * r[4], 80.0 * r[5],
+                         2.0e-4 * amp * r[6], 2.0e-4 * amp * r[7], 1.0 };
+        const double xs0 = (double)(4 * (int)((r[8] * 0.5 + 0.5) * 2047.0)), yy = (double)(int)((r[9] * 0.5 + 0.5) * 8191.0);
+        // the premises, in float64 on the lane's four pixels (the plan checks them on the footprint's corners)
+        bool ok = true;
+        for (int j = 0; j < 4 && ok; ++j) {
+            const double x = xs0 + j;
+            const double w = (x * Hi[6] + yy * Hi[7]) + Hi[8];
+            const double nx = (x * Hi[0] + yy * Hi[1]) + Hi[2], ny = (x * Hi[3] + yy * Hi[4]) + Hi[5];
+            ok = w > 0.52 && w < 1.9 && fabs(Hi[6]) <= 0.9 * RECIP_GUESS_LIMIT * (w * w) &&
+                 fabs(Hi[0]) * x + fabs(Hi[1]) * yy + fabs(Hi[2]) <= 8.0 * nx && fabs(Hi[3]) * x + fabs(Hi[4]) * yy + fabs(Hi[5]) <= 8.0 * ny &&
+                 fabs(Hi[6]) * x + fabs(Hi[7]) * yy + fabs(Hi[8]) <= 2.5 && nx / w >= 1.0 && ny / w >= 1.0 && nx / w < 32768.0 && ny / w < 32768.0;
+        }
+        if (!ok) continue;
+        float u[4], v[4];
+        uint32_t keys[8];
+        (void)coords_fast(Hi, xs0, yy, u, v, keys);
+        for (int j = 0; j < 4; ++j) {
+            const double x = xs0 + j;
+            const double w = (x * Hi[6] + yy * Hi[7]) + Hi[8];
+            const double iw = 1.0 / w;
+            const float ue = (float)(((x * Hi[0] + yy * Hi[1]) + Hi[2]) * iw), ve = (float)(((x * Hi[3] + yy * Hi[4]) + Hi[5]) * iw);
+            tested += 2;
+            if (keys[2 * j] == 0u) ++flagged; else if (__float_as_uint(ue) != __float_as_uint(u[j])) ++missed;
+            if (keys[2 * j + 1] == 0u) ++flagged; else if (__float_as_uint(ve) != __float_as_uint(v[j])) ++missed;
+        }
+    }
+    if (missed) atomicAdd(&counters[0], missed);
+    if (flagged) atomicAdd(&counters[1], flagged);
+    if (tested) atomicAdd(&counters[2], tested);
+}
+
+int launch_selftest_fast64(unsigned long long n, unsigned long long seed, unsigned long long* d_counters, hipStream_t st)
+{
+    hipLaunchKernelGGL(selftest_fast64_kernel, dim3(2048), dim3(256), 0, st, n, seed, d_counters);
+    return hip_fail(hipGetLastError(), "selftest_fast64_kernel launch");
 }
 
 // The byte taps (gather_blend_staged here, the staged rows in resize.hip) rely on ds_read_u8_d16_hi ZEROING the low half of its

@@ -347,6 +347,19 @@ def test_trimmed_reciprocal_matches_ieee_division(dev):
     assert bad.value == 0
 
 
+def test_fast_coordinate_chain_never_differs_unflagged(dev):
+    """The hot path's cheap float64 chain (fused affine forms, reciprocal to an ulp) must give the float32 coordinates of
+    cv2.perspectiveTransform's own arithmetic whenever its midpoint guard stays silent: 2^31 hashed (matrix, position) cases that
+    satisfy the plan's premises, a quarter of them at the certified limits."""
+    from meshflow_amd import _lib
+    c = (ctypes.c_uint64 * 3)(1, 1, 1)
+    _lib.check(_lib.lib.mf_selftest_fast64(1 << 31, 777, c))
+    missed, flagged, tested = c[0], c[1], c[2]
+    assert tested > (1 << 31)                  # most draws satisfy the premises (8 values per case)
+    assert missed == 0
+    assert flagged / tested < 2e-5             # guard window 512 of 2^29 low-mantissa patterns: ~1e-6 per value
+
+
 def test_degenerate_mesh_is_reported(dev):
     from meshflow_amd import synthetic
     H, W, R, C = 64, 96, 4, 4
