@@ -168,12 +168,12 @@ def cfg1_status():
     return 'skipped: decoder present but the CPU reference leg is not part of this bench (run the reference directly)'
 
 
-def host_clip(stab, frames, disp, hom, runs):
+def host_clip(stab, frames, disp, hom, runs, **kw):
     """stabilize_clip() from host frames to host frames, `runs` times: list of seconds."""
     times = []
     for _ in range(runs):
         t0 = time.perf_counter()
-        out = stab.stabilize_clip(frames, disp, hom)
+        out = stab.stabilize_clip(frames, disp, hom, **kw)
         times.append(time.perf_counter() - t0)
         del out
     return times
@@ -182,26 +182,62 @@ def host_clip(stab, frames, disp, hom, runs):
 def end_to_end(stab, d_frames, disp, hom, F, runs=5):
     """BASELINE.json's other figure: frames/s of stabilize_clip() from a Python list of NumPy frames in host memory to a list
     of stabilized frames + crop bounds + paths + stability score back in host memory (PCIe both ways, pageable buffers, as
-    the reference passes them).  Never `value` outside --mode e2e.  One untimed run first, then mean and min of `runs`."""
+    the reference passes them).  Never `value` outside --mode e2e.  One untimed run first, then mean and min of `runs`.
+    Two variants: the path up to mfs.py:158 (stabilized frames back), and -- `with_crop` -- what stabilize() hands its encoder:
+    mfs.py:150-162 including _crop_frames (mfs.py:159), only the cropped + resized frames travelling back."""
     frames = [f.copy() for f in d_frames.cpu().numpy()]           # separate allocations, like a decoder's output
-    host_clip(stab, frames, disp, hom, 1)
-    t = host_clip(stab, frames, disp, hom, runs)
-    mean, best = float(np.mean(t)), float(np.min(t))
-    return {'value': F / mean, 'unit': 'frames/s', 'ms_per_clip': mean * 1e3, 'min_ms_per_clip': best * 1e3,
-            'best_value': F / best, 'runs': runs,
-            'what': 'stabilize_clip(list of F host frames) -> list of F host frames + crop bounds + paths + score; '
-                    f'chunked, overlapped PCIe staging (meshflow_amd/pipeline.py); mean of {runs} runs after one untimed run, min beside it'}
+    res = {}
+    for key, kw in (('', {}), ('with_crop', {'crop': True, 'keep_uncropped': False})):
+        host_clip(stab, frames, disp, hom, 1, **kw)
+        t = host_clip(stab, frames, disp, hom, runs, **kw)
+        mean, best = float(np.mean(t)), float(np.min(t))
+        r = {'value': F / mean, 'unit': 'frames/s', 'ms_per_clip': mean * 1e3, 'min_ms_per_clip': best * 1e3, 'best_value': F / best, 'runs': runs}
+        if key:
+            r['what'] = ('stabilize_clip(crop=True, keep_uncropped=False): the same + clip-level crop rectangle + _crop_frames (mfs.py:159) on the '
+                         'device in the same pipeline (mf_warp_crop_u8c3_host_frames); only the cropped + resized frames come back')
+            res[key] = r
+        else:
+            r['what'] = ('stabilize_clip(list of F host frames) -> list of F stabilized host frames + crop bounds + paths + score; chunked, '
+                         f'overlapped PCIe staging below Python (csrc/hostpipe.hip, mf_warp_u8c3_host_frames); mean of {runs} runs after one '
+                         'untimed run, min beside it')
+            res.update(r)
+    return res
+
+
+def frame_checksums(frames):
+    """One position-weighted 63-bit sum per frame of a (n, H, W, 3) uint8 device tensor (tests compare runs with it)."""
+    import torch
+    n = frames.shape[0]
+    words = frames.reshape(n, -1)
+    weights = (torch.arange(words.shape[1], device=frames.device, dtype=torch.int64) % 65521) + 1
+    return [int(((words[i].to(torch.int64) * weights).sum() & 0x7FFFFFFFFFFFFFFF).item()) for i in range(n)]
+
+
+def visible_gpus():
+    """GPUs of this node WITHOUT touching torch.cuda or HIP (the launcher parent must not initialise the GPU before it starts its
+    children): the KFD topology lists one node per agent, GPUs are the ones with SIMDs.  None when /sys cannot tell."""
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        count = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, 'properties')) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            if int(props.get('simd_count', '0')) > 0:
+                count += 1
+        return count
+    except (OSError, ValueError):
+        return None if os.path.exists('/dev/kfd') else 0          # no kernel driver at all: no GPU
 
 
 def launch_children(args):
     """`python bench.py --gpus N` by itself: N fresh child processes, one per GPU, with torchrun's environment.  Nothing in
-    this parent touches a GPU (counting devices does not initialise HIP on this image); children are separate processes
-    started with subprocess -- never an exec of a process that has initialised the GPU.  Exit code: the first non-zero
-    child code."""
-    import torch
+    this parent touches a GPU, torch.cuda or HIP (the device count comes from /sys, else --gpus is trusted); children are separate
+    processes started with subprocess -- never an exec of a process that has initialised the GPU.  Exit code: the first non-zero
+    child code; when a rank dies the others are terminated by exact PID, and killed if they ignore that for 10 s (a rank stuck in a
+    collective may)."""
     backend = os.environ.get('MESHFLOW_DIST_BACKEND', 'nccl')
-    visible = torch.cuda.device_count()
-    if visible < 1 or (backend == 'nccl' and visible < args.gpus):
+    visible = visible_gpus()
+    if visible is not None and (visible < 1 or (backend == 'nccl' and visible < args.gpus)):
         print(f'bench.py: --gpus {args.gpus} but {visible} GPU(s) visible (one rank per GPU under RCCL; '
               f'MESHFLOW_DIST_BACKEND=gloo lets ranks share a GPU for functional tests)', file=sys.stderr)
         return 2
@@ -217,6 +253,7 @@ def launch_children(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     pending = list(procs)
+    deadline = None                              # set when the survivors have been asked to stop
     while pending:
         for p in list(pending):
             code = p.poll()
@@ -227,6 +264,11 @@ def launch_children(args):
                 rc = code if code > 0 else 1
                 for q in pending:              # a dead rank strands the others in their collectives: end them (exact PIDs)
                     q.terminate()
+                deadline = time.monotonic() + 10.0
+        if deadline is not None and pending and time.monotonic() > deadline:
+            for q in pending:
+                q.kill()
+            deadline = time.monotonic() + 1e9
         time.sleep(0.05)
     return rc
 
@@ -250,6 +292,8 @@ def main():
                          '"clips" = N independent clips, one per GPU, no collective (BASELINE config 5); '
                          '"e2e" = host frames in -> host frames out, PCIe both ways (N independent clips when N > 1)')
     ap.add_argument('--no-e2e', action='store_true', help='skip the host-buffers-in / host-buffers-out side measurement (N = 1 only)')
+    ap.add_argument('--checksum', action='store_true', help='add `frames_checksum` to the line: one position-weighted 63-bit sum per stabilized '
+                    'frame of the last step (the gathered clip on rank 0 when the gather ran, else this rank\'s shard) -- for the tests')
     ap.add_argument('--as-rank-of', type=int, default=0, metavar='N',
                     help='single process only: do the work rank 0 of an N-GPU "shard" run does (clip of N x frames, own '
                          'frame range, replicated Jacobi) without the collective -- predicts weak scaling on one GPU')
@@ -336,13 +380,24 @@ def main():
 
     # The three stages handed to dist.stabilize_sharded; HIP events bracket the Jacobi stage and the warp kernel on the
     # launch stream (torch's current stream IS the stream ops.* launch on).
+    # The Jacobi sweep of a step (578 one-wave workgroups at config 2: a fraction of the chip) is issued on a SIDE stream and joined
+    # by an event: issued back to back, step i+1's sweep then runs under step i's warp kernel instead of after it.  Everything else
+    # of a step stays on the main stream in order.
+    side = torch.cuda.Stream(device=device)
+    main_stream = torch.cuda.current_stream(device)
+
     def jacobi_fn():
         i = now['i']
-        if i is not None:
-            jev[i][0].record()
-        d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
-        if i is not None:
-            jev[i][1].record()
+        with torch.cuda.stream(side):
+            if i is not None:
+                jev[i][0].record(side)
+            d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
+            if i is not None:
+                jev[i][1].record(side)
+            done = torch.cuda.Event()
+            done.record(side)
+        main_stream.wait_event(done)
+        d_stab.record_stream(main_stream)      # allocated on the side stream, read on the main one
         return d_stab
 
     def warp_fn(lo_, hi_, d_stab):
@@ -443,7 +498,9 @@ def main():
     # one GPU -- an order of magnitude above a step -- and a consumer in host memory is better served by every rank
     # draining its own shard over its own PCIe link).  Both figures are reported side by side;
     # --no-gather skips them.
-    gather_ms = gather_error = d2h_ms = None
+    gather_ms = gather_error = d2h_ms = checksum = None
+    if args.checksum and not (world > 1 and not clips_mode and not args.no_gather):
+        checksum = frame_checksums(d_out)
     if world > 1 and not clips_mode and not args.no_gather:
         try:
             barrier()
@@ -451,6 +508,8 @@ def main():
             gathered = mfdist.gather_frames(d_out, F)
             barrier()
             gather_ms = max_over_ranks(time.perf_counter() - t1) * 1e3
+            if args.checksum and rank == 0:
+                checksum = frame_checksums(gathered)
             del gathered
             pinned = torch.empty(d_out.shape, dtype=torch.uint8, pin_memory=True)
             pinned.copy_(d_out)                      # touch the pages once
@@ -473,7 +532,8 @@ def main():
         except (OSError, ValueError):
             pass
         result = {
-            'metric': 'frames/sec stabilize() hot path (Jacobi + mesh warp + crop scan), inputs resident in HBM',
+            'metric': 'frames/sec stabilize() hot path (Jacobi + mesh warp + crop scan), inputs resident in HBM -- the kernel-path figure of '
+                      'BASELINE.json\'s metric; its host-to-host figure (PCIe both ways) is `end_to_end`, the warp kernel\'s %HBM-roofline is `roofline`',
             'value': (F * world if clips_mode else F) * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
@@ -515,6 +575,9 @@ def main():
                                      'pinned host memory over its own PCIe link (what a host-memory consumer would use instead)')
         if gather_error is not None:
             result['gather_error'] = gather_error
+        if checksum is not None:
+            result['frames_checksum'] = checksum
+            result['frames_checksum_range'] = [0, F] if gather_ms is not None else [lo, hi]
         if world == 1 and not args.no_e2e and args.as_rank_of <= 1:
             try:
                 result['end_to_end'] = end_to_end(stab, d_frames, disp, hom, F)

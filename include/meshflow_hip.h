@@ -62,7 +62,7 @@ const char* mf_last_error(void);
 
 /* ---- device plumbing (for hosts that do not bring their own allocator) ---- */
 int mf_device_count(int* count);
-int mf_set_device(int device);
+int mf_set_device(int device);                            /* + the one-time device check of the byte-tap kernels */
 int mf_malloc(void** d_ptr, size_t bytes);
 int mf_free(void* d_ptr);
 int mf_malloc_host(void** h_ptr, size_t bytes);          /* pinned host memory */
@@ -162,13 +162,26 @@ int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab,
                       int32_t* crop /* [n][4] */, float* kernel_ms);
 /* The same for frames that are separate allocations (the reference's Python lists of per-frame arrays, mfs.py:997, 1100):
  * frames[i] / out[i] point to frame i, H*W*3 bytes each.  mf_warp_u8c3_host is this with frames[i] = frames + i*H*W*3.
- * Both move the clip in chunks of 16 frames on three upload and three download threads with their own HIP streams; a
- * chunk is warped as soon as it has landed and travels back while later chunks are still going up (pageable memory is
- * fine; memory from mf_malloc_host makes the copies truly asynchronous).  Device buffers and streams are kept between
- * calls (grow-only, one cache per process, calls are serialised); mf_host_cache_release() frees them. */
+ * Both move the clip in chunks of 16 frames on four upload and four download threads with their own HIP streams (plus
+ * eight threads that fault the output pages in ahead of the downloads); a chunk is warped as soon as it has landed and
+ * travels back while later chunks are still going up (pageable memory is fine; memory from mf_malloc_host makes the
+ * copies truly asynchronous).  MF_PIPE_CHUNK / MF_PIPE_UP / MF_PIPE_DOWN / MF_PIPE_POPULATE in the environment retune it
+ * (read at every call).  Input and output frames must NOT overlap in memory (MF_ERR_INVALID_ARG): output pages are touched
+ * while the input is still being read.  Device buffers and streams are kept between calls, grow-only, ONE CACHE PER DEVICE
+ * (the calling thread's current device, mf_set_device): calls on one device are serialised, calls on different devices
+ * from different host threads run concurrently; mf_host_cache_release() frees all of them. */
 int mf_warp_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* out, const double* unstab, const double* stab,
                              int n, int W, int H, int R, int C, const uint8_t border_bgr[3],
                              int32_t* crop /* [n][4] */, float* kernel_ms);
+/* ... followed by the next step of stabilize(), _crop_frames (mfs.py:159, 1111-1157), in the same pipeline: once every chunk
+ * is warped the clip-level rectangle {max left, max top, min right, min bottom} (mfs.py:1103-1106) is reduced on the device,
+ * written to bounds[4], and every chunk is cropped to it and resized back to W x H (mf_crop_resize_u8c3) on its way out:
+ * cropped[i] receives frame i of what stabilize() hands to the encoder.  `out` (the uncropped stabilized frames) may be NULL:
+ * they then never cross PCIe.  An empty rectangle is MF_ERR_INVALID_ARG (cv2.resize fails on an empty source); bounds[] is
+ * written in either case. */
+int mf_warp_crop_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* out /* may be NULL */, uint8_t* const* cropped,
+                                  const double* unstab, const double* stab, int n, int W, int H, int R, int C,
+                                  const uint8_t border_bgr[3], int32_t* crop /* [n][4] */, int32_t bounds[4], float* kernel_ms);
 int mf_host_cache_release(void);
 
 /* ---- multi-GPU exchange steps, on RCCL directly: ONE process drives the GPUs 0..ndev-1 of a node ----

@@ -43,7 +43,11 @@ int mf_device_count(int* count)
     return MF_OK;
 }
 
-int mf_set_device(int device) { MF_HIP_TRY(hipSetDevice(device)); return MF_OK; }
+int mf_set_device(int device)
+{
+    MF_HIP_TRY(hipSetDevice(device));
+    return check_d16_zero_fill(nullptr);       // the one-time, synchronising device check of the byte-tap kernels: here, not in a launch
+}
 
 int mf_malloc(void** d_ptr, size_t bytes)
 {

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <mutex>
 #include <vector>
 
 #include "mf_common.h"
@@ -39,6 +40,26 @@ struct Comm {
 
 Rccl g_rccl;
 Comm g_comm;
+std::mutex g_comm_lock;          // the communicator is process-wide state: every entry point below holds this
+
+// Frees what a Comm holds (streams, communicators), on the right devices; keeps the caller's current device.
+int destroy_comm(Comm& c)
+{
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = MF_OK;
+    for (int g = 0; g < c.ndev; ++g) {
+        (void)hipSetDevice(g);
+        if (g < (int)c.streams.size() && c.streams[g]) (void)hipStreamDestroy(c.streams[g]);
+        if (g < (int)c.comms.size() && c.comms[g] && g_rccl.CommDestroy) {
+            const ncclResult_t r = g_rccl.CommDestroy(c.comms[g]);
+            if (r != ncclSuccess && rc == MF_OK) rc = -1000 - (int)r;
+        }
+    }
+    (void)hipSetDevice(prev);
+    c = Comm();
+    return rc;
+}
 
 int nccl_fail(ncclResult_t r, const char* what)
 {
@@ -96,6 +117,7 @@ extern "C" {
 
 int mf_comm_init_all(int ndev)
 {
+    std::lock_guard<std::mutex> guard(g_comm_lock);
     if (g_comm.ndev != 0) { set_error("mf_comm_init_all: a communicator already exists (mf_comm_destroy first)"); return MF_ERR_INVALID_ARG; }
     int count = 0;
     MF_HIP_TRY(hipGetDeviceCount(&count));
@@ -111,11 +133,16 @@ int mf_comm_init_all(int ndev)
     std::vector<int> devs(ndev);
     for (int g = 0; g < ndev; ++g) devs[g] = g;
     MF_NCCL_TRY(g_rccl.CommInitAll(c.comms.data(), ndev, devs.data()));
-    for (int g = 0; g < ndev; ++g) {
-        MF_HIP_TRY(hipSetDevice(g));
-        MF_HIP_TRY(hipStreamCreateWithFlags(&c.streams[g], hipStreamNonBlocking));
+    hipError_t e = hipSuccess;
+    for (int g = 0; g < ndev && e == hipSuccess; ++g) {
+        e = hipSetDevice(g);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c.streams[g], hipStreamNonBlocking);
     }
-    MF_HIP_TRY(hipSetDevice(prev));
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) {                         // part-way failure: give the communicators and streams back
+        (void)destroy_comm(c);
+        return hip_fail(e, "mf_comm_init_all: stream creation");
+    }
     g_comm = c;
     return MF_OK;
 }
@@ -123,56 +150,66 @@ int mf_comm_init_all(int ndev)
 int mf_comm_size(int* ndev)
 {
     if (!ndev) { set_error("mf_comm_size: null"); return MF_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> guard(g_comm_lock);
     *ndev = g_comm.ndev;
     return MF_OK;
 }
 
 int mf_comm_destroy(void)
 {
+    std::lock_guard<std::mutex> guard(g_comm_lock);
     if (g_comm.ndev == 0) return MF_OK;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
-    int rc = MF_OK;
-    for (int g = 0; g < g_comm.ndev; ++g) {
-        (void)hipSetDevice(g);
-        if (g_comm.streams[g]) (void)hipStreamDestroy(g_comm.streams[g]);
-        if (g_comm.comms[g]) { int r = nccl_fail(g_rccl.CommDestroy(g_comm.comms[g]), "ncclCommDestroy"); if (rc == MF_OK) rc = r; }
-    }
-    (void)hipSetDevice(prev);
-    g_comm = Comm();
+    const int rc = destroy_comm(g_comm);
+    if (rc != MF_OK) set_error("mf_comm_destroy: ncclCommDestroy failed (%d)", -1000 - rc);
     return rc;
 }
 
+// An RCCL call that fails between ncclGroupStart and ncclGroupEnd must not leave the group open (every later RCCL call of the
+// process would join it): close it, then report the first error.
+#define MF_NCCL_IN_GROUP(expr)                             \
+    do {                                                   \
+        if (rc == MF_OK) rc = nccl_fail((expr), #expr);    \
+    } while (0)
+
 int mf_allreduce_crop(int32_t* const* d_bounds)
 {
+    std::lock_guard<std::mutex> guard(g_comm_lock);
     if (g_comm.ndev == 0) { set_error("mf_allreduce_crop: no communicator (mf_comm_init_all first)"); return MF_ERR_INVALID_ARG; }
     if (!d_bounds) { set_error("mf_allreduce_crop: null"); return MF_ERR_INVALID_ARG; }
     for (int g = 0; g < g_comm.ndev; ++g)
         if (!d_bounds[g]) { set_error("mf_allreduce_crop: null pointer for device %d", g); return MF_ERR_INVALID_ARG; }
     // {left, top} take the maximum, {right, bottom} the minimum (mfs.py:1103-1106): two 8-byte reductions in ONE group
     MF_NCCL_TRY(g_rccl.GroupStart());
+    int rc = MF_OK;
     for (int g = 0; g < g_comm.ndev; ++g) {
-        MF_NCCL_TRY(g_rccl.AllReduce(d_bounds[g], d_bounds[g], 2, ncclInt32, ncclMax, g_comm.comms[g], g_comm.streams[g]));
-        MF_NCCL_TRY(g_rccl.AllReduce(d_bounds[g] + 2, d_bounds[g] + 2, 2, ncclInt32, ncclMin, g_comm.comms[g], g_comm.streams[g]));
+        MF_NCCL_IN_GROUP(g_rccl.AllReduce(d_bounds[g], d_bounds[g], 2, ncclInt32, ncclMax, g_comm.comms[g], g_comm.streams[g]));
+        MF_NCCL_IN_GROUP(g_rccl.AllReduce(d_bounds[g] + 2, d_bounds[g] + 2, 2, ncclInt32, ncclMin, g_comm.comms[g], g_comm.streams[g]));
     }
-    MF_NCCL_TRY(g_rccl.GroupEnd());
+    const ncclResult_t end = g_rccl.GroupEnd();            // always: closes the group even after a failed call
+    if (rc != MF_OK) return rc;
+    MF_NCCL_TRY(end);
     return sync_all();
 }
 
 int mf_gather_frames(const uint8_t* const* d_shards, const size_t* shard_bytes, uint8_t* d_dst, int root)
 {
+    std::lock_guard<std::mutex> guard(g_comm_lock);
     if (g_comm.ndev == 0) { set_error("mf_gather_frames: no communicator (mf_comm_init_all first)"); return MF_ERR_INVALID_ARG; }
     if (!d_shards || !shard_bytes || !d_dst || root < 0 || root >= g_comm.ndev) { set_error("mf_gather_frames: bad arguments"); return MF_ERR_INVALID_ARG; }
+    for (int g = 0; g < g_comm.ndev; ++g)                  // argument errors before the group opens
+        if (shard_bytes[g] != 0 && !d_shards[g]) { set_error("mf_gather_frames: null shard for device %d", g); return MF_ERR_INVALID_ARG; }
     MF_NCCL_TRY(g_rccl.GroupStart());
+    int rc = MF_OK;
     size_t offset = 0;
     for (int g = 0; g < g_comm.ndev; ++g) {
         if (shard_bytes[g] == 0) continue;
-        if (!d_shards[g]) { (void)g_rccl.GroupEnd(); set_error("mf_gather_frames: null shard for device %d", g); return MF_ERR_INVALID_ARG; }
-        MF_NCCL_TRY(g_rccl.Send(d_shards[g], shard_bytes[g], ncclUint8, root, g_comm.comms[g], g_comm.streams[g]));
-        MF_NCCL_TRY(g_rccl.Recv(d_dst + offset, shard_bytes[g], ncclUint8, g, g_comm.comms[root], g_comm.streams[root]));
+        MF_NCCL_IN_GROUP(g_rccl.Send(d_shards[g], shard_bytes[g], ncclUint8, root, g_comm.comms[g], g_comm.streams[g]));
+        MF_NCCL_IN_GROUP(g_rccl.Recv(d_dst + offset, shard_bytes[g], ncclUint8, g, g_comm.comms[root], g_comm.streams[root]));
         offset += shard_bytes[g];
     }
-    MF_NCCL_TRY(g_rccl.GroupEnd());
+    const ncclResult_t end = g_rccl.GroupEnd();
+    if (rc != MF_OK) return rc;
+    MF_NCCL_TRY(end);
     return sync_all();
 }
 

@@ -8,14 +8,22 @@
 // and records an event; DOWN host threads wait for it on their own streams and copy the stabilized chunk back, while
 // later chunks are still going up.  PCIe carries both directions at once and the kernels disappear behind the copies
 // (the same scheme as meshflow_amd/pipeline.py, below Python).  Device buffers, streams and the per-chunk cell table are
-// kept between calls (grow-only cache, one per process, serialised by a mutex; mf_host_cache_release frees it).
+// kept between calls (grow-only cache, ONE PER DEVICE, each serialised by its own mutex: a process that drives several GPUs
+// from several host threads -- mf_set_device(g) per thread -- runs their clips concurrently; mf_host_cache_release frees them).
+//
+// With `cropped` the call also runs the next step of stabilize(), _crop_frames (mfs.py:159, 1111-1157): once every chunk is
+// warped, the clip-level crop rectangle is reduced on the device (mfs.py:1103-1106), read back (16 bytes), and each chunk is
+// cropped + resized into the (no longer needed) input stack and travels back; `out` may then be NULL -- the reference only
+// uses the cropped frames afterwards -- and the uncropped frames never cross PCIe.
 #include <stdlib.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "mf_common.h"
@@ -51,14 +59,16 @@ struct Grow {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+constexpr int PIPE_MAX_DEVICES = 64;
 struct PipeCache {
     std::mutex lock;
     int device = -1;
-    Grow frames, out, table, unstab, stab, crop, status;
+    Grow frames, out, table, unstab, stab, crop, status, work, bounds;
     hipStream_t compute = nullptr, up[PIPE_MAX] = {}, down[PIPE_MAX] = {};
     void release()
     {
         frames.release(); out.release(); table.release(); unstab.release(); stab.release(); crop.release(); status.release();
+        work.release(); bounds.release();
         if (compute) (void)hipStreamDestroy(compute);
         for (auto& s : up) { if (s) (void)hipStreamDestroy(s); s = nullptr; }
         for (auto& s : down) { if (s) (void)hipStreamDestroy(s); s = nullptr; }
@@ -66,12 +76,12 @@ struct PipeCache {
         device = -1;
     }
 };
-PipeCache g_pipe;
+PipeCache g_pipe[PIPE_MAX_DEVICES];          // one cache per device: nothing is freed or re-allocated when the current device changes
 
 struct Shared {
     std::mutex m;
     std::condition_variable cv;
-    std::vector<char> up_ready, warp_ready, populated;
+    std::vector<char> up_ready, warp_ready, populated, resize_ready, populated2;
     hipError_t err = hipSuccess;
     const char* what = "";
     bool abort = false;
@@ -133,26 +143,50 @@ void populate_frames(uint8_t* const* host, int i0, int i1, size_t fb)
     }
 }
 
+// Every host frame as an address interval; true when an interval of `a` overlaps one of `b` (the populate threads write into
+// the output pages while the uploads are still reading the input: aliasing would corrupt the input silently).
+bool ranges_overlap(const uint8_t* const* a, const uint8_t* const* b, int n, size_t fb)
+{
+    std::vector<std::pair<uintptr_t, int>> v;
+    v.reserve(2 * (size_t)n);
+    for (int i = 0; i < n; ++i) { v.emplace_back((uintptr_t)a[i], 0); v.emplace_back((uintptr_t)b[i], 1); }
+    std::sort(v.begin(), v.end());
+    uintptr_t end[2] = { 0, 0 };                       // furthest end seen so far per side
+    for (const auto& it : v) {
+        if (it.first < end[1 - it.second]) return true;
+        const uintptr_t e = it.first + fb;
+        if (e > end[it.second]) end[it.second] = e;
+    }
+    return false;
+}
+
 }  // namespace
 
-int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, const double* unstab, const double* stab, int n, int W,
-                     int H, int R, int C, const uint8_t border_bgr[3], int32_t* crop, float* kernel_ms)
+int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t* const* cropped, const double* unstab, const double* stab,
+                     int n, int W, int H, int R, int C, const uint8_t border_bgr[3], int32_t* crop, int32_t* bounds, float* kernel_ms)
 {
-    std::lock_guard<std::mutex> cache_guard(g_pipe.lock);
-    PipeCache& pc = g_pipe;
     int dev = 0;
     MF_HIP_TRY(hipGetDevice(&dev));
-    if (pc.device != dev) {
-        if (pc.device >= 0) { int keep = dev; (void)hipSetDevice(pc.device); pc.release(); (void)hipSetDevice(keep); }
-        pc.device = dev;
-        MF_HIP_TRY(hipStreamCreateWithFlags(&pc.compute, hipStreamNonBlocking));
-        for (auto& s : pc.up) MF_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        for (auto& s : pc.down) MF_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    }
+    if (dev < 0 || dev >= PIPE_MAX_DEVICES) { set_error("mf_warp_u8c3_host: device %d out of range", dev); return MF_ERR_INVALID_ARG; }
+    PipeCache& pc = g_pipe[dev];
+    std::lock_guard<std::mutex> cache_guard(pc.lock);
     const size_t fb = (size_t)W * H * 3;
+    if ((out && ranges_overlap(frames, out, n, fb)) || (cropped && ranges_overlap(frames, cropped, n, fb)) ||
+        (out && cropped && ranges_overlap(out, cropped, n, fb))) {
+        set_error("mf_warp_u8c3_host: input and output frames overlap in memory (in-place operation is not supported)");
+        return MF_ERR_INVALID_ARG;
+    }
+    if (pc.device != dev) {                              // first use of this device: its streams
+        hipError_t se = hipStreamCreateWithFlags(&pc.compute, hipStreamNonBlocking);
+        for (auto& s : pc.up) if (se == hipSuccess) se = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        for (auto& s : pc.down) if (se == hipSuccess) se = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (se != hipSuccess) { pc.release(); return hip_fail(se, "hipStreamCreateWithFlags (host pipeline)"); }
+        pc.device = dev;
+    }
     const size_t vb1 = (size_t)(R + 1) * (C + 1) * 2 * sizeof(double);        // vertex displacements of one frame
-    static const int cfg_chunk = env_int("MF_PIPE_CHUNK", PIPE_CHUNK, 1, 4096), cfg_up = env_int("MF_PIPE_UP", PIPE_UP, 1, PIPE_MAX),
-                     cfg_down = env_int("MF_PIPE_DOWN", PIPE_DOWN, 1, PIPE_MAX), cfg_pop = env_int("MF_PIPE_POPULATE", PIPE_POPULATE, 0, PIPE_MAX);
+    // (read at every call: a host may retune between clips)
+    const int cfg_chunk = env_int("MF_PIPE_CHUNK", PIPE_CHUNK, 1, 4096), cfg_up = env_int("MF_PIPE_UP", PIPE_UP, 1, PIPE_MAX),
+              cfg_down = env_int("MF_PIPE_DOWN", PIPE_DOWN, 1, PIPE_MAX), cfg_pop = env_int("MF_PIPE_POPULATE", PIPE_POPULATE, 0, PIPE_MAX);
     const int chunk = n < cfg_chunk ? n : cfg_chunk;
     const int nchunks = (n + chunk - 1) / chunk;
     MF_HIP_TRY(pc.frames.need(fb * n)); MF_HIP_TRY(pc.out.need(fb * n));
@@ -160,40 +194,55 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, const do
     MF_HIP_TRY(pc.table.need(table_bytes(chunk, W, H, R, C)));
     MF_HIP_TRY(pc.crop.need((size_t)n * 4 * sizeof(int32_t)));
     MF_HIP_TRY(pc.status.need(sizeof(int32_t)));
+    MF_HIP_TRY(pc.bounds.need(4 * sizeof(int32_t)));
+    if (cropped) MF_HIP_TRY(pc.work.need(crop_resize_workspace_bytes(W, H)));
     uint8_t* d_frames = (uint8_t*)pc.frames.p;
     uint8_t* d_out = (uint8_t*)pc.out.p;
     int32_t* d_crop = (int32_t*)pc.crop.p;
 
-    std::vector<hipEvent_t> up_done(nchunks, nullptr), warp_done(nchunks, nullptr), t0(nchunks, nullptr), t1(nchunks, nullptr);
+    std::vector<hipEvent_t> up_done(nchunks, nullptr), warp_done(nchunks, nullptr), resize_done(nchunks, nullptr), t0(nchunks, nullptr),
+        t1(nchunks, nullptr);
+    hipEvent_t r0 = nullptr, r1 = nullptr;
     struct EventGuard {
-        std::vector<hipEvent_t>* v[4];
-        ~EventGuard() { for (auto* vec : v) for (hipEvent_t e : *vec) if (e) (void)hipEventDestroy(e); }
-    } guard{{&up_done, &warp_done, &t0, &t1}};
+        std::vector<hipEvent_t>* v[5];
+        hipEvent_t *a, *b;
+        ~EventGuard()
+        {
+            for (auto* vec : v) for (hipEvent_t e : *vec) if (e) (void)hipEventDestroy(e);
+            if (*a) (void)hipEventDestroy(*a);
+            if (*b) (void)hipEventDestroy(*b);
+        }
+    } guard{{&up_done, &warp_done, &resize_done, &t0, &t1}, &r0, &r1};
     for (int k = 0; k < nchunks; ++k) {
         MF_HIP_TRY(hipEventCreateWithFlags(&up_done[k], hipEventDisableTiming));
         MF_HIP_TRY(hipEventCreateWithFlags(&warp_done[k], hipEventDisableTiming));
+        if (cropped) MF_HIP_TRY(hipEventCreateWithFlags(&resize_done[k], hipEventDisableTiming));
         if (kernel_ms) { MF_HIP_TRY(hipEventCreate(&t0[k])); MF_HIP_TRY(hipEventCreate(&t1[k])); }
     }
+    if (kernel_ms && cropped) { MF_HIP_TRY(hipEventCreate(&r0)); MF_HIP_TRY(hipEventCreate(&r1)); }
 
     Shared sh;
     sh.up_ready.assign(nchunks, 0);
     sh.warp_ready.assign(nchunks, 0);
-    sh.populated.assign(nchunks, cfg_pop > 0 ? 0 : 1);
+    sh.resize_ready.assign(nchunks, 0);
+    sh.populated.assign(nchunks, cfg_pop > 0 && out ? 0 : 1);
+    sh.populated2.assign(nchunks, cfg_pop > 0 && cropped ? 0 : 1);
     std::vector<std::thread> workers;
     const int n_up = nchunks < cfg_up ? nchunks : cfg_up, n_down = nchunks < cfg_down ? nchunks : cfg_down;
     const int n_pop = nchunks < cfg_pop ? nchunks : cfg_pop;
+    auto chunk_end = [&](int k) { return (k * chunk + chunk < n) ? k * chunk + chunk : n; };
     for (int t = 0; t < n_pop; ++t)
         workers.emplace_back([&, t] {
-            for (int k = t; k < nchunks; k += n_pop) {
-                populate_frames(out, k * chunk, (k * chunk + chunk < n) ? k * chunk + chunk : n, fb);
-                sh.mark(sh.populated, k);
-            }
+            if (out)
+                for (int k = t; k < nchunks; k += n_pop) { populate_frames(out, k * chunk, chunk_end(k), fb); sh.mark(sh.populated, k); }
+            if (cropped)
+                for (int k = t; k < nchunks; k += n_pop) { populate_frames(cropped, k * chunk, chunk_end(k), fb); sh.mark(sh.populated2, k); }
         });
     for (int t = 0; t < n_up; ++t)
         workers.emplace_back([&, t] {
             if (hipSetDevice(dev) != hipSuccess) { sh.fail(hipErrorInvalidDevice, "hipSetDevice (upload thread)"); return; }
             for (int k = t; k < nchunks; k += n_up) {
-                const int i0 = k * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
+                const int i0 = k * chunk, i1 = chunk_end(k);
                 hipError_t e = copy_frames(d_frames, frames, i0, i1, fb, true, pc.up[t]);
                 if (e == hipSuccess) e = hipEventRecord(up_done[k], pc.up[t]);
                 if (e != hipSuccess) { sh.fail(e, "upload of a frame chunk"); return; }
@@ -204,13 +253,20 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, const do
     for (int t = 0; t < n_down; ++t)
         workers.emplace_back([&, t] {
             if (hipSetDevice(dev) != hipSuccess) { sh.fail(hipErrorInvalidDevice, "hipSetDevice (download thread)"); return; }
-            for (int k = t; k < nchunks; k += n_down) {
-                if (!sh.wait(sh.warp_ready, k) || !sh.wait(sh.populated, k)) return;
-                const int i0 = k * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n;
-                hipError_t e = hipStreamWaitEvent(pc.down[t], warp_done[k], 0);
-                if (e == hipSuccess) e = copy_frames(d_out, out, i0, i1, fb, false, pc.down[t]);
-                if (e != hipSuccess) { sh.fail(e, "download of a frame chunk"); return; }
-            }
+            if (out)
+                for (int k = t; k < nchunks; k += n_down) {
+                    if (!sh.wait(sh.warp_ready, k) || !sh.wait(sh.populated, k)) return;
+                    hipError_t e = hipStreamWaitEvent(pc.down[t], warp_done[k], 0);
+                    if (e == hipSuccess) e = copy_frames(d_out, out, k * chunk, chunk_end(k), fb, false, pc.down[t]);
+                    if (e != hipSuccess) { sh.fail(e, "download of a frame chunk"); return; }
+                }
+            if (cropped)                               // second phase: the cropped + resized chunks (they sit in the input stack)
+                for (int k = t; k < nchunks; k += n_down) {
+                    if (!sh.wait(sh.resize_ready, k) || !sh.wait(sh.populated2, k)) return;
+                    hipError_t e = hipStreamWaitEvent(pc.down[t], resize_done[k], 0);
+                    if (e == hipSuccess) e = copy_frames(d_frames, cropped, k * chunk, chunk_end(k), fb, false, pc.down[t]);
+                    if (e != hipSuccess) { sh.fail(e, "download of a cropped frame chunk"); return; }
+                }
             hipError_t e = hipStreamSynchronize(pc.down[t]);
             if (e != hipSuccess) sh.fail(e, "hipStreamSynchronize (download stream)");
         });
@@ -224,7 +280,7 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, const do
     if (e != hipSuccess) { sh.fail(e, "upload of the vertex displacements"); }
     for (int k = 0; k < nchunks && e == hipSuccess && rc == MF_OK; ++k) {
         if (!sh.wait(sh.up_ready, k)) break;
-        const int i0 = k * chunk, i1 = (i0 + chunk < n) ? i0 + chunk : n, m = i1 - i0;
+        const int i0 = k * chunk, i1 = chunk_end(k), m = i1 - i0;
         e = hipStreamWaitEvent(pc.compute, up_done[k], 0);
         if (e != hipSuccess) { sh.fail(e, "hipStreamWaitEvent"); break; }
         if (kernel_ms) (void)hipEventRecord(t0[k], pc.compute);
@@ -239,26 +295,62 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, const do
         sh.mark(sh.warp_ready, k);
     }
     int32_t status = 0;
+    int32_t rect[4] = { 0, 0, W - 1, H - 1 };
+    bool bad_rect = false;
     if (!sh.abort) {
-        e = hipMemcpyAsync(crop, d_crop, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute);
-        if (e == hipSuccess) e = hipMemcpyAsync(&status, pc.status.p, sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute);
-        if (e == hipSuccess) e = hipStreamSynchronize(pc.compute);
-        if (e != hipSuccess) sh.fail(e, "download of the crop values");
+        // clip-level crop rectangle (mfs.py:1103-1106) on the device, then per-frame values, rectangle and status in one wait
+        rc = launch_crop_reduce(d_crop, n, W, H, (int32_t*)pc.bounds.p, pc.compute);
+        if (rc != MF_OK) sh.fail(hipErrorUnknown, "kernel launch");
+        else {
+            e = hipMemcpyAsync(crop, d_crop, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute);
+            if (e == hipSuccess) e = hipMemcpyAsync(rect, pc.bounds.p, sizeof rect, hipMemcpyDeviceToHost, pc.compute);
+            if (e == hipSuccess) e = hipMemcpyAsync(&status, pc.status.p, sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute);
+            if (e == hipSuccess) e = hipStreamSynchronize(pc.compute);
+            if (e != hipSuccess) sh.fail(e, "download of the crop values");
+        }
+    }
+    if (!sh.abort && cropped) {
+        // _crop_frames (mfs.py:1111-1157): needs the rectangle of the WHOLE clip, hence a second phase.  A degenerate mesh or an
+        // empty rectangle (cv2.resize would fail on an empty source) ends the call before it.
+        bad_rect = rect[2] < rect[0] || rect[3] < rect[1];
+        if (status != 0 || bad_rect) sh.fail(hipSuccess, "");
+        else {
+            if (kernel_ms) (void)hipEventRecord(r0, pc.compute);
+            for (int k = 0; k < nchunks; ++k) {
+                const int i0 = k * chunk, m = chunk_end(k) - i0;
+                rc = launch_crop_resize(d_out + fb * i0, d_frames + fb * i0, m, W, H, rect[0], rect[1], rect[2], rect[3], pc.work.p, pc.compute);
+                if (rc != MF_OK) { sh.fail(hipErrorUnknown, "kernel launch"); break; }
+                e = hipEventRecord(resize_done[k], pc.compute);
+                if (e != hipSuccess) { sh.fail(e, "hipEventRecord"); break; }
+                sh.mark(sh.resize_ready, k);
+            }
+            if (kernel_ms && !sh.abort) (void)hipEventRecord(r1, pc.compute);
+        }
     }
     for (auto& w : workers) w.join();
+    if (bounds) for (int i = 0; i < 4; ++i) bounds[i] = rect[i];
+    if (status != 0) {
+        (void)hipDeviceSynchronize();
+        set_error("mf_warp_u8c3_host: %d degenerate mesh cell(s): no homography exists (cv2.findHomography would return None)", status);
+        return MF_ERR_DEGENERATE;
+    }
+    if (bad_rect) {
+        (void)hipDeviceSynchronize();
+        set_error("mf_warp_crop_u8c3_host_frames: empty crop rectangle (%d, %d, %d, %d): cv2.resize would fail on an empty source",
+                  rect[0], rect[1], rect[2], rect[3]);
+        return MF_ERR_INVALID_ARG;
+    }
     if (sh.abort) {
         (void)hipDeviceSynchronize();
         if (rc != MF_OK) return rc;                        // launch_* already set the message
         return hip_fail(sh.err, sh.what);
     }
     if (kernel_ms) {
+        MF_HIP_TRY(hipStreamSynchronize(pc.compute));
         float total = 0.0f;
         for (int k = 0; k < nchunks; ++k) { float ms = 0.0f; MF_HIP_TRY(hipEventElapsedTime(&ms, t0[k], t1[k])); total += ms; }
+        if (cropped) { float ms = 0.0f; MF_HIP_TRY(hipEventElapsedTime(&ms, r0, r1)); total += ms; }
         *kernel_ms = total;
-    }
-    if (status != 0) {
-        set_error("mf_warp_u8c3_host: %d degenerate mesh cell(s): no homography exists (cv2.findHomography would return None)", status);
-        return MF_ERR_DEGENERATE;
     }
     return MF_OK;
 }
@@ -269,14 +361,31 @@ using namespace mf;
 
 extern "C" {
 
+static int check_host_args(const char* name, const uint8_t* const* frames, uint8_t* const* out, uint8_t* const* cropped, const double* unstab,
+                           const double* stab, int n, int W, int H, int R, int C, const uint8_t* border_bgr, const int32_t* crop)
+{
+    if (!frames || !unstab || !stab || !border_bgr || !crop || (!out && !cropped)) { set_error("%s: null pointer", name); return MF_ERR_INVALID_ARG; }
+    if (n <= 0 || W < 2 || H < 2 || R <= 0 || C <= 0) { set_error("%s: bad sizes", name); return MF_ERR_INVALID_ARG; }
+    for (int i = 0; i < n; ++i)
+        if (!frames[i] || (out && !out[i]) || (cropped && !cropped[i])) { set_error("%s: null frame pointer %d", name, i); return MF_ERR_INVALID_ARG; }
+    return MF_OK;
+}
+
 int mf_warp_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* out, const double* unstab, const double* stab, int n,
                              int W, int H, int R, int C, const uint8_t border_bgr[3], int32_t* crop, float* kernel_ms)
 {
-    if (!frames || !out || !unstab || !stab || !border_bgr || !crop) { set_error("mf_warp_u8c3_host_frames: null pointer"); return MF_ERR_INVALID_ARG; }
-    if (n <= 0 || W < 2 || H < 2 || R <= 0 || C <= 0) { set_error("mf_warp_u8c3_host_frames: bad sizes"); return MF_ERR_INVALID_ARG; }
-    for (int i = 0; i < n; ++i)
-        if (!frames[i] || !out[i]) { set_error("mf_warp_u8c3_host_frames: null frame pointer %d", i); return MF_ERR_INVALID_ARG; }
-    return warp_host_frames(frames, out, unstab, stab, n, W, H, R, C, border_bgr, crop, kernel_ms);
+    if (!out) { set_error("mf_warp_u8c3_host_frames: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (const int rc = check_host_args("mf_warp_u8c3_host_frames", frames, out, nullptr, unstab, stab, n, W, H, R, C, border_bgr, crop)) return rc;
+    return warp_host_frames(frames, out, nullptr, unstab, stab, n, W, H, R, C, border_bgr, crop, nullptr, kernel_ms);
+}
+
+int mf_warp_crop_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t* const* cropped, const double* unstab,
+                                  const double* stab, int n, int W, int H, int R, int C, const uint8_t border_bgr[3], int32_t* crop,
+                                  int32_t bounds[4], float* kernel_ms)
+{
+    if (!cropped || !bounds) { set_error("mf_warp_crop_u8c3_host_frames: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (const int rc = check_host_args("mf_warp_crop_u8c3_host_frames", frames, out, cropped, unstab, stab, n, W, H, R, C, border_bgr, crop)) return rc;
+    return warp_host_frames(frames, out, cropped, unstab, stab, n, W, H, R, C, border_bgr, crop, bounds, kernel_ms);
 }
 
 int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab, const double* stab,
@@ -289,20 +398,22 @@ int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab,
     std::vector<const uint8_t*> in(n);
     std::vector<uint8_t*> outp(n);
     for (int i = 0; i < n; ++i) { in[i] = frames + fb * i; outp[i] = out + fb * i; }
-    return warp_host_frames(in.data(), outp.data(), unstab, stab, n, W, H, R, C, border_bgr, crop, kernel_ms);
+    return warp_host_frames(in.data(), outp.data(), nullptr, unstab, stab, n, W, H, R, C, border_bgr, crop, nullptr, kernel_ms);
 }
 
 int mf_host_cache_release(void)
 {
-    std::lock_guard<std::mutex> g(g_pipe.lock);
-    if (g_pipe.device >= 0) {
-        int prev = 0;
-        (void)hipGetDevice(&prev);
-        (void)hipSetDevice(g_pipe.device);
-        (void)hipDeviceSynchronize();
-        g_pipe.release();
-        (void)hipSetDevice(prev);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int d = 0; d < PIPE_MAX_DEVICES; ++d) {
+        std::lock_guard<std::mutex> g(g_pipe[d].lock);
+        if (g_pipe[d].device >= 0) {
+            (void)hipSetDevice(g_pipe[d].device);
+            (void)hipDeviceSynchronize();
+            g_pipe[d].release();
+        }
     }
+    (void)hipSetDevice(prev);
     return MF_OK;
 }
 

@@ -1137,16 +1137,21 @@ __global__ void d16_probe_kernel()
 }
 int check_d16_zero_fill(hipStream_t st)
 {
-    static int state = 0;                       // 0 unknown, 1 fine, -1 refused  (benign race: every thread computes the same)
-    if (state == 0) {
+    // per DEVICE: 0 unknown, 1 fine, -1 refused  (benign race: every thread computes the same).  The probe synchronises, so
+    // mf_set_device() runs it ahead of time; a launcher only gets here first when the host selected the device itself.
+    static int state[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hip_fail(hipErrorInvalidDevice, "d16 probe: hipGetDevice");
+    if (state[dev] == 0) {
         int h = 0;
         hipLaunchKernelGGL(d16_probe_kernel, dim3(1), dim3(64), 0, st);
-        if (hipStreamSynchronize(st) != hipSuccess || hipMemcpyFromSymbol(&h, HIP_SYMBOL(d16_probe_result), sizeof h) != hipSuccess)
-            return hip_fail(hipGetLastError(), "d16 probe");
-        state = h == 1 ? 1 : -1;
+        hipError_t e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipMemcpyFromSymbol(&h, HIP_SYMBOL(d16_probe_result), sizeof h);
+        if (e != hipSuccess) return hip_fail(e, "d16 probe");
+        state[dev] = h == 1 ? 1 : -1;
     }
-    if (state != 1) {
-        set_error("this device preserves the other half of a d16 LDS load (no SRAM ECC): the byte-tap kernels are not built for it");
+    if (state[dev] != 1) {
+        set_error("device %d preserves the other half of a d16 LDS load (no SRAM ECC): the byte-tap kernels are not built for it", dev);
         return MF_ERR_INVALID_ARG;
     }
     return MF_OK;

@@ -23,29 +23,42 @@ except Exception:  # pragma: no cover
     _tqdm = None
 
 
-def _warp_host_c(self, clip, unstab, stab):
+def _warp_host_c(self, clip, unstab, stab, crop=False, keep_uncropped=True):
     """Host frames in -> host frames out through the C ABI's own chunked pipeline (csrc/hostpipe.hip:
     `mf_warp_u8c3_host_frames`, upload / kernel / download threads below Python, GIL released for the whole call).
     Returns (stabilized frames (F, H, W, 3) uint8 array, clip-level crop bounds as np.int64 (left, top, right,
-    bottom), mfs.py:1103-1106)."""
+    bottom), mfs.py:1103-1106).  crop=True: `mf_warp_crop_u8c3_host_frames` -- the same pipeline followed by `_crop_frames`
+    (mfs.py:159, 1111-1157) on the device; returns (stabilized frames or None when keep_uncropped is False, bounds,
+    cropped + resized frames (F, H, W, 3))."""
     import ctypes
+    import torch
     from . import _lib, pipeline
     dev = self._torch_device()
     n, H, W = clip.num_frames, clip.height, clip.width
     frames = [clip.array[i] for i in range(n)] if clip.array is not None else \
         [pipeline._as_frame(f, H, W) for f in clip.frames]
-    out = np.empty((n, H, W, 3), dtype=np.uint8)
     fb = H * W * 3
+    want_out = keep_uncropped or not crop
+    out = np.empty((n, H, W, 3), dtype=np.uint8) if want_out else None
     pin = (ctypes.c_void_p * n)(*[f.ctypes.data for f in frames])
-    pout = (ctypes.c_void_p * n)(*[out.ctypes.data + i * fb for i in range(n)])
-    crop = np.empty((n, 4), dtype=np.int32)
+    pout = (ctypes.c_void_p * n)(*[out.ctypes.data + i * fb for i in range(n)]) if want_out else None
+    per_frame = np.empty((n, 4), dtype=np.int32)
     border = (ctypes.c_uint8 * 3)(*[int(max(0, min(255, round(float(c))))) for c in self.color_outside_image_area_bgr])
-    _lib.check(_lib.lib.mf_set_device(dev.index if dev.index is not None else 0))
-    _lib.check(_lib.lib.mf_warp_u8c3_host_frames(
-        pin, pout, unstab.ctypes.data_as(ctypes.c_void_p), stab.ctypes.data_as(ctypes.c_void_p), n, W, H,
-        self.mesh_row_count, self.mesh_col_count, border, crop.ctypes.data_as(ctypes.c_void_p), None))
-    bounds = (np.int64(crop[:, 0].max()), np.int64(crop[:, 1].max()), np.int64(crop[:, 2].min()), np.int64(crop[:, 3].min()))
-    return out, bounds
+    args = (unstab.ctypes.data_as(ctypes.c_void_p), stab.ctypes.data_as(ctypes.c_void_p), n, W, H,
+            self.mesh_row_count, self.mesh_col_count, border, per_frame.ctypes.data_as(ctypes.c_void_p))
+    # the library works on the calling thread's current HIP device: scope it like every other path here does (and leave the
+    # caller's current device as it was)
+    with torch.cuda.device(dev):
+        if not crop:
+            _lib.check(_lib.lib.mf_warp_u8c3_host_frames(pin, pout, *args, None))
+            bounds = (np.int64(per_frame[:, 0].max()), np.int64(per_frame[:, 1].max()),
+                      np.int64(per_frame[:, 2].min()), np.int64(per_frame[:, 3].min()))
+            return out, bounds
+        cropped = np.empty((n, H, W, 3), dtype=np.uint8)
+        pcrop = (ctypes.c_void_p * n)(*[cropped.ctypes.data + i * fb for i in range(n)])
+        rect = (ctypes.c_int32 * 4)()
+        _lib.check(_lib.lib.mf_warp_crop_u8c3_host_frames(pin, pout, pcrop, *args, rect, None))
+    return out, tuple(np.int64(v) for v in rect), cropped
 
 
 class MeshFlowStabilizer:
@@ -191,15 +204,17 @@ class MeshFlowStabilizer:
         """The hot path of `stabilize` (mfs.py:150-159, 162) on in-memory inputs, with ONE host->device and ONE
         device->host pass over the frames (the two private methods below each pay their own, like any drop-in
         for NumPy-in / NumPy-out methods must).  The passes are chunked and overlapped with each other and with
-        the kernels (`pipeline.py`): frames go up `chunk_frames` at a time on `io_threads` copy threads, each
-        chunk is warped as soon as it has landed and comes back while later chunks are still going up.
+        the kernels below Python (csrc/hostpipe.hip): each 16-frame chunk is warped as soon as it has landed and
+        comes back while later chunks are still going up.  (`chunk_frames` / `io_threads` are kept for callers of
+        earlier versions; the C pipeline has its own, MF_PIPE_* in the environment.)
 
         Returns (stabilized_frames list, crop_boundaries, vertex_stabilized_displacements, stability_score)
         and, with crop=True, a fifth item: the cropped + resized frames (`_crop_frames`, mfs.py:159), produced
-        on the device from the stabilized frames; keep_uncropped=False then skips copying the uncropped
-        stabilized frames back (the reference only uses the cropped ones afterwards) and returns None for them."""
+        on the device from the stabilized frames in the same pipeline once the clip-level rectangle is known
+        (`mf_warp_crop_u8c3_host_frames`); keep_uncropped=False then never brings the uncropped stabilized frames back
+        (the reference only uses the cropped ones afterwards) and returns None for them."""
         import torch
-        from . import ops, pipeline
+        from . import pipeline
         self._check_definition(adaptive_weights_definition)
         num_frames = len(unstabilized_frames)
         dev = self._torch_device()
@@ -207,38 +222,17 @@ class MeshFlowStabilizer:
         self._check_mesh_shape(unstab, num_frames)
         clip = pipeline.HostClip(unstabilized_frames, num_frames)
         H, W = clip.height, clip.width
+        # the frames travel through the C ABI's own pipeline (no Python threads, GIL released): up in chunks, warped as they land,
+        # and -- crop=True -- cropped + resized on the device once the clip-level rectangle is known, only then back
+        d_stab = self._stabilized_vertex_displacements_device(torch.from_numpy(unstab).to(dev), W, H,
+                                                              adaptive_weights_definition, homographies)
+        stab = d_stab.cpu().numpy()
+        score = self._compute_stability_score(num_frames, stab)
         if not crop:
-            # frames only travel through the warp: the C ABI's own pipeline moves them (no Python threads, GIL released)
-            d_stab = self._stabilized_vertex_displacements_device(torch.from_numpy(unstab).to(dev), W, H,
-                                                                  adaptive_weights_definition, homographies)
-            stab = d_stab.cpu().numpy()
             out_host, bounds = _warp_host_c(self, clip, unstab, stab)
-            return list(out_host), bounds, stab, self._compute_stability_score(num_frames, stab)
-        io = pipeline.ChunkedTransfer(dev, io_threads, io_threads)
-        try:
-            d_unstab = torch.from_numpy(unstab).to(dev)
-            want_uncropped = keep_uncropped or not crop
-            staged = self._start_upload(io, clip, chunk_frames)            # copies start now, on their own streams
-            d_stab = self._stabilized_vertex_displacements_device(d_unstab, W, H, adaptive_weights_definition, homographies)
-            out_host, d_out, bounds = self._warp_staged(io, staged, d_unstab, d_stab, want_uncropped)
-            stab = d_stab.cpu().numpy()
-            score = self._compute_stability_score(num_frames, stab)
-            cropped_host = None
-            if crop:
-                d_frames, ranges = staged[0], staged[1]
-                d_cropped = ops.crop_resize(d_out, bounds, out=d_frames)    # the input stack is no longer needed
-                cropped_host = np.empty((num_frames, H, W, 3), dtype=np.uint8)
-                done = torch.cuda.Event()
-                done.record(torch.cuda.current_stream(dev))
-                for k, (i0, i1) in enumerate(ranges):
-                    io.download(d_cropped[i0:i1], cropped_host[i0:i1], done, k)
-            io.finish()
-        finally:
-            io.close()
-        frames = list(out_host) if want_uncropped else None
-        if not crop:
-            return frames, bounds, stab, score
-        return frames, bounds, stab, score, list(cropped_host)
+            return list(out_host), bounds, stab, score
+        out_host, bounds, cropped_host = _warp_host_c(self, clip, unstab, stab, crop=True, keep_uncropped=keep_uncropped)
+        return (list(out_host) if out_host is not None else None), bounds, stab, score, list(cropped_host)
 
     def _start_upload(self, io, clip, chunk_frames):
         """Allocates the device clip and starts the chunked upload; returns (d_frames, ranges, upload futures, clip)."""
@@ -251,35 +245,6 @@ class MeshFlowStabilizer:
         allocated.record(torch.cuda.current_stream(dev))
         return d_frames, ranges, io.upload_all(clip, d_frames, ranges, allocated), clip
 
-    def _warp_staged(self, io, staged, d_unstab, d_stab, want_host):
-        """Warps every chunk as it lands and (want_host) queues its way back.  Returns (host frames or None,
-        device frames, clip-level crop bounds as np.int64 (left, top, right, bottom), mfs.py:1103-1106)."""
-        import torch
-        from . import ops
-        d_frames, ranges, uploads, clip = staged
-        dev = io.device
-        num_frames, H, W = clip.num_frames, clip.height, clip.width
-        R, C = self.mesh_row_count, self.mesh_col_count
-        d_out = torch.empty_like(d_frames)
-        d_crop = torch.empty((num_frames, 4), dtype=torch.int32, device=dev)
-        out_host = np.empty((num_frames, H, W, 3), dtype=np.uint8) if want_host else None
-        tables = {}
-        compute = torch.cuda.current_stream(dev)
-        for k, (i0, i1) in enumerate(ranges):
-            compute.wait_event(uploads[k].result())
-            table = ops.cell_table(d_unstab[i0:i1], d_stab[i0:i1], W, H, R, C, table=tables.get(i1 - i0), reset_status=False)
-            tables[i1 - i0] = table
-            ops.warp(d_frames[i0:i1], table, self.color_outside_image_area_bgr, out=d_out[i0:i1])
-            d_crop[i0:i1].copy_(table.crop)
-            if want_host:
-                done = torch.cuda.Event()
-                done.record(compute)
-                io.download(d_out[i0:i1], out_host[i0:i1], done, k)
-        bounds_h = ops.crop_reduce(d_crop, W, H).cpu().numpy()
-        for table in tables.values():
-            table.check()
-        return out_host, d_out, tuple(np.int64(v) for v in bounds_h)
-
     # ------------------------------------------------------------------------------------------
     # drop-in boundary, host buffers (same signatures as the reference)
     # ------------------------------------------------------------------------------------------
@@ -288,7 +253,10 @@ class MeshFlowStabilizer:
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError('no MI355X visible: the meshflow_amd hot path has no CPU fallback')
-        return torch.device(self.device if self.device is not None else f'cuda:{torch.cuda.current_device()}')
+        dev = torch.device(self.device if self.device is not None else 'cuda')
+        if dev.index is None:                 # 'cuda' without an index means the caller's CURRENT device, not device 0
+            dev = torch.device(dev.type, torch.cuda.current_device())
+        return dev
 
     def _get_stabilized_vertex_displacements(self, num_frames, unstabilized_frames, adaptive_weights_definition,
                                              vertex_unstabilized_displacements_by_frame_index, homographies):

@@ -12,6 +12,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope='module')
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: the -m gpu tests must run on an MI355X')
+    return torch.device('cuda:0')
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
@@ -143,3 +151,130 @@ def test_rccl_entry_points_single_rank():
         _lib.check(lib.mf_comm_destroy())
     _lib.check(lib.mf_comm_size(ctypes.byref(n)))
     assert n.value == 0
+
+
+@pytest.mark.parametrize('F,H,W,R,C,keep', [(40, 72, 100, 3, 5, True), (21, 96, 128, 8, 8, False)])
+def test_host_warp_crop_pipeline_equals_oracle(F, H, W, R, C, keep):
+    """mf_warp_crop_u8c3_host_frames = warp (mfs.py:909-1108) + clip-level rectangle (mfs.py:1103-1106) + _crop_frames
+    (mfs.py:1111-1157) in ONE host-to-host pipeline: cropped frames equal the NumPy oracle's crop of the C oracle's warp."""
+    from meshflow_amd import _lib
+    from oracle import clib, meshflow_oracle as mo
+    frames, disp, stab = _clip(F, H, W, R, C, seed=F + H)
+    want, want_crop, bad = clib.warp_clip(frames, R, C, disp, stab, (9, 8, 7))
+    assert bad == 0
+    rect = (want_crop[:, 0].max(), want_crop[:, 1].max(), want_crop[:, 2].min(), want_crop[:, 3].min())
+    want_cropped = np.stack(mo.crop_frames(list(want), rect))
+    border = (ctypes.c_uint8 * 3)(9, 8, 7)
+    ins = [f.copy() for f in frames]
+    outs = [np.zeros((H, W, 3), np.uint8) for _ in range(F)]
+    crs = [np.zeros((H, W, 3), np.uint8) for _ in range(F)]
+    pin = (ctypes.c_void_p * F)(*[f.ctypes.data for f in ins])
+    pout = (ctypes.c_void_p * F)(*[f.ctypes.data for f in outs]) if keep else None
+    pcr = (ctypes.c_void_p * F)(*[f.ctypes.data for f in crs])
+    for _ in range(2):                                      # second call: cached buffers
+        crop = np.zeros((F, 4), np.int32)
+        bounds = (ctypes.c_int32 * 4)()
+        ms = ctypes.c_float(-1)
+        _lib.check(_lib.lib.mf_warp_crop_u8c3_host_frames(pin, pout, pcr, _p(disp), _p(stab), F, W, H, R, C, border, _p(crop), bounds,
+                                                          ctypes.byref(ms)))
+        assert tuple(bounds) == tuple(int(v) for v in rect)
+        np.testing.assert_array_equal(crop, want_crop)
+        np.testing.assert_array_equal(np.stack(crs), want_cropped)
+        if keep:
+            np.testing.assert_array_equal(np.stack(outs), want)
+        assert ms.value > 0
+    np.testing.assert_array_equal(np.stack(ins), frames)    # inputs untouched
+
+
+def test_host_wrapper_rejects_overlapping_input_and_output():
+    from meshflow_amd import _lib
+    F, H, W, R, C = 8, 48, 64, 2, 2
+    frames, disp, stab = _clip(F, H, W, R, C, seed=2)
+    crop = np.zeros((F, 4), np.int32)
+    border = (ctypes.c_uint8 * 3)(0, 0, 255)
+    rc = _lib.lib.mf_warp_u8c3_host(_p(frames), _p(frames), _p(disp), _p(stab), F, W, H, R, C, border, _p(crop), None)
+    assert rc == _lib.MF_ERR_INVALID_ARG and b'overlap' in _lib.lib.mf_last_error()
+    big = np.zeros((F + 1, H, W, 3), np.uint8)                # output shifted by one frame over the input
+    big[:F] = frames
+    pin = (ctypes.c_void_p * F)(*[big[i].ctypes.data for i in range(F)])
+    pout = (ctypes.c_void_p * F)(*[big[i + 1].ctypes.data for i in range(F)])
+    rc = _lib.lib.mf_warp_u8c3_host_frames(pin, pout, _p(disp), _p(stab), F, W, H, R, C, border, _p(crop), None)
+    assert rc == _lib.MF_ERR_INVALID_ARG
+
+
+def test_host_warp_crop_reports_empty_rectangle():
+    """A clip whose crop rectangle is empty (cv2.resize would fail on an empty source): MF_ERR_INVALID_ARG, bounds still written."""
+    from meshflow_amd import _lib, synthetic
+    F, H, W, R, C = 6, 64, 96, 4, 4
+    frames = synthetic.frames_numpy(F, H, W, seed=1)
+    disp = np.zeros((F, R + 1, C + 1, 2))
+    stab = disp.copy()
+    stab[0, ..., 0] = 60.0       # content moves right by 60 px in frame 0 ...
+    stab[1, ..., 0] = -60.0      # ... and left by 60 px in frame 1: left bound 60 > right bound W - 1 - 60
+    border = (ctypes.c_uint8 * 3)(0, 0, 255)
+    outs = np.zeros_like(frames); crs = np.zeros_like(frames)
+    fb = H * W * 3
+    pin = (ctypes.c_void_p * F)(*[frames.ctypes.data + i * fb for i in range(F)])
+    pcr = (ctypes.c_void_p * F)(*[crs.ctypes.data + i * fb for i in range(F)])
+    crop = np.zeros((F, 4), np.int32)
+    bounds = (ctypes.c_int32 * 4)()
+    rc = _lib.lib.mf_warp_crop_u8c3_host_frames(pin, None, pcr, _p(disp), _p(stab), F, W, H, R, C, border, _p(crop), bounds, None)
+    assert rc == _lib.MF_ERR_INVALID_ARG and b'empty crop rectangle' in _lib.lib.mf_last_error()
+    assert bounds[0] > bounds[2]
+    # and the pipeline works again afterwards
+    stab[:] = 0.0
+    _lib.check(_lib.lib.mf_warp_crop_u8c3_host_frames(pin, None, pcr, _p(disp), _p(stab), F, W, H, R, C, border, _p(crop), bounds, None))
+    np.testing.assert_array_equal(crs, frames)              # identity warp, full-frame rectangle: resize is the identity
+
+
+def test_full_cfg2_clip_through_raw_c_abi_equals_device_path(dev):
+    """BASELINE config 2 at full size (300 frames of 1920x1080, 16x16 mesh) through raw-ctypes mf_warp_u8c3_host_frames equals the
+    device-resident operators (mf_cell_table_f64 + mf_warp_u8c3) byte for byte, and sampled frames equal the C oracle."""
+    import torch
+    from meshflow_amd import _lib, ops, synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    from oracle import clib
+    H, W, F, R, C = 1080, 1920, 300, 16, 16
+    disp, hom = synthetic.motion(F, R, C, seed=0)
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=10, optimization_num_iterations=100)
+    d_disp = torch.from_numpy(disp).to(dev)
+    d_stab = s._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
+    stab = d_stab.cpu().numpy()
+    d_frames = synthetic.frames_torch(F, H, W, dev, seed=0, kind='pattern')
+    frames = d_frames.cpu().numpy()
+    table = ops.cell_table(d_disp, d_stab, W, H, R, C)
+    d_out = ops.warp(d_frames, table)
+    want, want_crop = d_out.cpu().numpy(), table.crop.cpu().numpy()
+    del d_frames, d_out, table
+    out = np.empty_like(frames)
+    fb = H * W * 3
+    pin = (ctypes.c_void_p * F)(*[frames.ctypes.data + i * fb for i in range(F)])
+    pout = (ctypes.c_void_p * F)(*[out.ctypes.data + i * fb for i in range(F)])
+    crop = np.zeros((F, 4), np.int32)
+    _lib.check(_lib.lib.mf_warp_u8c3_host_frames(pin, pout, _p(np.ascontiguousarray(disp)), _p(np.ascontiguousarray(stab)), F, W, H, R, C,
+                                                 (ctypes.c_uint8 * 3)(0, 0, 255), _p(crop), None))
+    np.testing.assert_array_equal(crop, want_crop)
+    assert np.array_equal(out, want)
+    sel = [0, 149, 299]
+    ref, ref_crop, bad = clib.warp_clip(frames[sel], R, C, disp[sel], stab[sel], use_bbox=True, openmp=True)
+    assert bad == 0
+    np.testing.assert_array_equal(crop[sel], ref_crop)
+    assert np.array_equal(out[sel], ref)
+
+
+def test_host_pipeline_leaves_the_current_device_alone(dev):
+    """The C pipeline works on the calling thread's current HIP device; the Python boundary scopes it (torch.cuda.device) and must
+    leave torch's current device as it found it -- also for device='cuda' (no index = the CURRENT device, not device 0)."""
+    import torch
+    from meshflow_amd import synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    F, H, W, R, C = 6, 48, 64, 2, 2
+    frames, disp, hom = synthetic.clip(F, H, W, R, C, seed=5)
+    last = torch.cuda.device_count() - 1
+    for name in ('cuda', f'cuda:{last}'):
+        s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=3, optimization_num_iterations=5, device=name)
+        before = torch.cuda.current_device()
+        out, bounds, stab, score, cropped = s.stabilize_clip(list(frames), disp, hom, crop=True)
+        assert torch.cuda.current_device() == before
+        assert s._torch_device().index == (before if name == 'cuda' else last)
+        assert len(out) == F and len(cropped) == F

@@ -286,18 +286,21 @@ def test_warp_1080p_vs_c_oracle_and_identity(dev):
     np.testing.assert_array_equal(crop, [[0, 0, W - 1, H - 1]] * 2)
 
 
-def test_warp_full_cfg2_clip_properties(dev):
-    """BASELINE config 2 at full size (300 frames of 1920x1080, 16x16 mesh), device-resident, through properties that do
-    not need the oracle on all 300 frames: an integer global shift moves every interior pixel by exactly that shift and
-    paints the uncovered band in the border colour; the real smoothed motion is deterministic (two launches, same bytes)
-    and a sample of frames is bit-identical to the C oracle; the clip-level bounds follow mfs.py:1103-1106."""
+@pytest.mark.parametrize('F,H,W,clip_frames,first', [(300, 1080, 1920, 300, 0), (150, 2160, 3840, 1200, 450)])
+def test_warp_full_size_clip_properties(dev, F, H, W, clip_frames, first):
+    """BASELINE config 2 at full size (300 frames of 1920x1080, 16x16 mesh) and config 4 at SHARD size (150 frames of
+    3840x2160: frames 450..599 of the 1200-frame clip, what one of 8 GPUs holds; Jacobi over all 1200 frames), device-resident,
+    through properties that do not need the oracle on every frame: an integer global shift moves every interior pixel by
+    exactly that shift and paints the uncovered band in the border colour; the real smoothed motion is deterministic (two
+    launches, same bytes) and a sample of frames is bit-identical to the C oracle; the clip-level bounds follow mfs.py:1103-1106."""
     from meshflow_amd import ops, synthetic
     from meshflow_amd.stabilizer import MeshFlowStabilizer
     from oracle import clib
-    F, H, W, R, C = 300, 1080, 1920, 16, 16
-    d_frames = synthetic.frames_torch(F, H, W, dev, seed=0, kind='pattern')
-    disp, hom = synthetic.motion(F, R, C, seed=0)
-    d_disp = torch.from_numpy(disp).to(dev)
+    R, C = 16, 16
+    d_frames = synthetic.frames_torch(F, H, W, dev, seed=0, kind='pattern', first_frame=first)
+    disp_all, hom = synthetic.motion(clip_frames, R, C, seed=0)
+    d_disp_all = torch.from_numpy(disp_all).to(dev)
+    disp, d_disp = disp_all[first:first + F], d_disp_all[first:first + F]
     # (a) integer shift: stabilized = unstabilized + (dx, dy) on every vertex of every frame
     dx, dy = 7, -5
     d_shift = d_disp + torch.tensor([dx, dy], dtype=torch.float64, device=dev)
@@ -312,12 +315,12 @@ def test_warp_full_cfg2_clip_properties(dev):
     del out, table
     # (b) the smoothed motion of the config
     s = MeshFlowStabilizer(device=str(dev))
-    d_stab = s._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
+    d_stab = s._stabilized_vertex_displacements_device(d_disp_all, W, H, 0, hom)[first:first + F]
     out1, crop1 = s._stabilized_frames_device(d_frames, d_disp, d_stab)
     out1, crop1 = out1.clone(), crop1.clone()
     out2, crop2 = s._stabilized_frames_device(d_frames, d_disp, d_stab)
     assert torch.equal(out1, out2) and torch.equal(crop1, crop2)
-    sel = [0, 149, 299]
+    sel = [0, F // 2 - 1, F - 1]
     stab = d_stab.cpu().numpy()
     want, want_crop, bad = clib.warp_clip(d_frames[sel].cpu().numpy(), R, C, disp[sel], stab[sel], use_bbox=True, openmp=True)
     assert bad == 0
@@ -530,7 +533,6 @@ def test_methods_borrowed_by_a_foreign_class(dev):
         _jacobi_coefficients_device = amd.MeshFlowStabilizer._jacobi_coefficients_device
         _stabilized_vertex_displacements_device = amd.MeshFlowStabilizer._stabilized_vertex_displacements_device
         _start_upload = amd.MeshFlowStabilizer._start_upload
-        _warp_staged = amd.MeshFlowStabilizer._warp_staged
         _crop_frames = amd.MeshFlowStabilizer._crop_frames
         device = None
 
