@@ -402,7 +402,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
     region.flags_origin = 0;
     region.src_dwords = 0;
     if (sane && cnt > 0 && !overflow && (W & 3) == 0 && 3 * W >= MF_STAGE_PITCH && H > MF_STAGE_ROWS &&
-        umin > -4.0f && vmin > -4.0f && umax < 40000.0f && vmax < 40000.0f) {
+        umin > -1e6f && vmin > -1e6f && umax < 1e6f && vmax < 1e6f) {
         // Taps of a pixel at (u, v): columns ix, ix + 1 with ix = rint(32 u) >> 5 in [floor(u - 1/64), floor(u + 1/64)], same for
         // rows.  u and v over the footprint stay between their corner values (ratios of affine functions, w > 0), and the corner
         // values here are float32 evaluations: error below 0.01 at coordinates up to 8192 (a few operations at 2^-24 relative,
@@ -410,8 +410,13 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
         const float slack = (W <= 8192 && H <= 8192) ? 0.0625f : 1.0f;
         const int ix_lo = (int)floorf(umin - slack), ix_hi = (int)floorf(umax + slack) + 1;
         const int iy_lo = (int)floorf(vmin - slack), iy_hi = (int)floorf(vmax + slack) + 1;
-        const int sx0 = min(max(ix_lo, 0), (3 * W - MF_STAGE_PITCH) / 3), sy0 = min(max(iy_lo, 0), H - MF_STAGE_ROWS - 1);
-        if (ix_lo >= sx0 && ix_hi <= sx0 + MF_STAGE_COLS - 1 && iy_lo >= sy0 && iy_hi <= sy0 + MF_STAGE_ROWS - 1)
+        // STAGED: the window holds every tap position CLAMPED into the frame -- for a footprint whose taps all lie inside the frame
+        // that is every tap; for one on the frame border the warp kernel's per-tap path reads the clamped positions and paints the
+        // taps outside in the border colour (cv2.remap BORDER_CONSTANT, mfs.py:1063-1069)
+        const int cx_lo = min(max(ix_lo, 0), W - 1), cx_hi = min(max(ix_hi, 0), W - 1);
+        const int cy_lo = min(max(iy_lo, 0), H - 1), cy_hi = min(max(iy_hi, 0), H - 1);
+        const int sx0 = min(cx_lo, (3 * W - MF_STAGE_PITCH) / 3), sy0 = min(cy_lo, H - MF_STAGE_ROWS - 1);
+        if (cx_hi <= sx0 + MF_STAGE_COLS - 1 && cy_hi <= sy0 + MF_STAGE_ROWS - 1)
         {
             // DEEP also asks for a whole footprint (all 256 pixels inside the frame): its lanes are then all active.
             // Interior: every tap inside the frame (ix_lo >= 0, ix_hi <= W - 1) and no crop flag possible -- |u| < 1 needs

@@ -388,6 +388,23 @@ __device__ __forceinline__ void blend_pixel(uint32_t bxj, uint32_t byj, const Ta
     oR = udot2(vR, wq, 32768u);
 }
 
+// The 2 x 2 taps of ONE pixel from four separate LDS positions (the per-tap path of frame-border footprints: every tap at its position
+// clamped into the frame, a00 / a01 = row iy at columns ix / ix + 1, a10 / a11 = row iy + 1), in the blend's layout.  Loads and wait in
+// one asm block: nothing can be scheduled between them.
+__device__ __forceinline__ void taps_clamped(uint32_t a00, uint32_t a01, uint32_t a10, uint32_t a11, TapRegs& t)
+{
+    asm volatile("ds_read_u8 %0, %12 offset:0\n\tds_read_u8_d16_hi %1, %13 offset:0\n\t"
+                 "ds_read_u8 %2, %12 offset:1\n\tds_read_u8_d16_hi %3, %13 offset:1\n\t"
+                 "ds_read_u8 %4, %12 offset:2\n\tds_read_u8_d16_hi %5, %13 offset:2\n\t"
+                 "ds_read_u8 %6, %14 offset:0\n\tds_read_u8_d16_hi %7, %15 offset:0\n\t"
+                 "ds_read_u8 %8, %14 offset:1\n\tds_read_u8_d16_hi %9, %15 offset:1\n\t"
+                 "ds_read_u8 %10, %14 offset:2\n\tds_read_u8_d16_hi %11, %15 offset:2\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(t.lo[0]), "=&v"(t.hi[0]), "=&v"(t.lo[1]), "=&v"(t.hi[1]), "=&v"(t.lo[2]), "=&v"(t.hi[2]),
+                   "=&v"(t.lo[3]), "=&v"(t.hi[3]), "=&v"(t.lo[4]), "=&v"(t.hi[4]), "=&v"(t.lo[5]), "=&v"(t.hi[5])
+                 : "v"(a00), "v"(a01), "v"(a10), "v"(a11) : "memory");
+}
+
 // (two pixels' loads in flight at a time: 24 registers; a software pipeline with counted lgkmcnt waits measured the same)
 template <int PITCH = LDS_PITCH>
 __device__ __forceinline__ uint3 gather_blend_staged(const uint32_t (&bx)[4], const uint32_t (&by)[4], uint32_t lds_origin)
@@ -951,6 +968,27 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
                 const bool in_x0 = (unsigned)ix < (unsigned)W, in_x1 = (unsigned)(ix + 1) < (unsigned)W;
                 const bool in_y0 = (unsigned)iy < (unsigned)H, in_y1 = (unsigned)(iy + 1) < (unsigned)H;
                 const uint32_t cx0 = (uint32_t)min(max(ix, 0), W - 1), cx1 = (uint32_t)min(max(ix + 1, 0), W - 1);
+                if (staged) {
+                    // STAGED: the window holds every tap position CLAMPED into the frame (cell_table.hip), so the four taps are LDS
+                    // byte loads (a pixel without owner sits at (W+1, H+1): its clamped position may lie outside the window --
+                    // whatever the load returns is replaced by the border colour below).  (Unaligned 4-byte LDS loads instead:
+                    // +2 % kernel time; two pixels' loads in flight: register spills.)
+                    const uint32_t ra = umad24((uint32_t)min(max(iy, 0), H - 1), (uint32_t)LDS_PITCH, 0u - lds_origin);
+                    const uint32_t rb = umad24((uint32_t)min(max(iy + 1, 0), H - 1), (uint32_t)LDS_PITCH, 0u - lds_origin);
+                    TapRegs t;
+                    taps_clamped(umad24(cx0, 3u, ra), umad24(cx1, 3u, ra), umad24(cx0, 3u, rb), umad24(cx1, 3u, rb), t);
+                    const bool i00 = in_x0 && in_y0, i01 = in_x1 && in_y0, i10 = in_x0 && in_y1, i11 = in_x1 && in_y1;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const uint32_t bc = (border >> (8 * c)) & 0xFFu;
+                        t.lo[c] = i00 ? t.lo[c] : bc;
+                        t.hi[c] = i01 ? t.hi[c] : bc << 16;
+                        t.lo[3 + c] = i10 ? t.lo[3 + c] : bc;
+                        t.hi[3 + c] = i11 ? t.hi[3 + c] : bc << 16;
+                    }
+                    blend_pixel((uint32_t)sxx, (uint32_t)syy, t, oB[j], oG[j], oR[j]);
+                    continue;
+                }
                 const uint32_t r0 = (uint32_t)min(max(iy, 0), H - 1) * (uint32_t)W, r1 = (uint32_t)min(max(iy + 1, 0), H - 1) * (uint32_t)W;
                 const uint32_t o00 = (r0 + cx0) * 3u, o01 = (r0 + cx1) * 3u, o10 = (r1 + cx0) * 3u, o11 = (r1 + cx1) * 3u;
                 uint32_t p00, p01, p10, p11;                 // B | G << 8 | R << 16 | (next byte) << 24

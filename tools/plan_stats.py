@@ -49,3 +49,7 @@ pairhot = (ne == 2) & ((plan[:, 2] & 0x6000) == 0x2000)          # MF_PLAN_HOT i
 print(f'plan-certified pair path {pairhot.mean():.4f}')
 hot = (plan[:, 1] & 0x6000) == 0x2000                          # MF_PLAN_HOT without VALID: the warp kernel's straight-line path
 print(f'staged {((regions >> 31) & 1).mean():.4f}  certified interior {((regions >> 30) & 1).mean():.4f}  hot (single + unit + deep + whole) {hot.mean():.4f}')
+regs = buf[reg_off:reg_off + npl * 8].view(np.uint32)[0::2]
+print(f'regions: compact {((regs >> 29) & 1).mean():.4f}  staged but not deep {(((regs >> 31) & 1) & ~((regs >> 30) & 1)).mean():.4f}  unstaged {1 - ((regs >> 31) & 1).mean():.4f}')
+fast64 = (plan[:, 1] & 0x6002) == 0x2002
+print(f'hot with the fast64 certificate {fast64.mean():.4f}')
