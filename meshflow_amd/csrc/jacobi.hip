@@ -13,26 +13,33 @@
 // OMEGA = 10, 10 at OMEGA = 30); clips longer than 64 K frames spread each series over 2-8 wavefronts.
 #include <stdlib.h>
 
-#include "mf_common.h"
+#include "jacobi_kernels.h"
 
 namespace mf {
 
-template <int OMEGA, int K, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* __restrict__ b, double* __restrict__ x_out,
-                                                         const double* __restrict__ taps,
-                                                         const double* __restrict__ lam,
-                                                         const double* __restrict__ inv_on, int F, int S, int iters)
+// Any other radius (mfs.py:46 accepts every temporal_smoothing_radius): the same mapping with the radius at RUN time.  A thread
+// still owns K consecutive frames and all K accumulators, but instead of holding its whole K + 2 omega window in registers it
+// slides a K-entry window over it: tap d multiplies the window, then the entry that tap d+1 no longer needs is replaced by the
+// next one from LDS (one ds_read_b64 per tap; unrolled by K, so the rotation is a renaming).  The taps are wave-uniform scalar
+// loads, K at a time (constant address space).  Every output sums its taps in ascending order from zero, exactly like the
+// specialised kernel and the CPU oracle -- identical bits.  K is odd: a lane stride of K doubles keeps the 64-bit LDS reads
+// free of bank conflicts.  ~40 VGPRs whatever the radius.
+typedef const __attribute__((address_space(4))) double* ctap_t;
+
+template <int K, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void jacobi_runtime_kernel(const double* __restrict__ b, double* __restrict__ x_out,
+                                                                    const double* __restrict__ taps_g, const double* __restrict__ lam,
+                                                                    const double* __restrict__ inv_on, int F, int S, int omega, int iters)
 {
-    constexpr int NT = 2 * OMEGA + 1;
+    extern __shared__ double dyn[];
     constexpr int NTHR = 64 * WAVES;
-    constexpr int LEN = NTHR * K + 2 * OMEGA;
-    __shared__ double xs[2][LEN];
+    const int NT = 2 * omega + 1;
+    const int LEN = NTHR * K + 2 * omega + K;      // + K: the sliding window runs K - 1 entries past the last tap's reach
+    double* xs0 = dyn;
+    double* xs1 = dyn + LEN;
+    const ctap_t taps = (ctap_t)(uintptr_t)taps_g;
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
-
-    double w[NT];
-#pragma unroll
-    for (int d = 0; d < NT; ++d) w[d] = taps[d];
 
     double bt[K], two_lam[K], inv[K];
 #pragma unroll
@@ -43,32 +50,51 @@ __global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* _
         two_lam[k] = in ? 2.0 * lam[t] : 0.0;
         inv[k] = in ? inv_on[t] : 0.0;            // frames past the end stay exactly 0 = the zero halo
     }
-    for (int i = lane; i < LEN; i += NTHR) { xs[0][i] = 0.0; xs[1][i] = 0.0; }
+    for (int i = lane; i < LEN; i += NTHR) { xs0[i] = 0.0; xs1[i] = 0.0; }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; ++k) xs[0][OMEGA + lane * K + k] = bt[k];   // x_start = b
+    for (int k = 0; k < K; ++k) xs0[omega + lane * K + k] = bt[k];   // x_start = b
     __syncthreads();
 
-    int cur = 0;
+    double* cur = xs0;
+    double* nxt = xs1;
     double xn[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) xn[k] = bt[k];
     for (int it = 0; it < iters; ++it) {
-        double win[K + 2 * OMEGA];
-        const double* src = &xs[cur][lane * K];
+        const double* src = cur + lane * K;        // src[j] = x[frame lane K + j - omega]
+        double r[K], acc[K];
 #pragma unroll
-        for (int j = 0; j < K + 2 * OMEGA; ++j) win[j] = src[j];
+        for (int k = 0; k < K; ++k) { r[k] = src[k]; acc[k] = 0.0; }
+        // K taps per scalar load.  (Measured and rejected: fetching the next K under this block's FMAs, +20 %; all taps of a small
+        // radius loaded once and kept in scalar registers for every sweep, +10-30 % -- scalar-register spills; taps spread over the
+        // lanes of a register and fetched by v_readlane, 2x.)
+        int d = 0;
+        for (; d + K <= NT; d += K) {
+            double w[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) w[j] = taps[d + j];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[k] = __builtin_fma(w[j], r[(j + k) % K], acc[k]);
+                r[j] = src[d + j + K];             // slot j held x[.. + d + j]: tap d + j + 1 starts one entry later
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j)                // the last NT - d < K taps (wave-uniform tests)
+            if (d + j < NT) {
+                const double w = taps[d + j];
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[k] = __builtin_fma(w, r[(j + k) % K], acc[k]);
+                r[j] = src[d + j + K];
+            }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            double acc = 0.0;
-#pragma unroll
-            for (int d = 0; d < NT; ++d) acc = __builtin_fma(w[d], win[k + d], acc);
-            xn[k] = inv[k] * __builtin_fma(two_lam[k], acc, bt[k]);
+            xn[k] = inv[k] * __builtin_fma(two_lam[k], acc[k], bt[k]);
+            nxt[omega + lane * K + k] = xn[k];
         }
-        double* dst = &xs[cur ^ 1][OMEGA + lane * K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) dst[k] = xn[k];
-        cur ^= 1;
+        double* tmp = cur; cur = nxt; nxt = tmp;
         __syncthreads();
     }
 #pragma unroll
@@ -78,7 +104,20 @@ __global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* _
     }
 }
 
-// Fallback for any other (omega, F) -- specialised radii: 5, 10, 15, 20, 30 -- one 256-thread workgroup per series,
+template <int K, int WAVES>
+static int launch_runtime(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
+                          int F, int S, int omega, int iters, hipStream_t st)
+{
+    const size_t lds = (size_t)2 * (64 * WAVES * K + 2 * omega + K) * sizeof(double);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)jacobi_runtime_kernel<K, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(jacobi_runtime_kernel)");
+    }
+    hipLaunchKernelGGL((jacobi_runtime_kernel<K, WAVES>), dim3(S), dim3(64 * WAVES), lds, st, b, x, taps, lam, inv_on, F, S, omega, iters);
+    return hip_fail(hipGetLastError(), "jacobi_runtime_kernel launch");
+}
+
+// Last resort (a clip too long for the kernels above) -- one 256-thread workgroup per series,
 // thread-per-frame loop over LDS.  Same summation order as the specialised kernel, so both give identical bits, at a tenth of
 // the speed (F = 300, 16 x 16 mesh, 100 sweeps: omega = 40: 693 us = 4.1 TFLOP/s against 48 us = 16 TFLOP/s for omega = 10).
 __global__ __launch_bounds__(256) void jacobi_generic_kernel(const double* __restrict__ b, double* __restrict__ x_out,
@@ -112,15 +151,6 @@ __global__ __launch_bounds__(256) void jacobi_generic_kernel(const double* __res
     for (int t = threadIdx.x; t < F; t += blockDim.x) x_out[(size_t)t * S + s] = cur[omega + t];
 }
 
-template <int OMEGA, int K, int WAVES>
-static int launch_wave(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
-                       int F, int S, int iters, hipStream_t st)
-{
-    hipLaunchKernelGGL((jacobi_wave_kernel<OMEGA, K, WAVES>), dim3(S), dim3(64 * WAVES), 0, st, b, x, taps, lam, inv_on, F, S,
-                       iters);
-    return hip_fail(hipGetLastError(), "jacobi_wave_kernel launch");
-}
-
 int launch_jacobi(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
                   int F, int S, int omega, int iters, hipStream_t st)
 {
@@ -130,47 +160,44 @@ int launch_jacobi(const double* b, double* x, const double* taps, const double* 
     }
     // the fewest frames per thread that covers the clip: a long clip spreads each series over up to 8 wavefronts
     // (measured faster than more frames per lane even when there are more series than SIMDs: tools/time_jacobi.py)
-#define MF_JACOBI(O, K, WV) return launch_wave<O, K, WV>(b, x, taps, lam, inv_on, F, S, iters, st)
     // Far fewer series than SIMDs (1024): one wavefront per series leaves most SIMDs idle -- split each series over more
     // wavefronts with fewer frames per lane.  Measured (F = 300, 100 sweeps): 162 series (8 x 8 mesh) 40.7 us with one wavefront
     // per series, 31.8 with two, 30.4 with four; 578 series (16 x 16) 48.1 / 49.1 / 50.4 -- there the workgroup barrier of
     // a split series costs what the shorter per-lane loop saves, so the split starts below 512 series.
     static const int split = [] { const char* v = getenv("MF_JACOBI_SPLIT"); return v && *v ? atoi(v) : -1; }();   // tuning aid
     const int want = split > 0 ? split : (S < 256 ? 4 : S < 512 ? 2 : 1);
-    if (omega == 10 && want > 1) {
-        if (F <= 256 * 2 && want >= 4) MF_JACOBI(10, 2, 4);
-        if (F <= 128 * 3) MF_JACOBI(10, 3, 2);
+    static const bool force_runtime = [] { const char* v = getenv("MF_JACOBI_RUNTIME"); return v && *v == '1'; }();   // tuning aid
+    if (force_runtime) omega = -omega;                  // (skips the specialised radii below)
+    // Radii 1..32 have kernels specialised ahead of time (jacobi_spec.hip: the radius, the frames per thread and the wavefronts
+    // per series are compile-time constants -- whole window in registers, taps in scalar registers for all sweeps)
+    if (omega >= 1 && omega <= 32) {
+        int rc = MF_JACOBI_NOT_HERE;
+        switch ((omega - 1) / 8) {
+        case 0: rc = launch_jacobi_spec_g0(b, x, taps, lam, inv_on, F, S, omega, iters, want, st); break;
+        case 1: rc = launch_jacobi_spec_g1(b, x, taps, lam, inv_on, F, S, omega, iters, want, st); break;
+        case 2: rc = launch_jacobi_spec_g2(b, x, taps, lam, inv_on, F, S, omega, iters, want, st); break;
+        default: rc = launch_jacobi_spec_g3(b, x, taps, lam, inv_on, F, S, omega, iters, want, st); break;
+        }
+        if (rc != MF_JACOBI_NOT_HERE) return rc;
     }
-    if (omega == 10) {
-        if (F <= 64 * 5) MF_JACOBI(10, 5, 1);
-        if (F <= 128 * 5) MF_JACOBI(10, 5, 2);
-        if (F <= 256 * 5) MF_JACOBI(10, 5, 4);
-        if (F <= 512 * 5) MF_JACOBI(10, 5, 8);
-        if (F <= 512 * 10) MF_JACOBI(10, 10, 8);
-        if (F <= 512 * 19) MF_JACOBI(10, 19, 8);
-    } else if (omega == 5) {
-        if (F <= 64 * 5) MF_JACOBI(5, 5, 1);
-        if (F <= 128 * 5) MF_JACOBI(5, 5, 2);
-        if (F <= 256 * 5) MF_JACOBI(5, 5, 4);
-        if (F <= 512 * 5) MF_JACOBI(5, 5, 8);
-    } else if (omega == 15) {
-        if (F <= 64 * 8) MF_JACOBI(15, 8, 1);
-        if (F <= 128 * 8) MF_JACOBI(15, 8, 2);
-        if (F <= 256 * 8) MF_JACOBI(15, 8, 4);
-        if (F <= 512 * 8) MF_JACOBI(15, 8, 8);
-    } else if (omega == 20) {
-        if (F <= 64 * 8) MF_JACOBI(20, 8, 1);
-        if (F <= 128 * 8) MF_JACOBI(20, 8, 2);
-        if (F <= 256 * 8) MF_JACOBI(20, 8, 4);
-        if (F <= 512 * 8) MF_JACOBI(20, 8, 8);
-    } else if (omega == 30) {
-        if (F <= 64 * 10) MF_JACOBI(30, 10, 1);
-        if (F <= 128 * 10) MF_JACOBI(30, 10, 2);
-        if (F <= 256 * 10) MF_JACOBI(30, 10, 4);
-        if (F <= 512 * 10) MF_JACOBI(30, 10, 8);
-        if (F <= 512 * 19) MF_JACOBI(30, 19, 8);
+    // every other radius: the run-time-radius kernel.  Frames per thread K in {3, 5, 7} (19 for clips beyond 3584 frames), wavefronts per
+    // series = what covers the clip.  These sweeps are latency-bound (a sweep is one dependent pass per wavefront), so the fewest
+    // frames per thread win as long as the series' wavefronts still fit the chip about twice over (1024 SIMDs).
+    if (omega < 0) omega = -omega;
+    {
+        const auto waves_for = [&](int k) { int wv = 1; while (wv < 8 && F > 64 * wv * k) wv *= 2; return wv; };
+        const auto fits = [&](int k, int wv) { return F <= 64 * wv * k && (size_t)2 * (64 * wv * k + 2 * omega + k) * sizeof(double) <= 160 * 1024; };
+#define MF_JACOBI_RT(K, WV) if (wv == WV) return launch_runtime<K, WV>(b, x, taps, lam, inv_on, F, S, omega, iters, st)
+#define MF_JACOBI_RT_K(K) { MF_JACOBI_RT(K, 1); MF_JACOBI_RT(K, 2); MF_JACOBI_RT(K, 4); MF_JACOBI_RT(K, 8); }
+        for (const int k : { 3, 5, 7 }) {
+            const int wv = waves_for(k);
+            if (!fits(k, wv) || (k != 7 && (long long)S * wv > 2048)) continue;
+            if (k == 3) MF_JACOBI_RT_K(3) else if (k == 5) MF_JACOBI_RT_K(5) else MF_JACOBI_RT_K(7)
+        }
+        if (fits(19, 8)) return launch_runtime<19, 8>(b, x, taps, lam, inv_on, F, S, omega, iters, st);
+#undef MF_JACOBI_RT_K
+#undef MF_JACOBI_RT
     }
-#undef MF_JACOBI
     const size_t lds = ((size_t)2 * (F + 2 * omega) + 2 * omega + 1) * sizeof(double);
     if (lds > 160 * 1024) {
         set_error("mf_jacobi_f64: F=%d omega=%d needs %zu bytes of LDS (> 160 KiB)", F, omega, lds);

@@ -1,0 +1,58 @@
+// Ahead-of-time table of the specialised Jacobi kernels (jacobi_kernels.h): compiled once per group of eight radii
+// (-DMF_JACOBI_GROUP=g: radii 8 g + 1 .. 8 g + 8), so that the groups build in parallel.  Per radius: the fewest frames per thread K
+// that keeps the window in registers (5 up to omega = 12, 8 up to 20, 10 beyond) x 1 / 2 / 4 / 8 wavefronts per series, i.e. clips of up
+// to 512 K frames; omega = 10 and 30 (BASELINE configs 2-4) also have the long-clip variants (K = 10, 19).  Longer clips and larger
+// radii take jacobi.hip's run-time-radius kernel.
+#include "jacobi_kernels.h"
+
+#ifndef MF_JACOBI_GROUP
+#error "compile with -DMF_JACOBI_GROUP=0..3"
+#endif
+
+namespace mf {
+
+#define MF_CAT2(a, b) a##b
+#define MF_CAT(a, b) MF_CAT2(a, b)
+
+namespace {
+
+template <int OMEGA>
+int launch_radius(const double* b, double* x, const double* taps, const double* lam, const double* inv_on, int F, int S, int iters, int want, hipStream_t st)
+{
+    constexpr int K = OMEGA <= 12 ? 5 : OMEGA <= 20 ? 8 : 10;
+#define MF_JACOBI(O, KK, WV) return launch_wave<O, KK, WV>(b, x, taps, lam, inv_on, F, S, iters, st)
+    // Far fewer series than SIMDs (1024): one wavefront per series leaves most SIMDs idle -- split each series over more
+    // wavefronts with fewer frames per lane (measured at omega = 10, F = 300, 100 sweeps: 162 series 40.7 us with one wavefront
+    // per series, 31.8 with two, 30.4 with four; 578 series 48.1 / 49.1 / 50.4: the split starts below 512 series)
+    if (OMEGA == 10 && want > 1) {
+        if (F <= 256 * 2 && want >= 4) MF_JACOBI(10, 2, 4);
+        if (F <= 128 * 3) MF_JACOBI(10, 3, 2);
+    }
+    if (F <= 64 * K) MF_JACOBI(OMEGA, K, 1);
+    if (F <= 128 * K) MF_JACOBI(OMEGA, K, 2);
+    if (F <= 256 * K) MF_JACOBI(OMEGA, K, 4);
+    if (F <= 512 * K) MF_JACOBI(OMEGA, K, 8);
+    if (OMEGA == 10) {
+        if (F <= 512 * 10) MF_JACOBI(10, 10, 8);
+        if (F <= 512 * 19) MF_JACOBI(10, 19, 8);
+    }
+    if (OMEGA == 30 && F <= 512 * 19) MF_JACOBI(30, 19, 8);
+#undef MF_JACOBI
+    return MF_JACOBI_NOT_HERE;
+}
+
+}  // namespace
+
+int MF_CAT(launch_jacobi_spec_g, MF_JACOBI_GROUP)(const double* b, double* x, const double* taps, const double* lam, const double* inv_on, int F, int S,
+                                                  int omega, int iters, int want, hipStream_t st)
+{
+    constexpr int O0 = 8 * MF_JACOBI_GROUP;
+    switch (omega - O0) {
+#define MF_CASE(i) case i: return launch_radius<O0 + i>(b, x, taps, lam, inv_on, F, S, iters, want, st);
+    MF_CASE(1) MF_CASE(2) MF_CASE(3) MF_CASE(4) MF_CASE(5) MF_CASE(6) MF_CASE(7) MF_CASE(8)
+#undef MF_CASE
+    default: return MF_JACOBI_NOT_HERE;
+    }
+}
+
+}  // namespace mf

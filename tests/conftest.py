@@ -17,7 +17,7 @@ def _ensure_built():
     import subprocess
     lib = os.path.join(REPO, 'meshflow_amd', 'libmeshflow_hip.so')
     if not os.path.exists(lib):
-        subprocess.run(['make', '-C', os.path.join(REPO, 'meshflow_amd', 'csrc')], check=True)
+        subprocess.run(['make', '-j8', '-C', os.path.join(REPO, 'meshflow_amd', 'csrc')], check=True)
     if not os.path.exists(os.path.join(REPO, 'oracle', '_build', 'liboracle.so')):
         subprocess.run(['make', '-C', os.path.join(REPO, 'oracle')], check=True)
 

@@ -87,7 +87,12 @@ def test_jacobi_config_sized_vs_reference_golden(dev, golden_dir, name):
     (320, 6, 10, 7), (321, 6, 10, 7), (640, 4, 10, 5), (1200, 4, 10, 20), (2400, 2, 10, 10),
     (600, 10, 30, 20), (1216, 2, 30, 5), (2432, 2, 30, 3),
     (1, 3, 10, 4), (2, 3, 10, 4), (11, 5, 10, 30),
-    (50, 7, 5, 13), (17, 3, 1, 9), (3000, 2, 10, 3), (700, 3, 40, 6),   # generic kernel
+    (50, 7, 5, 13), (3000, 2, 10, 3),
+    # radii without a specialised kernel: the run-time-radius kernel (1 / 2 / 4 / 8 wavefronts per series, 3 / 5 / 7 / 19 frames per
+    # lane, tap counts that are and are not multiples of the window length) ...
+    (17, 3, 1, 9), (300, 578, 7, 20), (300, 100, 12, 20), (300, 600, 25, 10), (700, 3, 40, 6), (448, 600, 3, 8), (449, 600, 3, 8),
+    (900, 40, 12, 6), (1800, 30, 7, 5), (3584, 3, 17, 3), (3585, 3, 17, 3), (9000, 2, 9, 2), (300, 20, 64, 5), (64, 5, 100, 4),
+    (10000, 2, 7, 2),                                                    # ... and the last resort beyond its LDS
 ])
 def test_jacobi_bit_exact_vs_c_oracle(dev, F, S, omega, iters):
     from meshflow_amd import synthetic
@@ -101,6 +106,22 @@ def test_jacobi_bit_exact_vs_c_oracle(dev, F, S, omega, iters):
     want = clib.jacobi_banded(b, taps, lam, inv_on, omega, iters)
     got = _hip_jacobi(dev, b, taps, lam, inv_on, omega, iters)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize('omega', list(range(1, 34)) + [40, 47])
+def test_jacobi_every_radius_bit_exact_vs_c_oracle(dev, omega):
+    """mfs.py:46 accepts any temporal_smoothing_radius: radii 1..32 have kernels specialised ahead of time (csrc/jacobi_spec.hip),
+    larger ones the run-time-radius kernel; short and long clips, one and several wavefronts per series -- all bit-identical."""
+    from meshflow_amd import synthetic
+    from oracle import clib
+    for F, S, iters in ((300, 40, 12), (37, 9, 5), (1500, 3, 3)):
+        b = np.cumsum(2.0 * synthetic.normal(np.arange(F * S).reshape(F, S), seed=omega + F), axis=0)
+        taps = np.exp(-np.square((3 / omega) * np.arange(-omega, omega + 1)))
+        lam = 0.1 + 0.85 * synthetic.uniform01(np.arange(F), seed=omega)
+        inv_on = 1.0 / (1 + 2 * lam * taps.sum())
+        want = clib.jacobi_banded(b, taps, lam, inv_on, omega, iters, openmp=True)
+        got = _hip_jacobi(dev, b, taps, lam, inv_on, omega, iters)
+        assert np.array_equal(got, want), (omega, F, S)
 
 
 def test_jacobi_full_cfg3_properties(dev):

@@ -28,5 +28,9 @@ for split in ('1', '2', '4'):
     subprocess.run([sys.executable, __file__, 'child', '300,16,16,10,100', '240,16,16,10,100', '300,8,8,10,100'], env=dict(os.environ, MF_JACOBI_SPLIT=split))
 print('default selection', flush=True)
 subprocess.run([sys.executable, __file__, 'child', '300,16,16,10,100', '300,32,32,10,100', '2400,16,16,10,100', '600,32,32,30,200'])
-print('radii without a specialised kernel (generic kernel)', flush=True)
-subprocess.run([sys.executable, __file__, 'child', '300,16,16,5,100', '300,16,16,15,100', '300,16,16,20,100', '600,32,32,20,100', '300,16,16,40,100'])
+print('other radii: specialised ahead of time up to 32, the run-time-radius kernel beyond', flush=True)
+subprocess.run([sys.executable, __file__, 'child', '300,16,16,7,100', '300,16,16,12,100', '300,16,16,25,100', '300,16,16,40,100', '600,32,32,25,200', '2400,16,16,12,100', '300,16,16,64,100'])
+print('specialised radii through the run-time-radius kernel (MF_JACOBI_RUNTIME=1)', flush=True)
+subprocess.run([sys.executable, __file__, 'child', '300,16,16,10,100', '300,16,16,5,100', '300,16,16,20,100', '600,32,32,30,200', '2400,16,16,10,100'], env=dict(os.environ, MF_JACOBI_RUNTIME='1'))
+print('... and through their own kernels', flush=True)
+subprocess.run([sys.executable, __file__, 'child', '300,16,16,10,100', '300,16,16,5,100', '300,16,16,20,100', '600,32,32,30,200', '2400,16,16,10,100'])
