@@ -82,52 +82,120 @@ __device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b)
     return (uint32_t)(((unsigned long long)(a & 0xFFFFFFu) * (unsigned long long)(b & 0xFFFFFFu)) >> 32);
 }
 
-constexpr int kRows = 2;              // output rows per wavefront (amortises the scalar set-up and the column table); 1: +8 %, 4: +4 %
-constexpr int kWaves = 4;             // wavefronts per workgroup (they never cooperate; 1, 2 and 4 measure the same)
+constexpr int kRows = 8;              // output rows per wavefront
+constexpr int kWaves = 4;             // wavefronts per workgroup (they never cooperate)
+constexpr int kSrcRows = kRows + 1;   // source rows a wavefront stages: _crop_frames only ever scales UP (the crop lies inside the frame), so
+                                      // consecutive output rows advance by at most one source row
 
+// The horizontal pass of ONE staged source row for the lane's four pixels: t = S[sx] a0 + S[sx+1] a1 per channel (v_dot2_u32_u16 with
+// the weights pre-scaled by 16: T = 16 t < 2^24), returned as T & ~255 = 256 (t >> 4), what the vertical pass multiplies.  The taps
+// are byte loads with immediate offsets: ds_read_u8 puts S[sx] into the low byte of one register, ds_read_u8_d16_hi S[sx+1] into
+// bits 16-23 of another (with SRAM ECC a d16 load zeroes the other half of its destination: check_d16_zero_fill), one v_or_b32 joins
+// them.  All 24 loads and their wait sit in ONE asm block: nothing can be scheduled between issue and wait.
+__device__ __forceinline__ void hpass_row(const uint32_t (&at)[4], const uint32_t (&w)[4], uint32_t (&T)[4][3])
+{
+    uint32_t lo[4][3], hi[4][3];
+    asm volatile("ds_read_u8 %0, %24 offset:0\n\tds_read_u8_d16_hi %1, %24 offset:3\n\t"
+                 "ds_read_u8 %2, %24 offset:1\n\tds_read_u8_d16_hi %3, %24 offset:4\n\t"
+                 "ds_read_u8 %4, %24 offset:2\n\tds_read_u8_d16_hi %5, %24 offset:5\n\t"
+                 "ds_read_u8 %6, %25 offset:0\n\tds_read_u8_d16_hi %7, %25 offset:3\n\t"
+                 "ds_read_u8 %8, %25 offset:1\n\tds_read_u8_d16_hi %9, %25 offset:4\n\t"
+                 "ds_read_u8 %10, %25 offset:2\n\tds_read_u8_d16_hi %11, %25 offset:5\n\t"
+                 "ds_read_u8 %12, %26 offset:0\n\tds_read_u8_d16_hi %13, %26 offset:3\n\t"
+                 "ds_read_u8 %14, %26 offset:1\n\tds_read_u8_d16_hi %15, %26 offset:4\n\t"
+                 "ds_read_u8 %16, %26 offset:2\n\tds_read_u8_d16_hi %17, %26 offset:5\n\t"
+                 "ds_read_u8 %18, %27 offset:0\n\tds_read_u8_d16_hi %19, %27 offset:3\n\t"
+                 "ds_read_u8 %20, %27 offset:1\n\tds_read_u8_d16_hi %21, %27 offset:4\n\t"
+                 "ds_read_u8 %22, %27 offset:2\n\tds_read_u8_d16_hi %23, %27 offset:5\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(lo[0][0]), "=&v"(hi[0][0]), "=&v"(lo[0][1]), "=&v"(hi[0][1]), "=&v"(lo[0][2]), "=&v"(hi[0][2]),
+                   "=&v"(lo[1][0]), "=&v"(hi[1][0]), "=&v"(lo[1][1]), "=&v"(hi[1][1]), "=&v"(lo[1][2]), "=&v"(hi[1][2]),
+                   "=&v"(lo[2][0]), "=&v"(hi[2][0]), "=&v"(lo[2][1]), "=&v"(hi[2][1]), "=&v"(lo[2][2]), "=&v"(hi[2][2]),
+                   "=&v"(lo[3][0]), "=&v"(hi[3][0]), "=&v"(lo[3][1]), "=&v"(hi[3][1]), "=&v"(lo[3][2]), "=&v"(hi[3][2])
+                 : "v"(at[0]), "v"(at[1]), "v"(at[2]), "v"(at[3]) : "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) T[j][c] = udot2(lo[j][c] | hi[j][c], w[j], 0u) & ~255u;
+}
+
+// The vertical pass + store of one output row: out = (((b0 (t0 >> 4)) >> 16) + ((b1 (t1 >> 4)) >> 16) + 2) >> 2, each product's
+// high half by one v_mul_hi_u32_u24 of (256 b) and (256 (t >> 4)).  No saturation needed: each weight pair sums to 2048 +- 1 (two
+// cvRound of complementary fractions), so t <= 255 * 2049, t >> 4 <= 32655 and the two high halves sum to at most
+// 2049 * 32655 / 65536 < 1021, i.e. (sum + 2) >> 2 <= 255 -- cv2's saturate_cast never triggers either.
+__device__ __forceinline__ void vpass_store(const uint32_t (&T0)[4][3], const uint32_t (&T1)[4][3], uint32_t b0s, uint32_t b1s,
+                                            uint8_t* __restrict__ dst, uint32_t o, int x0, int W)
+{
+    uint32_t px[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t vB = (mulhi_u24(b0s, T0[j][0]) + mulhi_u24(b1s, T1[j][0]) + 2u) >> 2;
+        const uint32_t vG = (mulhi_u24(b0s, T0[j][1]) + mulhi_u24(b1s, T1[j][1]) + 2u) >> 2;
+        const uint32_t vR = (mulhi_u24(b0s, T0[j][2]) + mulhi_u24(b1s, T1[j][2]) + 2u) >> 2;
+        px[j] = vB | (vG << 8) | (vR << 16);
+    }
+    if ((W & 3) == 0 && x0 + 3 < W) {
+        uint3 d;
+        d.x = px[0] | (px[1] << 24);
+        d.y = (px[1] >> 8) | (px[2] << 16);
+        d.z = (px[2] >> 16) | (px[3] << 8);
+        *reinterpret_cast<uint3*>(dst + o) = d;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x0 + j < W) {
+                dst[o + 3 * j + 0] = (uint8_t)(px[j]);
+                dst[o + 3 * j + 1] = (uint8_t)(px[j] >> 8);
+                dst[o + 3 * j + 2] = (uint8_t)(px[j] >> 16);
+            }
+    }
+}
+
+// Workgroup = kWaves wavefronts; wavefront = kRows consecutive output rows x 256 pixels; lane = 4 consecutive pixels per row (one
+// 12-byte store each).  The source rows of an output row are shared by all its pixels, and -- the crop only ever scales UP -- by the
+// NEXT output row too: the kRows output rows of a wavefront read at most kRows + 1 source rows.  The wavefront copies the span it
+// needs of each (<= 800 bytes, from the dword holding the first tap) into LDS with ONE global->LDS 16-byte load per row, runs the
+// horizontal pass once per SOURCE row (the result of an output row's second source row is the next output row's first) and the
+// vertical pass per output row: (kRows + 1) / kRows horizontal passes per output row instead of 2, 9 window copies per 8 rows
+// instead of 16.  Anything that cannot be staged (a frame narrower than a chunk, the last rows of the stack, a call that scales down)
+// takes the direct path below, row by row.
 __global__ __launch_bounds__(64 * kWaves) void resize_kernel(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out, int n,
                                                      int W, int H, int left, int top, int cw,
                                                      const ResizeTab* __restrict__ xtab,
                                                      const ResizeTab* __restrict__ ytab, TileOrder order)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_rows[kWaves][kRows][2 * kRowPitch + 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_rows[kWaves][kSrcRows][kRowPitch + 16];
     int f, tile_y, tile_x;
     if (!order.decode(blockIdx.x, f, tile_y, tile_x)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ya = (tile_y * kWaves + wave) * kRows;
     const int xw = tile_x * 256, x0 = xw + lane * 4;
     if (ya >= H) return;
+    const int rows = min(kRows, H - ya);
     const size_t frame_bytes = (size_t)W * H * 3;
     const uint8_t* __restrict__ src = frames + (size_t)f * frame_bytes;
     uint8_t* __restrict__ dst = out + (size_t)f * frame_bytes;
     const size_t limit = (size_t)(n - f) * frame_bytes;
     const size_t base = (size_t)(uintptr_t)src;
 
-    // span of source columns this wavefront touches: taps sx .. sx+1 for its first .. last pixel (the tables are
-    // monotone); a row is staged when the span fits the LDS row and the 16-byte chunks stay inside the frame stack
+    // span of source columns this wavefront touches: taps sx .. sx+1 for its first .. last pixel (the tables are monotone), and of
+    // source rows: sy0 of its first .. sy1 of its last output row
     const uint32_t sx_first = (uint32_t)xtab[xw].ofs, sx_last = (uint32_t)xtab[min(xw + 255, W - 1)].ofs;
     const uint32_t span = 3u * (sx_last + 2u - sx_first);
-    uint32_t row0[kRows], row1[kRows], b0s[kRows], b1s[kRows], s0[kRows], s1[kRows];
-    bool staged[kRows];
-#pragma unroll
-    for (int q = 0; q < kRows; ++q) {
-        const ResizeTab yt = ytab[min(ya + q, H - 1)];
-        b0s[q] = (yt.w & 0xFFFFu) << 8;
-        b1s[q] = (yt.w >> 16) << 8;
-        row0[q] = (uint32_t)(top + (yt.ofs & 0xFFFF)) * (uint32_t)W + (uint32_t)left;
-        row1[q] = (uint32_t)(top + (yt.ofs >> 16)) * (uint32_t)W + (uint32_t)left;
-        const size_t g0 = (size_t)(row0[q] + sx_first) * 3u, g1 = (size_t)(row1[q] + sx_first) * 3u;     // byte offsets in the frame
-        s0[q] = (uint32_t)((base + g0) & 3u);                                                          // misalignment of each row
-        s1[q] = (uint32_t)((base + g1) & 3u);
-        staged[q] = ya + q < H && span + 3u + 12u <= (uint32_t)kRowPitch && g0 >= 3u && g1 >= 3u &&
-                    (g0 > g1 ? g0 : g1) - 3u + (size_t)kRowPitch <= limit;
-        if (staged[q] && lane < kRowPitch / 16) {
-            uint32_t o = (uint32_t)lane << 4;
-            asm("" : "+v"(o));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (g0 - s0[q]) + o),
-                                             (__attribute__((address_space(3))) void*)&s_rows[wave][q][0], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (g1 - s1[q]) + o),
-                                             (__attribute__((address_space(3))) void*)&s_rows[wave][q][kRowPitch], 16, 0, 0);
+    const int r_first = ytab[ya].ofs & 0xFFFF, r_last = ytab[ya + rows - 1].ofs >> 16;
+    const int nsrc = r_last - r_first + 1;
+    // byte offset in the frame of the first tap of source row i: g(i) = ((top + r_first + i) W + left + sx_first) 3
+    const size_t g_first = ((size_t)(top + r_first) * (size_t)W + (size_t)left + sx_first) * 3u;
+    const size_t g_last = g_first + (size_t)(nsrc - 1) * (size_t)W * 3u;
+    const bool staged = nsrc <= kSrcRows && span + 3u + 12u <= (uint32_t)kRowPitch && g_first >= 3u && g_last - 3u + (size_t)kRowPitch <= limit;
+    if (staged && lane < kRowPitch / 16) {
+        uint32_t o = (uint32_t)lane << 4;
+        asm("" : "+v"(o));
+#pragma unroll 1
+        for (int i = 0; i < nsrc; ++i) {
+            const size_t g = g_first + (size_t)i * (size_t)W * 3u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (g - ((base + g) & 3u)) + o),
+                                             (__attribute__((address_space(3))) void*)&s_rows[wave][i][0], 16, 0, 0);
         }
     }
     ResizeTab xt[4];
@@ -138,112 +206,86 @@ __global__ __launch_bounds__(64 * kWaves) void resize_kernel(const uint8_t* __re
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // staged rows (and the column table) have landed
     if (x0 >= W) return;
 
+    if (staged) {
+        uint32_t rel[4], wq[4];
 #pragma unroll
-    for (int q = 0; q < kRows; ++q) {
-        const int y = ya + q;
-        if (y >= H) break;
-        uint32_t px[4];
-        // Fast path: the lane's four pixels are inside the frame and every tap load stays inside the frame stack.
-        // Where sx is the last column of the crop the second weight is 0, so whatever lies right of it may be read.
-        const bool whole = x0 + 3 < W && ((size_t)(max(row0[q], row1[q]) + (uint32_t)cw) * 3u + 8u <= limit);
-        if (staged[q] || whole) {
-            // per pixel and channel (S[sx], S[sx+1]) as two uint16 in one register -- {B, G, R} of source row 0, then of row 1
-            uint32_t fld[4][6];
-            if (staged[q]) {
-                // from the staged rows by byte loads with immediate offsets: ds_read_u8 puts S[sx] into the low byte of one register,
-                // ds_read_u8_d16_hi S[sx+1] into bits 16-23 of another (with SRAM ECC a d16 load zeroes the other half of its
-                // destination), one v_or_b32 joins them -- instead of three dword loads, two v_alignbyte_b32 and three v_perm_b32
-                // per pixel and row (the same scheme as the warp kernel's taps, warp.hip)
-                uint32_t lo[4][6], hi[4][6];
+        for (int j = 0; j < 4; ++j) { rel[j] = 3u * ((uint32_t)xt[j].ofs - sx_first) + (uint32_t)(uintptr_t)&s_rows[wave][0][0]; wq[j] = xt[j].w; }
+        const uint32_t mis0 = (uint32_t)((base + g_first) & 3u), mis_step = (3u * (uint32_t)W) & 3u;      // misalignment of row i: (mis0 + i mis_step) & 3
+        const auto row_at = [&](int i, uint32_t (&at)[4]) {
+            const uint32_t add = (uint32_t)i * (uint32_t)(kRowPitch + 16) + ((mis0 + (uint32_t)i * mis_step) & 3u);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t rel = 3u * ((uint32_t)xt[j].ofs - sx_first);
-                    const uint32_t at0 = (uint32_t)(uintptr_t)&s_rows[wave][q][0] + rel + s0[q];
-                    const uint32_t at1 = (uint32_t)(uintptr_t)&s_rows[wave][q][kRowPitch] + rel + s1[q];
-                    asm volatile("ds_read_u8 %0, %6 offset:0\n\tds_read_u8_d16_hi %1, %6 offset:3\n\t"
-                                 "ds_read_u8 %2, %6 offset:1\n\tds_read_u8_d16_hi %3, %6 offset:4\n\t"
-                                 "ds_read_u8 %4, %6 offset:2\n\tds_read_u8_d16_hi %5, %6 offset:5"
-                                 : "=&v"(lo[j][0]), "=&v"(hi[j][0]), "=&v"(lo[j][1]), "=&v"(hi[j][1]), "=&v"(lo[j][2]), "=&v"(hi[j][2])
-                                 : "v"(at0));
-                    asm volatile("ds_read_u8 %0, %6 offset:0\n\tds_read_u8_d16_hi %1, %6 offset:3\n\t"
-                                 "ds_read_u8 %2, %6 offset:1\n\tds_read_u8_d16_hi %3, %6 offset:4\n\t"
-                                 "ds_read_u8 %4, %6 offset:2\n\tds_read_u8_d16_hi %5, %6 offset:5"
-                                 : "=&v"(lo[j][3]), "=&v"(hi[j][3]), "=&v"(lo[j][4]), "=&v"(hi[j][4]), "=&v"(lo[j][5]), "=&v"(hi[j][5])
-                                 : "v"(at1));
-                    if (j & 1) {
-                        // the compiler does not see these loads: wait here (two pixels' worth in flight) and hand the registers over
-                        asm volatile("s_waitcnt lgkmcnt(0)"
-                                     : "+v"(lo[j - 1][0]), "+v"(hi[j - 1][0]), "+v"(lo[j - 1][1]), "+v"(hi[j - 1][1]), "+v"(lo[j - 1][2]), "+v"(hi[j - 1][2]),
-                                       "+v"(lo[j - 1][3]), "+v"(hi[j - 1][3]), "+v"(lo[j - 1][4]), "+v"(hi[j - 1][4]), "+v"(lo[j - 1][5]), "+v"(hi[j - 1][5]),
-                                       "+v"(lo[j][0]), "+v"(hi[j][0]), "+v"(lo[j][1]), "+v"(hi[j][1]), "+v"(lo[j][2]), "+v"(hi[j][2]),
-                                       "+v"(lo[j][3]), "+v"(hi[j][3]), "+v"(lo[j][4]), "+v"(hi[j][4]), "+v"(lo[j][5]), "+v"(hi[j][5]) :: "memory");
+            for (int j = 0; j < 4; ++j) at[j] = rel[j] + add;
+        };
+        // Two register sets take turns as "first source row" and "second source row" of an output row (no copies): an output row
+        // whose first source row is the previous one's second reuses its horizontal pass.
+        uint32_t Ta[4][3], Tb[4][3], at[4];
+        int have_a = -1, have_b = -1;                                  // source row (relative) each set holds
+#pragma unroll 1
+        for (int q = 0; q < rows; q += 2) {
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) { fld[j - 1][c] = lo[j - 1][c] | hi[j - 1][c]; fld[j][c] = lo[j][c] | hi[j][c]; }
-                    }
+            for (int h = 0; h < 2; ++h) {
+                const int y = ya + q + h;
+                if (y >= ya + rows) break;
+                const ResizeTab yt = ytab[y];
+                const int i0 = (yt.ofs & 0xFFFF) - r_first, i1 = (yt.ofs >> 16) - r_first;
+                const uint32_t b0s = (yt.w & 0xFFFFu) << 8, b1s = (yt.w >> 16) << 8;
+                const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
+                if (h == 0) {                                          // first source row in set A, second in set B
+                    if (have_a != i0) { row_at(i0, at); hpass_row(at, wq, Ta); have_a = i0; }
+                    if (have_b != i1) { row_at(i1, at); hpass_row(at, wq, Tb); have_b = i1; }
+                    vpass_store(Ta, Tb, b0s, b1s, dst, o, x0, W);
+                } else {                                               // ... and the other way round: this row's first is usually set B
+                    if (have_b != i0) { row_at(i0, at); hpass_row(at, wq, Tb); have_b = i0; }
+                    if (have_a != i1) { row_at(i1, at); hpass_row(at, wq, Ta); have_a = i1; }
+                    vpass_store(Tb, Ta, b0s, b1s, dst, o, x0, W);
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint2 a, b;                                              // bytes: B0 G0 R0 B1 | G1 R1 . .
-                    __builtin_memcpy(&a, src + (row0[q] + (uint32_t)xt[j].ofs) * 3u, 8);
-                    __builtin_memcpy(&b, src + (row1[q] + (uint32_t)xt[j].ofs) * 3u, 8);
-                    fld[j][0] = __builtin_amdgcn_perm(a.y, a.x, 0x0C030C00u); fld[j][3] = __builtin_amdgcn_perm(b.y, b.x, 0x0C030C00u);
-                    fld[j][1] = __builtin_amdgcn_perm(a.y, a.x, 0x0C040C01u); fld[j][4] = __builtin_amdgcn_perm(b.y, b.x, 0x0C040C01u);
-                    fld[j][2] = __builtin_amdgcn_perm(a.y, a.x, 0x0C050C02u); fld[j][5] = __builtin_amdgcn_perm(b.y, b.x, 0x0C050C02u);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // v_dot2_u32_u16 with the weights pre-scaled by 16: T = 16 t < 2^24, T & ~255 = 256 (t >> 4), and
-                // (b * (t >> 4)) >> 16 is the high half of the 24 x 24-bit product (256 b) * (256 (t >> 4)): one v_and + one
-                // v_mul_hi_u32_u24 per term
-                const uint32_t w = xt[j].w;                                        // 16 a0 | 16 a1 << 16
-                const uint32_t tB0 = udot2(fld[j][0], w, 0u), tG0 = udot2(fld[j][1], w, 0u), tR0 = udot2(fld[j][2], w, 0u);
-                const uint32_t tB1 = udot2(fld[j][3], w, 0u), tG1 = udot2(fld[j][4], w, 0u), tR1 = udot2(fld[j][5], w, 0u);
-                const uint32_t vB = (mulhi_u24(b0s[q], tB0 & ~255u) + mulhi_u24(b1s[q], tB1 & ~255u) + 2u) >> 2;
-                const uint32_t vG = (mulhi_u24(b0s[q], tG0 & ~255u) + mulhi_u24(b1s[q], tG1 & ~255u) + 2u) >> 2;
-                const uint32_t vR = (mulhi_u24(b0s[q], tR0 & ~255u) + mulhi_u24(b1s[q], tR1 & ~255u) + 2u) >> 2;
-                // no saturation needed: each weight pair sums to 2048 +- 1 (two cvRound of complementary fractions), so
-                // t <= 255 * 2049, t >> 4 <= 32655 and the two high halves sum to at most 2049 * 32655 / 65536 < 1021,
-                // i.e. (sum + 2) >> 2 <= 255 -- cv2's saturate_cast never triggers either
-                px[j] = vB | (vG << 8) | (vR << 16);
-            }
-        } else {
-            const uint32_t b0 = b0s[q] >> 8, b1 = b1s[q] >> 8;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                px[j] = 0;
-                if (x0 + j >= W) continue;
-                const uint32_t a0 = (xt[j].w & 0xFFFFu) >> 4, a1 = xt[j].w >> 20;
-                const uint32_t sx = (uint32_t)xt[j].ofs, sx1 = min(sx + 1u, (uint32_t)(cw - 1));     // a1 == 0 where sx == cw-1
-                const uint32_t p00 = load_bgr(src, (row0[q] + sx) * 3u, limit), p01 = load_bgr(src, (row0[q] + sx1) * 3u, limit);
-                const uint32_t p10 = load_bgr(src, (row1[q] + sx) * 3u, limit), p11 = load_bgr(src, (row1[q] + sx1) * 3u, limit);
-                uint32_t r = 0;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const uint32_t t0 = ((p00 >> (8 * c)) & 255u) * a0 + ((p01 >> (8 * c)) & 255u) * a1;
-                    const uint32_t t1 = ((p10 >> (8 * c)) & 255u) * a0 + ((p11 >> (8 * c)) & 255u) * a1;
-                    const uint32_t v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2u) >> 2;
-                    r |= min(v, 255u) << (8 * c);
-                }
-                px[j] = r;
             }
         }
+        return;
+    }
+
+    // direct path: taps straight from the frame, row by row
+#pragma unroll 1
+    for (int q = 0; q < rows; ++q) {
+        const int y = ya + q;
+        const ResizeTab yt = ytab[y];
+        const uint32_t b0s = (yt.w & 0xFFFFu) << 8, b1s = (yt.w >> 16) << 8;
+        const uint32_t row0 = (uint32_t)(top + (yt.ofs & 0xFFFF)) * (uint32_t)W + (uint32_t)left;
+        const uint32_t row1 = (uint32_t)(top + (yt.ofs >> 16)) * (uint32_t)W + (uint32_t)left;
         const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
-        if ((W & 3) == 0 && x0 + 3 < W) {
-            uint3 d;
-            d.x = px[0] | (px[1] << 24);
-            d.y = (px[1] >> 8) | (px[2] << 16);
-            d.z = (px[2] >> 16) | (px[3] << 8);
-            *reinterpret_cast<uint3*>(dst + o) = d;
-        } else {
+        // Fast form: the lane's four pixels are inside the frame and every tap load stays inside the frame stack.
+        // Where sx is the last column of the crop the second weight is 0, so whatever lies right of it may be read.
+        const bool whole = x0 + 3 < W && ((size_t)(max(row0, row1) + (uint32_t)cw) * 3u + 8u <= limit);
+        if (whole) {
+            uint32_t T0[4][3], T1[4][3];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (x0 + j < W) {
-                    dst[o + 3 * j + 0] = (uint8_t)(px[j]);
-                    dst[o + 3 * j + 1] = (uint8_t)(px[j] >> 8);
-                    dst[o + 3 * j + 2] = (uint8_t)(px[j] >> 16);
-                }
+            for (int j = 0; j < 4; ++j) {
+                uint2 a, b;                                              // bytes: B0 G0 R0 B1 | G1 R1 . .
+                __builtin_memcpy(&a, src + (row0 + (uint32_t)xt[j].ofs) * 3u, 8);
+                __builtin_memcpy(&b, src + (row1 + (uint32_t)xt[j].ofs) * 3u, 8);
+                const uint32_t w = xt[j].w;
+                T0[j][0] = udot2(__builtin_amdgcn_perm(a.y, a.x, 0x0C030C00u), w, 0u) & ~255u; T1[j][0] = udot2(__builtin_amdgcn_perm(b.y, b.x, 0x0C030C00u), w, 0u) & ~255u;
+                T0[j][1] = udot2(__builtin_amdgcn_perm(a.y, a.x, 0x0C040C01u), w, 0u) & ~255u; T1[j][1] = udot2(__builtin_amdgcn_perm(b.y, b.x, 0x0C040C01u), w, 0u) & ~255u;
+                T0[j][2] = udot2(__builtin_amdgcn_perm(a.y, a.x, 0x0C050C02u), w, 0u) & ~255u; T1[j][2] = udot2(__builtin_amdgcn_perm(b.y, b.x, 0x0C050C02u), w, 0u) & ~255u;
+            }
+            vpass_store(T0, T1, b0s, b1s, dst, o, x0, W);
+            continue;
+        }
+        const uint32_t b0 = b0s >> 8, b1 = b1s >> 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (x0 + j >= W) continue;
+            const uint32_t a0 = (xt[j].w & 0xFFFFu) >> 4, a1 = xt[j].w >> 20;
+            const uint32_t sx = (uint32_t)xt[j].ofs, sx1 = min(sx + 1u, (uint32_t)(cw - 1));     // a1 == 0 where sx == cw-1
+            const uint32_t p00 = load_bgr(src, (row0 + sx) * 3u, limit), p01 = load_bgr(src, (row0 + sx1) * 3u, limit);
+            const uint32_t p10 = load_bgr(src, (row1 + sx) * 3u, limit), p11 = load_bgr(src, (row1 + sx1) * 3u, limit);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t t0 = ((p00 >> (8 * c)) & 255u) * a0 + ((p01 >> (8 * c)) & 255u) * a1;
+                const uint32_t t1 = ((p10 >> (8 * c)) & 255u) * a0 + ((p11 >> (8 * c)) & 255u) * a1;
+                const uint32_t v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2u) >> 2;
+                dst[o + 3 * j + c] = (uint8_t)min(v, 255u);
+            }
         }
     }
 }
