@@ -110,6 +110,10 @@ __device__ __forceinline__ int cv_round_f32(float v)
 }
 
 // OpenCV's mask test, exactly (imgwarp.cpp WarpPerspectiveInvoker: 64-wide destination blocks).
+// (OpenCV's block is min(1024 / min(16, H), W) pixels wide: 64 for every frame of 16 rows or more -- or narrower than 64 pixels, which
+// is one block either way.  A frame under 16 rows tall AND over 64 pixels wide would get wider blocks, i.e. one rounding of x-dependent
+// terms placed differently: visible only on an exact rounding tie at a mask edge.  Not modelled -- here, in oracle/warp_oracle.c and in
+// oracle/meshflow_oracle.py alike; tests/test_cv2_crosscheck.py is where a real OpenCV would show it.)
 __device__ __forceinline__ bool mask_test_exact(const double* __restrict__ M, int lo_x, int hi_x, int lo_y, int hi_y,
                                              int x, int y)
 {

@@ -328,7 +328,8 @@ def warp_perspective_rect_mask(rect, H_fwd, frame_width, frame_height):
 
     The source mask is 255 on the inclusive rect (L,T,Rt,B) and 0 elsewhere, float64, bilinear,
     BORDER_CONSTANT 0.  Restates imgproc/imgwarp.cpp WarpPerspectiveInvoker + remapBilinear:
-    M = invert(H_fwd); destination blocks are 64 wide, and for pixel (x, y) of the block starting
+    M = invert(H_fwd); destination blocks are 64 wide (OpenCV: min(1024 / min(16, H), W) -- 64 for every frame of at least 16 rows;
+    a frame under 16 rows and over 64 pixels wide would differ on exact rounding ties only: not modelled), and for pixel (x, y) of the block starting
     at column xb:  X0 = M0*xb + M1*y + M2 (same for Y0, W0);  W = W0 + M6*x1;  W = W ? 32/W : 0;
     fX = clamp((X0 + M0*x1)*W);  X = cvRound(fX);  ix = X >> 5, fx = X & 31 (same for Y).
     The bilinear sample of the rect image is non-zero iff a tap with non-zero weight lies on the

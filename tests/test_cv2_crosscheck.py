@@ -125,3 +125,86 @@ def test_vertex_velocities_against_reference_code_with_real_cv2():
         want = s._get_unstabilized_vertex_velocities(frames[t], frames[t + 1])[0]
         got = mt.unstabilized_vertex_velocities(W, H, R, C, er, ec, feats[t][0], feats[t][1], hom[t])
         assert np.array_equal(want, got)
+
+
+# ---- config-2 geometry (1920x1080, 16x16 mesh) and the committed goldens: one run anywhere `cv2` exists settles rows a-7 / a-8 / a-9 /
+# ---- a-11 / f-1 of SURVEY.md section 8 --------------------------------------------------------------------------------------------
+
+def _cfg2_cells(n_cells=24, seed=11):
+    """A sample of config-2 cells of one frame of the bench clip: (unstabilized float32 corners, stabilized float64 corners, rect)."""
+    H, W, R, C = 1080, 1920, 16, 16
+    disp, hom = synthetic.motion(40, R, C, seed=0)
+    stab = mo.stabilized_vertex_displacements(W, H, 0, disp, hom, 10, 100)
+    grid = mo.vertex_x_y(W, H, R, C).reshape(R + 1, C + 1, 2)
+    moved = grid.astype(np.float64) + (stab[20] - disp[20])
+    g = np.random.default_rng(seed)
+    cells = []
+    for k in g.choice(R * C, n_cells, replace=False):
+        r, c = divmod(int(k), C)
+        ub = grid[r:r + 2, c:c + 2].reshape(-1, 2)
+        sb = moved[r:r + 2, c:c + 2].reshape(-1, 2)
+        cells.append((ub, sb, (int(ub[:, 0].min()), int(ub[:, 1].min()), int(ub[:, 0].max()), int(ub[:, 1].max()))))
+    return H, W, cells
+
+
+def test_cfg2_find_homography_both_directions():
+    """mfs.py:1041-1042 on config-2 cells: the restated 4-point solver against cv2.findHomography, both directions."""
+    _, _, cells = _cfg2_cells()
+    for ub, sb, _ in cells:
+        for src, dst in ((ub, sb), (sb, ub)):
+            ref, _ = cv2.findHomography(src, dst)
+            np.testing.assert_allclose(mo.find_homography_4pt(src, dst), ref, rtol=1e-8, atol=1e-8)
+
+
+def test_cfg2_warp_perspective_mask_and_perspective_transform():
+    """mfs.py:1050-1054 at full frame size: the non-zero pattern of the warped cell mask and the float32 coordinates of every pixel."""
+    H, W, cells = _cfg2_cells(n_cells=6)
+    xy = np.swapaxes(np.indices((W, H), dtype=np.float32), 0, 2).reshape(-1, 1, 2)
+    for ub, sb, (L, T, Rt, B) in cells:
+        Hf, _ = cv2.findHomography(ub, sb)
+        Hi, _ = cv2.findHomography(sb, ub)
+        mask = np.zeros((H, W)); mask[T:B + 1, L:Rt + 1] = 255
+        ref = cv2.warpPerspective(mask, Hf, (W, H)) != 0
+        got = mo.warp_perspective_rect_mask((L, T, Rt, B), Hf, W, H)
+        assert (ref != got).sum() <= 2                                  # at most a rounding tie or two along 400 px of edge
+        np.testing.assert_array_equal(mo.perspective_transform_f32(xy, Hi), cv2.perspectiveTransform(xy, Hi))
+
+
+def test_cfg2_remap_full_frame():
+    """mfs.py:1063-1069 on a 1920x1080 frame with a smooth few-pixel displacement field incl. samples beyond all four borders."""
+    H, W = 1080, 1920
+    src = synthetic.frames_numpy(1, H, W, seed=0, kind='noise')[0]
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    mx = (xx + 9.0 * np.sin(yy / 97.0) - 3.3).astype(np.float32)
+    my = (yy + 7.0 * np.cos(xx / 131.0) + 2.7).astype(np.float32)
+    ref = cv2.remap(src, mx.reshape(H, W, 1), my.reshape(H, W, 1), cv2.INTER_LINEAR, borderValue=(0, 0, 255))
+    np.testing.assert_array_equal(mo.remap_bilinear_u8c3(src, mx, my, (0, 0, 255)), ref)
+
+
+def test_cfg2_resize_of_the_real_crop_rectangle():
+    """mfs.py:1150: cv2.resize of the bench clip's crop rectangle (13, 11, 1909, 1068) back to 1920x1080 -- a 1.2 % up-scale."""
+    H, W = 1080, 1920
+    frame = synthetic.frames_numpy(1, H, W, seed=0, kind='noise')[0]
+    for (l, t, r, b) in ((13, 11, 1909, 1068), (0, 0, W - 1, H - 1), (100, 37, 1500, 1000)):
+        crop = frame[t:b + 1, l:r + 1]
+        np.testing.assert_array_equal(mo.resize_linear_u8(crop, W, H), cv2.resize(crop, (W, H)))
+        np.testing.assert_array_equal(mo.crop_frames([frame], (l, t, r, b))[0], cv2.resize(crop, (W, H)))
+
+
+@pytest.mark.parametrize('name', ['warp_small', 'warp_ragged', 'warp_jitter', 'warp_shift', 'warp_mesh16'])
+def test_reference_with_real_cv2_reproduces_the_committed_goldens(name):
+    """The reference's OWN _get_stabilized_frames_and_crop_boundaries (mfs.py:909-1108) with the REAL cv2 against tests/golden/warp_*.npz
+    (made by the same method under the stub cv2 whose four calls are the oracle's restatements): equal crop bounds, and frames equal up to
+    rounding ties of the two homography solvers.  Needs /root/reference (or MESHFLOW_REFERENCE_DIR) importable."""
+    ref_dir = os.environ.get('MESHFLOW_REFERENCE_DIR', '/root/reference')
+    if not os.path.exists(os.path.join(ref_dir, 'meshflowstabilizer.py')):
+        pytest.skip('reference not present')
+    sys.path.insert(0, ref_dir)
+    import meshflowstabilizer as mfs
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'))
+    s = mfs.MeshFlowStabilizer(mesh_row_count=int(g['R']), mesh_col_count=int(g['C']),
+                               color_outside_image_area_bgr=tuple(int(v) for v in g['border']))
+    out, bounds = s._get_stabilized_frames_and_crop_boundaries(int(g['F']), list(g['frames']), g['unstab'], g['stab'])
+    assert tuple(int(b) for b in bounds) == tuple(int(b) for b in g['bounds'])
+    diff = np.stack(out) != g['out']
+    assert diff.mean() < 1e-4, f'{int(diff.sum())} bytes differ'
