@@ -455,8 +455,30 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
                 }
             }
             // the pair shape (`covered`: the second cell is IN, or the two single-edge masks overlap across the footprint)
-            if (deep && !overflow && cnt == 2 && single_ok[0] && !(p.e[0] & MF_PLAN_IN) && wlo_all > 0.52f && whi_all < 1.9f)
-                p.e[2] = (uint16_t)MF_PLAN_HOT;
+            if (deep && !overflow && cnt == 2 && single_ok[0] && !(p.e[0] & MF_PLAN_IN) && wlo_all > 0.52f && whi_all < 1.9f) {
+                // PAIR_VERT: the deciding edge a x + b y + c runs closer to vertical (the warp kernel then transposes its lanes so that a
+                // lane's four pixels run ALONG the edge); PAIR_FAST: both cells satisfy the premises of the kernel's cheap coordinate
+                // chain -- as MF_PLAN_FAST64, plus the reciprocal-guess condition along the direction the lane's pixels run
+                const bool vert = fabsf(single_edge[0][0]) >= fabsf(single_edge[0][1]);
+                bool fast = true;
+                for (int i = 0; i < 2; ++i) {
+                    float h[9];
+                    hi_of(p.e[i] & 0xFFFu, h);
+                    float nx_lo = 1e30f, ny_lo = 1e30f, w_lo = 1e30f;
+                    for (int q = 0; q < 4; ++q) {
+                        const float cx = cxs[q & 1], cy = cys[q >> 1];
+                        nx_lo = fminf(nx_lo, h[0] * cx + h[1] * cy + h[2]);
+                        ny_lo = fminf(ny_lo, h[3] * cx + h[4] * cy + h[5]);
+                        w_lo = fminf(w_lo, h[6] * cx + h[7] * cy + h[8]);
+                    }
+                    const float nabs_x = fabsf(h[0]) * cxs[1] + fabsf(h[1]) * cys[1] + fabsf(h[2]);
+                    const float nabs_y = fabsf(h[3]) * cxs[1] + fabsf(h[4]) * cys[1] + fabsf(h[5]);
+                    const float wabs = fabsf(h[6]) * cxs[1] + fabsf(h[7]) * cys[1] + fabsf(h[8]);
+                    fast = fast && nx_lo > 0.0f && ny_lo > 0.0f && nabs_x <= 7.9f * nx_lo && nabs_y <= 7.9f * ny_lo && wabs <= 2.45f &&
+                           fabsf(h[vert ? 7 : 6]) <= 0.9f * 2.5e-4f * (w_lo * w_lo);
+                }
+                p.e[2] = (uint16_t)(MF_PLAN_HOT | (fast ? MF_PLAN_PAIR_FAST : 0u) | (vert ? MF_PLAN_PAIR_VERT : 0u));
+            }
             // the multi shape: coverage is left to the kernel
             else if (interior && !overflow && cnt >= 2 && cnt <= 4 && coded && wlo_all > 0.52f && whi_all < 1.9f)
                 p.e[4] = (uint16_t)(p.e[4] | MF_PLAN_HOT | ((uint32_t)(cnt - 1) << MF_PLAN_COUNT_SHIFT));

@@ -245,35 +245,44 @@ __device__ __forceinline__ uint32_t midpoint_key(double a)
     return ((uint32_t)__double_as_longlong(a) + (0x10000000u + FAST64_WINDOW)) & (0x1FFFFFFFu & ~(2u * FAST64_WINDOW - 1u));
 }
 
-// The hot path's coordinates by the cheap chain; false (wave-uniform) when some value is too close to a float32 midpoint.
+// The cheap chain for a lane whose four pixels step along x (VERT = false: (x0 + j, y0)) or along y (VERT: (x0, y0 + j), the
+// transposed lane mapping of the pair path); returns the smallest midpoint key (0 = some value too close to a float32 midpoint).
 // `keys` (self-test only): the eight midpoint keys, u then v per pixel.
-__device__ __forceinline__ bool coords_fast(const double (&Hi)[9], double xs0, double yy, float (&u)[4], float (&v)[4], uint32_t* keys = nullptr)
+template <bool VERT>
+__device__ __forceinline__ uint32_t coords_fast_dir(const double (&Hi)[9], double xs0, double yy0, float (&u)[4], float (&v)[4], uint32_t* keys = nullptr)
 {
-    const double c0 = __builtin_fma(yy, Hi[1], Hi[2]), c3 = __builtin_fma(yy, Hi[4], Hi[5]), c6 = __builtin_fma(yy, Hi[7], Hi[8]);
-    const double w0 = __builtin_fma(xs0, Hi[6], c6);
+    const double t0 = VERT ? yy0 : xs0, o = VERT ? xs0 : yy0;                        // stepping coordinate, the other one
+    const double a0 = Hi[VERT ? 1 : 0], a3 = Hi[VERT ? 4 : 3], a6 = Hi[VERT ? 7 : 6];   // coefficients of the stepping coordinate
+    const double c0 = __builtin_fma(o, Hi[VERT ? 0 : 1], Hi[2]), c3 = __builtin_fma(o, Hi[VERT ? 3 : 4], Hi[5]), c6 = __builtin_fma(o, Hi[VERT ? 6 : 7], Hi[8]);
+    const double w0 = __builtin_fma(t0, a6, c6);
     double r0 = __builtin_amdgcn_rcp(w0);
     double e = __builtin_fma(-w0, r0, 1.0);
     r0 = __builtin_fma(r0, e, r0);
     e = __builtin_fma(-w0, r0, 1.0);
     r0 = __builtin_fma(r0, e, r0);
-    const double c1 = Hi[6] * (r0 * r0), c2 = (Hi[6] * c1) * r0;
+    const double c1 = a6 * (r0 * r0), c2 = (a6 * c1) * r0;
     uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const double xs = xs0 + (double)j;
+        const double t = t0 + (double)j;
         double g = r0;
         if (j > 0) {
-            const double wj = __builtin_fma(xs, Hi[6], c6);
+            const double wj = __builtin_fma(t, a6, c6);
             g = recip_guess(r0, c1, c2, (double)j);
             g = __builtin_fma(g, __builtin_fma(-wj, g, 1.0), g);
         }
-        const double a = __builtin_fma(xs, Hi[0], c0) * g, b = __builtin_fma(xs, Hi[3], c3) * g;
+        const double a = __builtin_fma(t, a0, c0) * g, b = __builtin_fma(t, a3, c3) * g;
         u[j] = (float)a;
         v[j] = (float)b;
         key = min(key, min(midpoint_key(a), midpoint_key(b)));
         if (keys) { keys[2 * j] = midpoint_key(a); keys[2 * j + 1] = midpoint_key(b); }
     }
-    return __ballot(key == 0u) == 0;
+    return key;
+}
+// The hot path's coordinates by the cheap chain; false (wave-uniform) when some value is too close to a float32 midpoint.
+__device__ __forceinline__ bool coords_fast(const double (&Hi)[9], double xs0, double yy, float (&u)[4], float (&v)[4], uint32_t* keys = nullptr)
+{
+    return __ballot(coords_fast_dir<false>(Hi, xs0, yy, u, v, keys) == 0u) == 0;
 }
 __device__ __forceinline__ bool cell_coords_fast(crec_t rec, double xs0, double yy, float (&u)[4], float (&v)[4])
 {
@@ -411,9 +420,9 @@ __device__ __forceinline__ void taps_clamped(uint32_t a00, uint32_t a01, uint32_
 
 // (two pixels' loads in flight at a time: 24 registers; a software pipeline with counted lgkmcnt waits measured the same)
 template <int PITCH = LDS_PITCH>
-__device__ __forceinline__ uint3 gather_blend_staged(const uint32_t (&bx)[4], const uint32_t (&by)[4], uint32_t lds_origin)
+__device__ __forceinline__ void gather_blend_sums(const uint32_t (&bx)[4], const uint32_t (&by)[4], uint32_t lds_origin,
+                                                  uint32_t (&oB)[4], uint32_t (&oG)[4], uint32_t (&oR)[4])
 {
-    uint32_t oB[4], oG[4], oR[4];
 #pragma unroll
     for (int j = 0; j < 4; j += 2) {
         TapRegs t0, t1;
@@ -423,6 +432,12 @@ __device__ __forceinline__ uint3 gather_blend_staged(const uint32_t (&bx)[4], co
         blend_pixel(bx[j], by[j], t0, oB[j], oG[j], oR[j]);
         blend_pixel(bx[j + 1], by[j + 1], t1, oB[j + 1], oG[j + 1], oR[j + 1]);
     }
+}
+template <int PITCH = LDS_PITCH>
+__device__ __forceinline__ uint3 gather_blend_staged(const uint32_t (&bx)[4], const uint32_t (&by)[4], uint32_t lds_origin)
+{
+    uint32_t oB[4], oG[4], oR[4];
+    gather_blend_sums<PITCH>(bx, by, lds_origin, oB, oG, oR);
     // the 12 result bytes sit in byte 2 of the 12 sums: 6 v_perm_b32 + 3 v_or_b32 gather them into B0 G0 R0 B1 | G1 R1 B2 G2 |
     // R2 B3 G3 R3
     const uint32_t pair = 0x0C0C0602u, pair_hi = 0x06020C0Cu;
@@ -602,6 +617,66 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
                                              (__attribute__((address_space(3))) void*)&s_hi[0][1][0], 4, 0, 0);
         }
         const cedge_t eb = fedge + k0 * MF_EDGE_FLOATS + 3u * (pv.z & 3u);
+#ifndef MF_NO_FASTPAIR
+        if (pv.y & MF_PLAN_PAIR_FAST) {
+            // LANE-UNIFORM form.  The edge crosses the footprint, but hardly ever the four pixels of a LANE when the lane's pixels run
+            // ALONG it: for a mostly vertical edge (MF_PLAN_PAIR_VERT) the lanes are transposed -- lane l = column l % 32, rows
+            // 4 (l / 32) .. + 3 -- for a mostly horizontal one they stay as they are (4 pixels of a row).  When every lane's four
+            // pixels have ONE owner (wave-uniform test) the lane reads that owner's matrix from LDS once and runs the hot path's
+            // cheap coordinate chain on it (one reciprocal per lane, plan-certified premises for both cells, midpoint guard): 5 LDS
+            // matrix reads instead of 20 and 60 float64 operations instead of 100 per lane.  A transposed lane's pixels go back
+            // through LDS (the window is no longer needed) to the row-major lanes that store them, 12 bytes each.
+            const bool vert = (pv.y & MF_PLAN_PAIR_VERT) != 0;
+            const int px = vert ? xa + (lane & 31) : x0, py = vert ? ya + 4 * (lane >> 5) : y;
+            const float pxf = (float)px, pyf = (float)py;
+            uint32_t own4[4];
+            float nr = 1e30f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // (the same evaluation as below -- a x + (b y + c), two fma -- so the scaled error band keeps its meaning)
+                const float gb = vert ? __builtin_fmaf(eb[0], pxf, __builtin_fmaf(eb[1], pyf + (float)j, eb[2]))
+                                      : __builtin_fmaf(eb[0], pxf + (float)j, __builtin_fmaf(eb[1], pyf, eb[2]));
+                own4[j] = gb > EDGE_BAND ? 0u : OWN_ROW;
+                nr = fminf(nr, fabsf(gb));
+            }
+            const bool one_owner = own4[0] == own4[1] && own4[1] == own4[2] && own4[2] == own4[3];
+            if (__ballot(!(nr > EDGE_BAND) || !one_owner) == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // matrices and window have landed in LDS
+                const double* hp = reinterpret_cast<const double*>(reinterpret_cast<const uint8_t*>(&s_hi[0][0][0]) + own4[0]);
+                const double2 h01 = *reinterpret_cast<const double2*>(hp), h23 = *reinterpret_cast<const double2*>(hp + 2);
+                const double2 h45 = *reinterpret_cast<const double2*>(hp + 4), h67 = *reinterpret_cast<const double2*>(hp + 6);
+                const double Hl[9] = { h01.x, h01.y, h23.x, h23.y, h45.x, h45.y, h67.x, h67.y, hp[8] };
+                float u[4], v[4];
+                const uint32_t key = vert ? coords_fast_dir<true>(Hl, (double)px, (double)py, u, v) : coords_fast_dir<false>(Hl, (double)px, (double)py, u, v);
+                if (__ballot(key == 0u) == 0) {
+                    uint32_t bx[4], by[4];
+                    fixed_point(u, v, bx, by);
+                    uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
+                    uint3 d;
+                    if (vert) {
+                        uint32_t oB[4], oG[4], oR[4];
+                        gather_blend_sums(bx, by, lds_origin, oB, oG, oR);
+                        // pixel (column c, row r) as B | G << 8 | R << 16 at word r * 32 + c of the (spent) window buffer ...
+                        volatile uint32_t* tw = reinterpret_cast<volatile uint32_t*>(&s_src[0]);
+                        const uint32_t at = (uint32_t)(4 * (lane >> 5)) * 32u + (uint32_t)(lane & 31);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            tw[at + 32u * (uint32_t)j] = __builtin_amdgcn_perm(oR[j], __builtin_amdgcn_perm(oG[j], oB[j], 0x0C0C0602u), 0x0C060100u);
+                        __builtin_amdgcn_wave_barrier();
+                        // ... and row-major lane l takes its four pixels, words 4 l .. 4 l + 3
+                        const uint32_t p0 = tw[4 * lane], p1 = tw[4 * lane + 1], p2 = tw[4 * lane + 2], p3 = tw[4 * lane + 3];
+                        d.x = p0 | (p1 << 24);
+                        d.y = (p1 >> 8) | (p2 << 16);
+                        d.z = (p2 >> 16) | (p3 << 8);
+                    } else {
+                        d = gather_blend_staged(bx, by, lds_origin);
+                    }
+                    *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;
+                    return;
+                }
+            }
+        }
+#endif
         const float rb = __builtin_fmaf(eb[1], (float)y, eb[2]), xf0 = (float)x0;
         uint32_t own[4];
         float near = 1e30f;

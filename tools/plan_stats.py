@@ -53,3 +53,6 @@ regs = buf[reg_off:reg_off + npl * 8].view(np.uint32)[0::2]
 print(f'regions: compact {((regs >> 29) & 1).mean():.4f}  staged but not deep {(((regs >> 31) & 1) & ~((regs >> 30) & 1)).mean():.4f}  unstaged {1 - ((regs >> 31) & 1).mean():.4f}')
 fast64 = (plan[:, 1] & 0x6002) == 0x2002
 print(f'hot with the fast64 certificate {fast64.mean():.4f}')
+pf = (ne == 2) & ((plan[:, 2] & 0x6001) == 0x2001)
+pv_ = (ne == 2) & ((plan[:, 2] & 0x6003) == 0x2003)
+print(f'pair path with the fast certificate {pf.mean():.4f} (of which transposed lanes {pv_.mean():.4f})')
