@@ -237,16 +237,19 @@ __device__ __forceinline__ void cell_coords(crec_t rec, double xs0, double yy, i
 // affine forms, a reciprocal good to an ulp) lands within a few dozen float64 ulps of the exact chain's value (bound: DESIGN.md
 // section 4.3, certified per footprint by the plan: MF_PLAN_FAST64), so both convert to the SAME float32 unless the cheap value lies
 // within that distance of a float32 rounding midpoint, i.e. unless the low 29 mantissa bits are within FAST64_WINDOW of 0x10000000.
-// midpoint_key() is 0 exactly then (one add + one and on the low dword); a wavefront with any such value redoes its
+// midpoint_key() is below FAST64_NEAR exactly then (one v_lshl_add_u32 on the low dword); a wavefront with any such value redoes its
 // coordinates with the exact chain (about one wavefront in 2,000 at config-2 geometry).
 constexpr uint32_t FAST64_WINDOW = 256u;
+// (low dword << 3) + const: the 29 dropped mantissa bits, shifted to the top of the register and offset so that the window around the
+// midpoint pattern 0x10000000 maps to [0, 16 FAST64_WINDOW) -- ONE v_lshl_add_u32 per value; the smallest key of a lane decides.
+constexpr uint32_t FAST64_NEAR = 16u * FAST64_WINDOW;
 __device__ __forceinline__ uint32_t midpoint_key(double a)
 {
-    return ((uint32_t)__double_as_longlong(a) + (0x10000000u + FAST64_WINDOW)) & (0x1FFFFFFFu & ~(2u * FAST64_WINDOW - 1u));
+    return ((uint32_t)__double_as_longlong(a) << 3) + ((0x10000000u + FAST64_WINDOW) << 3);
 }
 
 // The cheap chain for a lane whose four pixels step along x (VERT = false: (x0 + j, y0)) or along y (VERT: (x0, y0 + j), the
-// transposed lane mapping of the pair path); returns the smallest midpoint key (0 = some value too close to a float32 midpoint).
+// transposed lane mapping of the pair path); returns the smallest midpoint key (< FAST64_NEAR = some value too close to a float32 midpoint).
 // `keys` (self-test only): the eight midpoint keys, u then v per pixel.
 template <bool VERT>
 __device__ __forceinline__ uint32_t coords_fast_dir(const double (&Hi)[9], double xs0, double yy0, float (&u)[4], float (&v)[4], uint32_t* keys = nullptr)
@@ -254,7 +257,8 @@ __device__ __forceinline__ uint32_t coords_fast_dir(const double (&Hi)[9], doubl
     const double t0 = VERT ? yy0 : xs0, o = VERT ? xs0 : yy0;                        // stepping coordinate, the other one
     const double a0 = Hi[VERT ? 1 : 0], a3 = Hi[VERT ? 4 : 3], a6 = Hi[VERT ? 7 : 6];   // coefficients of the stepping coordinate
     const double c0 = __builtin_fma(o, Hi[VERT ? 0 : 1], Hi[2]), c3 = __builtin_fma(o, Hi[VERT ? 3 : 4], Hi[5]), c6 = __builtin_fma(o, Hi[VERT ? 6 : 7], Hi[8]);
-    const double w0 = __builtin_fma(t0, a6, c6);
+    // the affine forms at the lane's first pixel, then + j a (j = 1, 2, 3 are exact constants): one fma per pixel and form
+    const double w0 = __builtin_fma(t0, a6, c6), n0 = __builtin_fma(t0, a0, c0), m0 = __builtin_fma(t0, a3, c3);
     double r0 = __builtin_amdgcn_rcp(w0);
     double e = __builtin_fma(-w0, r0, 1.0);
     r0 = __builtin_fma(r0, e, r0);
@@ -264,14 +268,15 @@ __device__ __forceinline__ uint32_t coords_fast_dir(const double (&Hi)[9], doubl
     uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const double t = t0 + (double)j;
-        double g = r0;
+        double g = r0, nj = n0, mj = m0;
         if (j > 0) {
-            const double wj = __builtin_fma(t, a6, c6);
+            const double wj = __builtin_fma((double)j, a6, w0);
+            nj = __builtin_fma((double)j, a0, n0);
+            mj = __builtin_fma((double)j, a3, m0);
             g = recip_guess(r0, c1, c2, (double)j);
             g = __builtin_fma(g, __builtin_fma(-wj, g, 1.0), g);
         }
-        const double a = __builtin_fma(t, a0, c0) * g, b = __builtin_fma(t, a3, c3) * g;
+        const double a = nj * g, b = mj * g;
         u[j] = (float)a;
         v[j] = (float)b;
         key = min(key, min(midpoint_key(a), midpoint_key(b)));
@@ -282,7 +287,7 @@ __device__ __forceinline__ uint32_t coords_fast_dir(const double (&Hi)[9], doubl
 // The hot path's coordinates by the cheap chain; false (wave-uniform) when some value is too close to a float32 midpoint.
 __device__ __forceinline__ bool coords_fast(const double (&Hi)[9], double xs0, double yy, float (&u)[4], float (&v)[4], uint32_t* keys = nullptr)
 {
-    return __ballot(coords_fast_dir<false>(Hi, xs0, yy, u, v, keys) == 0u) == 0;
+    return __ballot(coords_fast_dir<false>(Hi, xs0, yy, u, v, keys) < FAST64_NEAR) == 0;
 }
 __device__ __forceinline__ bool cell_coords_fast(crec_t rec, double xs0, double yy, float (&u)[4], float (&v)[4])
 {
@@ -648,7 +653,7 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
                 const double Hl[9] = { h01.x, h01.y, h23.x, h23.y, h45.x, h45.y, h67.x, h67.y, hp[8] };
                 float u[4], v[4];
                 const uint32_t key = vert ? coords_fast_dir<true>(Hl, (double)px, (double)py, u, v) : coords_fast_dir<false>(Hl, (double)px, (double)py, u, v);
-                if (__ballot(key == 0u) == 0) {
+                if (__ballot(key < FAST64_NEAR) == 0) {
                     uint32_t bx[4], by[4];
                     fixed_point(u, v, bx, by);
                     uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
@@ -1223,8 +1228,8 @@ __global__ void selftest_fast64_kernel(unsigned long long n, unsigned long long 
             const double iw = 1.0 / w;
             const float ue = (float)(((x * Hi[0] + yy * Hi[1]) + Hi[2]) * iw), ve = (float)(((x * Hi[3] + yy * Hi[4]) + Hi[5]) * iw);
             tested += 2;
-            if (keys[2 * j] == 0u) ++flagged; else if (__float_as_uint(ue) != __float_as_uint(u[j])) ++missed;
-            if (keys[2 * j + 1] == 0u) ++flagged; else if (__float_as_uint(ve) != __float_as_uint(v[j])) ++missed;
+            if (keys[2 * j] < FAST64_NEAR) ++flagged; else if (__float_as_uint(ue) != __float_as_uint(u[j])) ++missed;
+            if (keys[2 * j + 1] < FAST64_NEAR) ++flagged; else if (__float_as_uint(ve) != __float_as_uint(v[j])) ++missed;
         }
     }
     if (missed) atomicAdd(&counters[0], missed);
