@@ -458,7 +458,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             if (deep && !overflow && cnt == 2 && single_ok[0] && !(p.e[0] & MF_PLAN_IN) && wlo_all > 0.52f && whi_all < 1.9f) {
                 // PAIR_VERT: the deciding edge a x + b y + c runs closer to vertical (the warp kernel then transposes its lanes so that a
                 // lane's four pixels run ALONG the edge); PAIR_FAST: both cells satisfy the premises of the kernel's cheap coordinate
-                // chain -- as MF_PLAN_FAST64, plus the reciprocal-guess condition along the direction the lane's pixels run
+                // chain -- as MF_PLAN_FAST64
                 const bool vert = fabsf(single_edge[0][0]) >= fabsf(single_edge[0][1]);
                 bool fast = true;
                 for (int i = 0; i < 2; ++i) {
@@ -474,8 +474,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
                     const float nabs_x = fabsf(h[0]) * cxs[1] + fabsf(h[1]) * cys[1] + fabsf(h[2]);
                     const float nabs_y = fabsf(h[3]) * cxs[1] + fabsf(h[4]) * cys[1] + fabsf(h[5]);
                     const float wabs = fabsf(h[6]) * cxs[1] + fabsf(h[7]) * cys[1] + fabsf(h[8]);
-                    fast = fast && nx_lo > 0.0f && ny_lo > 0.0f && nabs_x <= 7.9f * nx_lo && nabs_y <= 7.9f * ny_lo && wabs <= 2.45f &&
-                           fabsf(h[vert ? 7 : 6]) <= 0.9f * 2.5e-4f * (w_lo * w_lo);
+                    fast = fast && nx_lo > 0.0f && ny_lo > 0.0f && nabs_x <= 7.9f * nx_lo && nabs_y <= 7.9f * ny_lo && wabs <= 2.45f && w_lo > 0.52f;
                 }
                 p.e[2] = (uint16_t)(MF_PLAN_HOT | (fast ? MF_PLAN_PAIR_FAST : 0u) | (vert ? MF_PLAN_PAIR_VERT : 0u));
             }

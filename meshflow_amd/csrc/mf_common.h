@@ -68,8 +68,8 @@ inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 // (bits 6-7 of that word: entries - 1) when the footprint is whole, its region STAGED and interior (every tap two pixels inside the
 // frame) and every denominator in (0.52, 1.9): the "multi" path of the kernel -- ownership from the coded edges only, coverage
 // checked at run time (a pixel without owner sends the wavefront to the general code).
-// ... and in the same entry 2: MF_PLAN_PAIR_FAST = BOTH cells satisfy the premises of the cheap coordinate chain (MF_PLAN_FAST64's, plus
-// the reciprocal-guess condition along the direction the lane's pixels run), so the kernel may take its lane-uniform form of the pair
+// ... and in the same entry 2: MF_PLAN_PAIR_FAST = BOTH cells satisfy the premises of the cheap coordinate chain (MF_PLAN_FAST64's),
+// so the kernel may take its lane-uniform form of the pair
 // path; MF_PLAN_PAIR_VERT = the deciding edge is closer to vertical than to horizontal: transposed lanes (a lane = 1 column x 4 rows).
 #define MF_PLAN_PAIR_FAST 0x0001u
 #define MF_PLAN_PAIR_VERT 0x0002u

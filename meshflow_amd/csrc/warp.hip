@@ -258,25 +258,29 @@ __device__ __forceinline__ uint32_t coords_fast_dir(const double (&Hi)[9], doubl
     const double a0 = Hi[VERT ? 1 : 0], a3 = Hi[VERT ? 4 : 3], a6 = Hi[VERT ? 7 : 6];   // coefficients of the stepping coordinate
     const double c0 = __builtin_fma(o, Hi[VERT ? 0 : 1], Hi[2]), c3 = __builtin_fma(o, Hi[VERT ? 3 : 4], Hi[5]), c6 = __builtin_fma(o, Hi[VERT ? 6 : 7], Hi[8]);
     // the affine forms at the lane's first pixel, then + j a (j = 1, 2, 3 are exact constants): one fma per pixel and form
-    const double w0 = __builtin_fma(t0, a6, c6), n0 = __builtin_fma(t0, a0, c0), m0 = __builtin_fma(t0, a3, c3);
-    double r0 = __builtin_amdgcn_rcp(w0);
-    double e = __builtin_fma(-w0, r0, 1.0);
-    r0 = __builtin_fma(r0, e, r0);
-    e = __builtin_fma(-w0, r0, 1.0);
-    r0 = __builtin_fma(r0, e, r0);
-    const double c1 = a6 * (r0 * r0), c2 = (a6 * c1) * r0;
+    double w[4], n[4], m[4];
+    w[0] = __builtin_fma(t0, a6, c6); n[0] = __builtin_fma(t0, a0, c0); m[0] = __builtin_fma(t0, a3, c3);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        w[j] = __builtin_fma((double)j, a6, w[0]);
+        n[j] = __builtin_fma((double)j, a0, n[0]);
+        m[j] = __builtin_fma((double)j, a3, m[0]);
+    }
+    // ONE reciprocal for the four denominators: R = 1 / (w0 w1 w2 w3) by v_rcp_f64 + two Newton steps (0.07 < product < 13.1), then
+    // 1 / w0 = (R w2 w3) w1 and so on -- nine multiplications; the rounding errors of the w_j themselves cancel (the same values sit
+    // in the product), what remains is 5 roundings per reciprocal.
+    const double q01 = w[0] * w[1], q23 = w[2] * w[3], pr = q01 * q23;
+    double r = __builtin_amdgcn_rcp(pr);
+    double e = __builtin_fma(-pr, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-pr, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double ra = r * q23, rb = r * q01;
+    const double g[4] = { ra * w[1], ra * w[0], rb * w[3], rb * w[2] };
     uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        double g = r0, nj = n0, mj = m0;
-        if (j > 0) {
-            const double wj = __builtin_fma((double)j, a6, w0);
-            nj = __builtin_fma((double)j, a0, n0);
-            mj = __builtin_fma((double)j, a3, m0);
-            g = recip_guess(r0, c1, c2, (double)j);
-            g = __builtin_fma(g, __builtin_fma(-wj, g, 1.0), g);
-        }
-        const double a = nj * g, b = mj * g;
+        const double a = n[j] * g[j], b = m[j] * g[j];
         u[j] = (float)a;
         v[j] = (float)b;
         key = min(key, min(midpoint_key(a), midpoint_key(b)));
