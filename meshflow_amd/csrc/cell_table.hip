@@ -427,24 +427,28 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             const uint32_t bs = (3u * (uint32_t)sx0) & ~3u;
             region.flags_origin = MF_REGION_STAGED | (deep ? MF_REGION_DEEP : 0u) | ((uint32_t)sy0 * MF_STAGE_PITCH + bs);
             region.src_dwords = ((uint32_t)sy0 * (3u * (uint32_t)W) + bs) >> 2;
+            // The premises of the warp kernel's cheap coordinate chain (warp.hip, cheap_quotients) for EVERY listed cell on this footprint:
+            // no cancellation in the numerators -- the sum of the magnitudes of a numerator's terms (largest at the far corner: x, y >= 0)
+            // at most 8 x the numerator, which is u w >= umin wlo for every listed cell -- denominator terms bounded, denominator above
+            // 0.52.  One pass for the three paths that use it (hot, pair, multi), from the matrices read again after the candidate loop.
+            bool cheap_all = interior && !overflow && cnt <= 4 && umin > 0.0f && vmin > 0.0f && wlo_all > 0.52f;
+            if (cheap_all) {
+                const float nx_lo = 7.9f * umin * wlo_all, ny_lo = 7.9f * vmin * wlo_all;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < cnt) {
+                        float h[9];
+                        hi_of((int)(p.e[i] & 0xFFFu), h);
+                        cheap_all = cheap_all && fabsf(h[0]) * cxs[1] + fabsf(h[1]) * cys[1] + fabsf(h[2]) <= nx_lo &&
+                                    fabsf(h[3]) * cxs[1] + fabsf(h[4]) * cys[1] + fabsf(h[5]) <= ny_lo &&
+                                    fabsf(h[6]) * cxs[1] + fabsf(h[7]) * cys[1] + fabsf(h[8]) <= 2.45f;
+                    }
+            }
             if (deep && p.e[1] == (uint16_t)MF_PLAN_UNIT && (p.e[0] & (MF_PLAN_VALID | MF_PLAN_IN)) == (MF_PLAN_VALID | MF_PLAN_IN)) {
                 // FAST64: no cancellation in the numerators (sum of the terms' magnitudes at most 8 x the value, everywhere on
                 // the footprint: the former grows with x and y, the latter is smallest at a corner), denominator terms bounded --
                 // the premises of the warp kernel's error bound for its cheap coordinate chain (warp.hip, cell_coords_fast)
-                // (evaluated here, for hot footprints only, from the cell's matrix read again: keeps the candidate loop's registers)
-                float h[9];
-                hi_of(p.e[0] & 0xFFFu, h);
-                float nx_lo = 1e30f, ny_lo = 1e30f;
-                for (int q = 0; q < 4; ++q) {
-                    const float cx = cxs[q & 1], cy = cys[q >> 1];
-                    nx_lo = fminf(nx_lo, h[0] * cx + h[1] * cy + h[2]);
-                    ny_lo = fminf(ny_lo, h[3] * cx + h[4] * cy + h[5]);
-                }
-                // (sums of magnitudes: largest at the far corner, x, y >= 0)
-                const float nabs_x = fabsf(h[0]) * cxs[1] + fabsf(h[1]) * cys[1] + fabsf(h[2]);
-                const float nabs_y = fabsf(h[3]) * cxs[1] + fabsf(h[4]) * cys[1] + fabsf(h[5]);
-                const float wabs = fabsf(h[6]) * cxs[1] + fabsf(h[7]) * cys[1] + fabsf(h[8]);
-                const bool fast64 = nx_lo > 0.0f && ny_lo > 0.0f && nabs_x <= 7.9f * nx_lo && nabs_y <= 7.9f * ny_lo && wabs <= 2.45f;
+                const bool fast64 = cheap_all;
                 p.e[1] = (uint16_t)(MF_PLAN_UNIT | MF_PLAN_HOT | (fast64 ? MF_PLAN_FAST64 : 0u));
                 // COMPACT window: 9 rows x 112 bytes hold every tap -> one global->LDS load instead of two
                 const uint32_t cbs = (3u * (uint32_t)ix_lo) & ~3u;
@@ -460,27 +464,14 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
                 // lane's four pixels run ALONG the edge); PAIR_FAST: both cells satisfy the premises of the kernel's cheap coordinate
                 // chain -- as MF_PLAN_FAST64
                 const bool vert = fabsf(single_edge[0][0]) >= fabsf(single_edge[0][1]);
-                bool fast = true;
-                for (int i = 0; i < 2; ++i) {
-                    float h[9];
-                    hi_of(p.e[i] & 0xFFFu, h);
-                    float nx_lo = 1e30f, ny_lo = 1e30f, w_lo = 1e30f;
-                    for (int q = 0; q < 4; ++q) {
-                        const float cx = cxs[q & 1], cy = cys[q >> 1];
-                        nx_lo = fminf(nx_lo, h[0] * cx + h[1] * cy + h[2]);
-                        ny_lo = fminf(ny_lo, h[3] * cx + h[4] * cy + h[5]);
-                        w_lo = fminf(w_lo, h[6] * cx + h[7] * cy + h[8]);
-                    }
-                    const float nabs_x = fabsf(h[0]) * cxs[1] + fabsf(h[1]) * cys[1] + fabsf(h[2]);
-                    const float nabs_y = fabsf(h[3]) * cxs[1] + fabsf(h[4]) * cys[1] + fabsf(h[5]);
-                    const float wabs = fabsf(h[6]) * cxs[1] + fabsf(h[7]) * cys[1] + fabsf(h[8]);
-                    fast = fast && nx_lo > 0.0f && ny_lo > 0.0f && nabs_x <= 7.9f * nx_lo && nabs_y <= 7.9f * ny_lo && wabs <= 2.45f && w_lo > 0.52f;
-                }
+                const bool fast = cheap_all;
                 p.e[2] = (uint16_t)(MF_PLAN_HOT | (fast ? MF_PLAN_PAIR_FAST : 0u) | (vert ? MF_PLAN_PAIR_VERT : 0u));
             }
             // the multi shape: coverage is left to the kernel
-            else if (interior && !overflow && cnt >= 2 && cnt <= 4 && coded && wlo_all > 0.52f && whi_all < 1.9f)
-                p.e[4] = (uint16_t)(p.e[4] | MF_PLAN_HOT | ((uint32_t)(cnt - 1) << MF_PLAN_COUNT_SHIFT));
+            else if (interior && !overflow && cnt >= 2 && cnt <= 4 && coded && wlo_all > 0.52f && whi_all < 1.9f) {
+                const bool fast = cheap_all;
+                p.e[4] = (uint16_t)(p.e[4] | MF_PLAN_HOT | (fast ? MF_PLAN_MULTI_FAST : 0u) | ((uint32_t)(cnt - 1) << MF_PLAN_COUNT_SHIFT));
+            }
         }
     }
 }

@@ -73,6 +73,8 @@ inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 // path; MF_PLAN_PAIR_VERT = the deciding edge is closer to vertical than to horizontal: transposed lanes (a lane = 1 column x 4 rows).
 #define MF_PLAN_PAIR_FAST 0x0001u
 #define MF_PLAN_PAIR_VERT 0x0002u
+// ... and bit 12 of the first edge-code word e[4] (next to its MF_PLAN_HOT = the multi path): every listed cell satisfies those premises.
+#define MF_PLAN_MULTI_FAST 0x1000u
 #define MF_PLAN_COUNT_SHIFT 6
 struct alignas(16) FootPlan { uint16_t e[8]; };
 // Source region of a footprint (FootRegion).  STAGED: every bilinear tap of every pixel of the footprint lies in columns sx0 ..

@@ -248,27 +248,13 @@ __device__ __forceinline__ uint32_t midpoint_key(double a)
     return ((uint32_t)__double_as_longlong(a) << 3) + ((0x10000000u + FAST64_WINDOW) << 3);
 }
 
-// The cheap chain for a lane whose four pixels step along x (VERT = false: (x0 + j, y0)) or along y (VERT: (x0, y0 + j), the
-// transposed lane mapping of the pair path); returns the smallest midpoint key (< FAST64_NEAR = some value too close to a float32 midpoint).
-// `keys` (self-test only): the eight midpoint keys, u then v per pixel.
-template <bool VERT>
-__device__ __forceinline__ uint32_t coords_fast_dir(const double (&Hi)[9], double xs0, double yy0, float (&u)[4], float (&v)[4], uint32_t* keys = nullptr)
+// Quotients n_j / w_j and m_j / w_j of a lane's four pixels on the cheap chain, whatever matrices the forms came from: ONE reciprocal
+// for the four denominators -- R = 1 / (w0 w1 w2 w3) by v_rcp_f64 + two Newton steps (0.07 < product < 13.1), then 1 / w0 = (R w2 w3) w1
+// and so on: nine multiplications; the rounding errors of the w_j themselves cancel (the same values sit in the product), what remains
+// is 5 roundings per reciprocal.  Returns the smallest midpoint key of the eight values.
+__device__ __forceinline__ uint32_t cheap_quotients(const double (&w)[4], const double (&n)[4], const double (&m)[4], float (&u)[4], float (&v)[4],
+                                                    uint32_t* keys = nullptr)
 {
-    const double t0 = VERT ? yy0 : xs0, o = VERT ? xs0 : yy0;                        // stepping coordinate, the other one
-    const double a0 = Hi[VERT ? 1 : 0], a3 = Hi[VERT ? 4 : 3], a6 = Hi[VERT ? 7 : 6];   // coefficients of the stepping coordinate
-    const double c0 = __builtin_fma(o, Hi[VERT ? 0 : 1], Hi[2]), c3 = __builtin_fma(o, Hi[VERT ? 3 : 4], Hi[5]), c6 = __builtin_fma(o, Hi[VERT ? 6 : 7], Hi[8]);
-    // the affine forms at the lane's first pixel, then + j a (j = 1, 2, 3 are exact constants): one fma per pixel and form
-    double w[4], n[4], m[4];
-    w[0] = __builtin_fma(t0, a6, c6); n[0] = __builtin_fma(t0, a0, c0); m[0] = __builtin_fma(t0, a3, c3);
-#pragma unroll
-    for (int j = 1; j < 4; ++j) {
-        w[j] = __builtin_fma((double)j, a6, w[0]);
-        n[j] = __builtin_fma((double)j, a0, n[0]);
-        m[j] = __builtin_fma((double)j, a3, m[0]);
-    }
-    // ONE reciprocal for the four denominators: R = 1 / (w0 w1 w2 w3) by v_rcp_f64 + two Newton steps (0.07 < product < 13.1), then
-    // 1 / w0 = (R w2 w3) w1 and so on -- nine multiplications; the rounding errors of the w_j themselves cancel (the same values sit
-    // in the product), what remains is 5 roundings per reciprocal.
     const double q01 = w[0] * w[1], q23 = w[2] * w[3], pr = q01 * q23;
     double r = __builtin_amdgcn_rcp(pr);
     double e = __builtin_fma(-pr, r, 1.0);
@@ -287,6 +273,27 @@ __device__ __forceinline__ uint32_t coords_fast_dir(const double (&Hi)[9], doubl
         if (keys) { keys[2 * j] = midpoint_key(a); keys[2 * j + 1] = midpoint_key(b); }
     }
     return key;
+}
+
+// The cheap chain for a lane whose four pixels step along x (VERT = false: (x0 + j, y0)) or along y (VERT: (x0, y0 + j), the
+// transposed lane mapping of the pair path); returns the smallest midpoint key (< FAST64_NEAR = some value too close to a float32 midpoint).
+// `keys` (self-test only): the eight midpoint keys, u then v per pixel.
+template <bool VERT>
+__device__ __forceinline__ uint32_t coords_fast_dir(const double (&Hi)[9], double xs0, double yy0, float (&u)[4], float (&v)[4], uint32_t* keys = nullptr)
+{
+    const double t0 = VERT ? yy0 : xs0, o = VERT ? xs0 : yy0;                        // stepping coordinate, the other one
+    const double a0 = Hi[VERT ? 1 : 0], a3 = Hi[VERT ? 4 : 3], a6 = Hi[VERT ? 7 : 6];   // coefficients of the stepping coordinate
+    const double c0 = __builtin_fma(o, Hi[VERT ? 0 : 1], Hi[2]), c3 = __builtin_fma(o, Hi[VERT ? 3 : 4], Hi[5]), c6 = __builtin_fma(o, Hi[VERT ? 6 : 7], Hi[8]);
+    // the affine forms at the lane's first pixel, then + j a (j = 1, 2, 3 are exact constants): one fma per pixel and form
+    double w[4], n[4], m[4];
+    w[0] = __builtin_fma(t0, a6, c6); n[0] = __builtin_fma(t0, a0, c0); m[0] = __builtin_fma(t0, a3, c3);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        w[j] = __builtin_fma((double)j, a6, w[0]);
+        n[j] = __builtin_fma((double)j, a0, n[0]);
+        m[j] = __builtin_fma((double)j, a3, m[0]);
+    }
+    return cheap_quotients(w, n, m, u, v, keys);
 }
 // The hot path's coordinates by the cheap chain; false (wave-uniform) when some value is too close to a float32 midpoint.
 __device__ __forceinline__ bool coords_fast(const double (&Hi)[9], double xs0, double yy, float (&u)[4], float (&v)[4], uint32_t* keys = nullptr)
@@ -766,16 +773,37 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
         if (__ballot(!(near > EDGE_BAND) || worst == OWN_NONE) == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // matrices and window have landed in LDS
             float u[4], v[4];
+            bool have = false;
+#ifndef MF_NO_FASTMULTI
+            if (pv.z & MF_PLAN_MULTI_FAST) {
+                // every listed cell satisfies the premises of the cheap chain: fused affine forms per pixel from its owner's matrix, one
+                // reciprocal for the lane's four denominators, midpoint guard (a flagged wavefront takes the exact chain below)
+                double wq[4], nq[4], mq[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double* hp = reinterpret_cast<const double*>(reinterpret_cast<const uint8_t*>(&s_hi[0][0][0]) + own[j]);
-                const double2 h01 = *reinterpret_cast<const double2*>(hp), h23 = *reinterpret_cast<const double2*>(hp + 2);
-                const double2 h45 = *reinterpret_cast<const double2*>(hp + 4), h67 = *reinterpret_cast<const double2*>(hp + 6);
-                const double h8 = hp[8];
-                const double xs = xs0 + (double)j;
-                const double iw = recip_unit_range((xs * h67.x + yy * h67.y) + h8);
-                u[j] = (float)(((xs * h01.x + yy * h01.y) + h23.x) * iw);
-                v[j] = (float)(((xs * h23.y + yy * h45.x) + h45.y) * iw);
+                for (int j = 0; j < 4; ++j) {
+                    const double* hp = reinterpret_cast<const double*>(reinterpret_cast<const uint8_t*>(&s_hi[0][0][0]) + own[j]);
+                    const double2 h01 = *reinterpret_cast<const double2*>(hp), h23 = *reinterpret_cast<const double2*>(hp + 2);
+                    const double2 h45 = *reinterpret_cast<const double2*>(hp + 4), h67 = *reinterpret_cast<const double2*>(hp + 6);
+                    const double xs = xs0 + (double)j;
+                    nq[j] = __builtin_fma(xs, h01.x, __builtin_fma(yy, h01.y, h23.x));
+                    mq[j] = __builtin_fma(xs, h23.y, __builtin_fma(yy, h45.x, h45.y));
+                    wq[j] = __builtin_fma(xs, h67.x, __builtin_fma(yy, h67.y, hp[8]));
+                }
+                have = __ballot(cheap_quotients(wq, nq, mq, u, v) < FAST64_NEAR) == 0;
+            }
+#endif
+            if (!have) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double* hp = reinterpret_cast<const double*>(reinterpret_cast<const uint8_t*>(&s_hi[0][0][0]) + own[j]);
+                    const double2 h01 = *reinterpret_cast<const double2*>(hp), h23 = *reinterpret_cast<const double2*>(hp + 2);
+                    const double2 h45 = *reinterpret_cast<const double2*>(hp + 4), h67 = *reinterpret_cast<const double2*>(hp + 6);
+                    const double h8 = hp[8];
+                    const double xs = xs0 + (double)j;
+                    const double iw = recip_unit_range((xs * h67.x + yy * h67.y) + h8);
+                    u[j] = (float)(((xs * h01.x + yy * h01.y) + h23.x) * iw);
+                    v[j] = (float)(((xs * h23.y + yy * h45.x) + h45.y) * iw);
+                }
             }
             uint32_t bx[4], by[4];
             fixed_point(u, v, bx, by);
