@@ -52,6 +52,8 @@
 #include "mf_common.h"
 #include <stdlib.h>
 
+#include <type_traits>
+
 // At most 80 scalar registers: a CU admits min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) workgroups of 256 threads
 // (MI355X_MICROARCH.md), i.e. 7 with the 94 the compiler would take and 8 with 80 (the excess is kept in VGPR lanes, the kernel
 // stays at 64 VGPRs): -1.7 % kernel time.
@@ -642,55 +644,51 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
             // cheap coordinate chain on it (one reciprocal per lane, plan-certified premises for both cells, midpoint guard): 5 LDS
             // matrix reads instead of 20 and 60 float64 operations instead of 100 per lane.  A transposed lane's pixels go back
             // through LDS (the window is no longer needed) to the row-major lanes that store them, 12 bytes each.
-            const bool vert = (pv.y & MF_PLAN_PAIR_VERT) != 0;
-            const int px = vert ? xa + (lane & 31) : x0, py = vert ? ya + 4 * (lane >> 5) : y;
-            const float pxf = (float)px, pyf = (float)py;
-            uint32_t own4[4];
-            float nr = 1e30f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // (the same evaluation as below -- a x + (b y + c), two fma -- so the scaled error band keeps its meaning)
-                const float gb = vert ? __builtin_fmaf(eb[0], pxf, __builtin_fmaf(eb[1], pyf + (float)j, eb[2]))
-                                      : __builtin_fmaf(eb[0], pxf + (float)j, __builtin_fmaf(eb[1], pyf, eb[2]));
-                own4[j] = gb > EDGE_BAND ? 0u : OWN_ROW;
-                nr = fminf(nr, fabsf(gb));
-            }
-            const bool one_owner = own4[0] == own4[1] && own4[1] == own4[2] && own4[2] == own4[3];
-            if (__ballot(!(nr > EDGE_BAND) || !one_owner) == 0) {
+            // (two instantiations, chosen by a scalar branch: no per-lane selects on the wave-uniform direction)
+            const auto lane_uniform = [&](auto vert_c) -> bool {
+                constexpr bool VERT = decltype(vert_c)::value;
+                const int px = VERT ? xa + (lane & 31) : x0, py = VERT ? ya + 4 * (lane >> 5) : y;
+                // The edge function is affine along the lane, so its values at the lane's first and last pixel decide for all four: both
+                // beyond the error band on the same side = one owner (the same evaluation as below -- a x + (b y + c), two fma -- so the
+                // scaled band keeps its meaning: beyond +-1 the sign is the exact function's)
+                const float g0 = __builtin_fmaf(eb[0], (float)px, __builtin_fmaf(eb[1], (float)py, eb[2]));
+                const float g3 = VERT ? __builtin_fmaf(eb[0], (float)px, __builtin_fmaf(eb[1], (float)(py + 3), eb[2]))
+                                      : __builtin_fmaf(eb[0], (float)(px + 3), __builtin_fmaf(eb[1], (float)py, eb[2]));
+                const float lo = fminf(g0, g3), hi = fmaxf(g0, g3);
+                const bool first = lo > EDGE_BAND, second = hi < -EDGE_BAND;         // (NaN coefficients: neither)
+                if (__ballot(!(first || second)) != 0) return false;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // matrices and window have landed in LDS
-                const double* hp = reinterpret_cast<const double*>(reinterpret_cast<const uint8_t*>(&s_hi[0][0][0]) + own4[0]);
-                const double2 h01 = *reinterpret_cast<const double2*>(hp), h23 = *reinterpret_cast<const double2*>(hp + 2);
-                const double2 h45 = *reinterpret_cast<const double2*>(hp + 4), h67 = *reinterpret_cast<const double2*>(hp + 6);
-                const double Hl[9] = { h01.x, h01.y, h23.x, h23.y, h45.x, h45.y, h67.x, h67.y, hp[8] };
+                typedef const __attribute__((address_space(3))) double* lds_d;
+                const lds_d hp = (lds_d)(uintptr_t)((uint32_t)(uintptr_t)&s_hi[0][0][0] + (first ? 0u : OWN_ROW));
+                const double Hl[9] = { hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8] };
                 float u[4], v[4];
-                const uint32_t key = vert ? coords_fast_dir<true>(Hl, (double)px, (double)py, u, v) : coords_fast_dir<false>(Hl, (double)px, (double)py, u, v);
-                if (__ballot(key < FAST64_NEAR) == 0) {
-                    uint32_t bx[4], by[4];
-                    fixed_point(u, v, bx, by);
-                    uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
-                    uint3 d;
-                    if (vert) {
-                        uint32_t oB[4], oG[4], oR[4];
-                        gather_blend_sums(bx, by, lds_origin, oB, oG, oR);
-                        // pixel (column c, row r) as B | G << 8 | R << 16 at word r * 32 + c of the (spent) window buffer ...
-                        volatile uint32_t* tw = reinterpret_cast<volatile uint32_t*>(&s_src[0]);
-                        const uint32_t at = (uint32_t)(4 * (lane >> 5)) * 32u + (uint32_t)(lane & 31);
+                if (__ballot(coords_fast_dir<VERT>(Hl, (double)px, (double)py, u, v) < FAST64_NEAR) != 0) return false;
+                uint32_t bx[4], by[4];
+                fixed_point(u, v, bx, by);
+                uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
+                uint3 d;
+                if (VERT) {
+                    uint32_t oB[4], oG[4], oR[4];
+                    gather_blend_sums(bx, by, lds_origin, oB, oG, oR);
+                    // pixel (column c, row r) as B | G << 8 | R << 16 at word r * 32 + c of the (spent) window buffer ...
+                    volatile uint32_t* tw = reinterpret_cast<volatile uint32_t*>(&s_src[0]);
+                    const uint32_t at = (uint32_t)(4 * (lane >> 5)) * 32u + (uint32_t)(lane & 31);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            tw[at + 32u * (uint32_t)j] = __builtin_amdgcn_perm(oR[j], __builtin_amdgcn_perm(oG[j], oB[j], 0x0C0C0602u), 0x0C060100u);
-                        __builtin_amdgcn_wave_barrier();
-                        // ... and row-major lane l takes its four pixels, words 4 l .. 4 l + 3
-                        const uint32_t p0 = tw[4 * lane], p1 = tw[4 * lane + 1], p2 = tw[4 * lane + 2], p3 = tw[4 * lane + 3];
-                        d.x = p0 | (p1 << 24);
-                        d.y = (p1 >> 8) | (p2 << 16);
-                        d.z = (p2 >> 16) | (p3 << 8);
-                    } else {
-                        d = gather_blend_staged(bx, by, lds_origin);
-                    }
-                    *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;
-                    return;
+                    for (int j = 0; j < 4; ++j)
+                        tw[at + 32u * (uint32_t)j] = __builtin_amdgcn_perm(oR[j], __builtin_amdgcn_perm(oG[j], oB[j], 0x0C0C0602u), 0x0C060100u);
+                    __builtin_amdgcn_wave_barrier();
+                    // ... and row-major lane l takes its four pixels, words 4 l .. 4 l + 3
+                    const uint32_t p0 = tw[4 * lane], p1 = tw[4 * lane + 1], p2 = tw[4 * lane + 2], p3 = tw[4 * lane + 3];
+                    d.x = p0 | (p1 << 24);
+                    d.y = (p1 >> 8) | (p2 << 16);
+                    d.z = (p2 >> 16) | (p3 << 8);
+                } else {
+                    d = gather_blend_staged(bx, by, lds_origin);
                 }
-            }
+                *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;
+                return true;
+            };
+            if ((pv.y & MF_PLAN_PAIR_VERT) ? lane_uniform(std::true_type{}) : lane_uniform(std::false_type{})) return;
         }
 #endif
         const float rb = __builtin_fmaf(eb[1], (float)y, eb[2]), xf0 = (float)x0;
