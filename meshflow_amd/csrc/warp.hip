@@ -626,9 +626,12 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
         // global->LDS DMA (one 80-byte load per cell, scalar base address), and every pixel reads its owner's row.
         const uint32_t k0 = pv.x & 0xFFFu, k1 = (pv.x >> 16) & 0xFFFu;
         if (lane < 20) {
-            const uint32_t lo4 = (uint32_t)lane << 2;
-            const uint8_t* __restrict__ g0 = (const uint8_t*)(uintptr_t)(frec + k0 * MF_CELL_DOUBLES + MF_CELL_OFF_HI);
-            const uint8_t* __restrict__ g1 = (const uint8_t*)(uintptr_t)(frec + k1 * MF_CELL_DOUBLES + MF_CELL_OFF_HI);
+            uint32_t lo4 = (uint32_t)lane << 2;
+            asm("" : "+v"(lo4));                        // (opaque: keeps the scalar base + 32-bit lane offset addressing form)
+            uint64_t b0 = (uint64_t)(uintptr_t)(frec + k0 * MF_CELL_DOUBLES + MF_CELL_OFF_HI), b1 = (uint64_t)(uintptr_t)(frec + k1 * MF_CELL_DOUBLES + MF_CELL_OFF_HI);
+            asm("" : "+s"(b0), "+s"(b1));                   // (whole bases in scalar registers: scalar base + 32-bit lane offset addressing)
+            const uint8_t* __restrict__ g0 = (const uint8_t*)(uintptr_t)b0;
+            const uint8_t* __restrict__ g1 = (const uint8_t*)(uintptr_t)b1;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + lo4),
                                              (__attribute__((address_space(3))) void*)&s_hi[0][0][0], 4, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g1 + lo4),
@@ -659,7 +662,9 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
                 if (__ballot(!(first || second)) != 0) return false;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // matrices and window have landed in LDS
                 typedef const __attribute__((address_space(3))) double* lds_d;
-                const lds_d hp = (lds_d)(uintptr_t)((uint32_t)(uintptr_t)&s_hi[0][0][0] + (first ? 0u : OWN_ROW));
+                uint32_t hrow = (uint32_t)(uintptr_t)&s_hi[0][0][0] + (first ? 0u : OWN_ROW);
+                asm("" : "+v"(hrow));                                    // (one address register + immediate offsets, not a select per load)
+                const lds_d hp = (lds_d)(uintptr_t)hrow;
                 const double Hl[9] = { hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8] };
                 float u[4], v[4];
                 if (__ballot(coords_fast_dir<VERT>(Hl, (double)px, (double)py, u, v) < FAST64_NEAR) != 0) return false;
@@ -730,12 +735,15 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
         // takes -- or one inside the float32 error band of an edge -- sends the wavefront to the general code.
         const int ne = (int)((pv.z >> MF_PLAN_COUNT_SHIFT) & 3u) + 1;
         if (lane < 20) {
-            const uint32_t lo4 = (uint32_t)lane << 2;
+            uint32_t lo4 = (uint32_t)lane << 2;
+            asm("" : "+v"(lo4));                        // (opaque: keeps the scalar base + 32-bit lane offset addressing form)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i < ne) {
                     const uint32_t k = ((i < 2 ? pv.x : pv.y) >> (16 * (i & 1))) & 0xFFFu;
-                    const uint8_t* __restrict__ gi = (const uint8_t*)(uintptr_t)(frec + k * MF_CELL_DOUBLES + MF_CELL_OFF_HI);
+                    uint64_t bi = (uint64_t)(uintptr_t)(frec + k * MF_CELL_DOUBLES + MF_CELL_OFF_HI);
+                    asm("" : "+s"(bi));
+                    const uint8_t* __restrict__ gi = (const uint8_t*)(uintptr_t)bi;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gi + lo4),
                                                      (__attribute__((address_space(3))) void*)&s_hi[0][i][0], 4, 0, 0);
                 }
@@ -868,7 +876,8 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
             // (a) entry e's nine doubles are 18 consecutive dwords of its record: lanes 0..19 copy them (and two dwords of padding)
             // straight into row e of s_hi, one global->LDS load per entry with a scalar base address -- no per-lane cell lookup
             if (lane < 20) {
-                const uint32_t lo4 = (uint32_t)lane << 2;
+                uint32_t lo4 = (uint32_t)lane << 2;
+            asm("" : "+v"(lo4));                        // (opaque: keeps the scalar base + 32-bit lane offset addressing form)
 #pragma unroll 1
                 for (int e = 0; e < ne; ++e) {
                     const uint32_t d = e < 2 ? pv.x : e < 4 ? pv.y : e < 6 ? pv.z : pv.w;
