@@ -376,31 +376,41 @@ __device__ __forceinline__ void fixed_point(const float (&u)[4], const float (&v
 // placed here.
 struct TapRegs { uint32_t lo[6], hi[6]; };      // {B, G, R} of row iy, then of row iy + 1: X0 in lo (byte 0), X1 in hi (byte 2)
 
+// Tap address of one pixel: LDS byte address of its top-left tap's B.
 template <int PITCH>
-__device__ __forceinline__ void taps_issue(uint32_t bxj, uint32_t byj, uint32_t lds_origin, TapRegs& t)
+__device__ __forceinline__ uint32_t tap_address(uint32_t bxj, uint32_t byj, uint32_t lds_origin)
 {
     // ix = bits[5..21] of the raw float; bits[22..28] (the 1.5*2^23 pattern, constant) ride along in the 24-bit multiplier
     // operand and are taken out again through the origin
-    const uint32_t at = umad24(byj >> 5, (uint32_t)PITCH, umad24(bxj >> 5, 3u, 0u - lds_origin - MAGIC_HI * (3u + (uint32_t)PITCH)));
-    asm volatile("ds_read_u8 %0, %12 offset:0\n\tds_read_u8_d16_hi %1, %12 offset:3\n\t"
-                 "ds_read_u8 %2, %12 offset:1\n\tds_read_u8_d16_hi %3, %12 offset:4\n\t"
-                 "ds_read_u8 %4, %12 offset:2\n\tds_read_u8_d16_hi %5, %12 offset:5\n\t"
-                 "ds_read_u8 %6, %12 offset:%13\n\tds_read_u8_d16_hi %7, %12 offset:%16\n\t"
-                 "ds_read_u8 %8, %12 offset:%14\n\tds_read_u8_d16_hi %9, %12 offset:%17\n\t"
-                 "ds_read_u8 %10, %12 offset:%15\n\tds_read_u8_d16_hi %11, %12 offset:%18"
-                 : "=&v"(t.lo[0]), "=&v"(t.hi[0]), "=&v"(t.lo[1]), "=&v"(t.hi[1]), "=&v"(t.lo[2]), "=&v"(t.hi[2]),
-                   "=&v"(t.lo[3]), "=&v"(t.hi[3]), "=&v"(t.lo[4]), "=&v"(t.hi[4]), "=&v"(t.lo[5]), "=&v"(t.hi[5])
-                 : "v"(at), "n"(PITCH), "n"(PITCH + 1), "n"(PITCH + 2), "n"(PITCH + 3), "n"(PITCH + 4), "n"(PITCH + 5));
+    return umad24(byj >> 5, (uint32_t)PITCH, umad24(bxj >> 5, 3u, 0u - lds_origin - MAGIC_HI * (3u + (uint32_t)PITCH)));
 }
 
-// Waits for every LDS load in flight and hands the registers of two pixels to the compiler as ready (it does not see the loads).
-__device__ __forceinline__ void taps_wait(TapRegs& t, TapRegs& u)
+// The 24 byte loads of TWO pixels and their wait in ONE asm block: the compiler does not see LDS loads issued from inline asm, so nothing
+// -- no copy, no spill, no reordering under another compiler version or flag -- can come between a load and the wait that makes its
+// register valid.  (Row pitch in the immediates: one instantiation per window layout.)
+#define MF_TAP_LOADS(R0, R1, R2, R3, R4, R5, R6, R7, R8, R9, R10, R11, A, P0, P1, P2, P3, P4, P5)                                    \
+    "ds_read_u8 " R0 ", " A " offset:0\n\tds_read_u8_d16_hi " R1 ", " A " offset:3\n\t"                                              \
+    "ds_read_u8 " R2 ", " A " offset:1\n\tds_read_u8_d16_hi " R3 ", " A " offset:4\n\t"                                              \
+    "ds_read_u8 " R4 ", " A " offset:2\n\tds_read_u8_d16_hi " R5 ", " A " offset:5\n\t"                                              \
+    "ds_read_u8 " R6 ", " A " offset:" P0 "\n\tds_read_u8_d16_hi " R7 ", " A " offset:" P3 "\n\t"                                    \
+    "ds_read_u8 " R8 ", " A " offset:" P1 "\n\tds_read_u8_d16_hi " R9 ", " A " offset:" P4 "\n\t"                                    \
+    "ds_read_u8 " R10 ", " A " offset:" P2 "\n\tds_read_u8_d16_hi " R11 ", " A " offset:" P5 "\n\t"
+#define MF_TAP_PAIR_ASM(P0, P1, P2, P3, P4, P5)                                                                                     \
+    asm volatile(MF_TAP_LOADS("%0", "%1", "%2", "%3", "%4", "%5", "%6", "%7", "%8", "%9", "%10", "%11", "%24", P0, P1, P2, P3, P4, P5)   \
+                 MF_TAP_LOADS("%12", "%13", "%14", "%15", "%16", "%17", "%18", "%19", "%20", "%21", "%22", "%23", "%25", P0, P1, P2, P3, P4, P5) \
+                 "s_waitcnt lgkmcnt(0)"                                                                                             \
+                 : "=&v"(t.lo[0]), "=&v"(t.hi[0]), "=&v"(t.lo[1]), "=&v"(t.hi[1]), "=&v"(t.lo[2]), "=&v"(t.hi[2]),                  \
+                   "=&v"(t.lo[3]), "=&v"(t.hi[3]), "=&v"(t.lo[4]), "=&v"(t.hi[4]), "=&v"(t.lo[5]), "=&v"(t.hi[5]),                  \
+                   "=&v"(u.lo[0]), "=&v"(u.hi[0]), "=&v"(u.lo[1]), "=&v"(u.hi[1]), "=&v"(u.lo[2]), "=&v"(u.hi[2]),                  \
+                   "=&v"(u.lo[3]), "=&v"(u.hi[3]), "=&v"(u.lo[4]), "=&v"(u.hi[4]), "=&v"(u.lo[5]), "=&v"(u.hi[5])                   \
+                 : "v"(at0), "v"(at1) : "memory")
+template <int PITCH>
+__device__ __forceinline__ void taps_pair(uint32_t at0, uint32_t at1, TapRegs& t, TapRegs& u)
 {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(t.lo[0]), "+v"(t.hi[0]), "+v"(t.lo[1]), "+v"(t.hi[1]), "+v"(t.lo[2]), "+v"(t.hi[2]),
-                   "+v"(t.lo[3]), "+v"(t.hi[3]), "+v"(t.lo[4]), "+v"(t.hi[4]), "+v"(t.lo[5]), "+v"(t.hi[5]),
-                   "+v"(u.lo[0]), "+v"(u.hi[0]), "+v"(u.lo[1]), "+v"(u.hi[1]), "+v"(u.lo[2]), "+v"(u.hi[2]),
-                   "+v"(u.lo[3]), "+v"(u.hi[3]), "+v"(u.lo[4]), "+v"(u.hi[4]), "+v"(u.lo[5]), "+v"(u.hi[5]) :: "memory");
+    static_assert(PITCH == MF_STAGE_PITCH || PITCH == MF_COMPACT_PITCH, "one asm string per window pitch");
+    static_assert(MF_STAGE_PITCH == 160 && MF_COMPACT_PITCH == 112, "the immediate offsets below are the pitch + 0..5");
+    if (PITCH == MF_STAGE_PITCH) MF_TAP_PAIR_ASM("160", "161", "162", "163", "164", "165");
+    else MF_TAP_PAIR_ASM("112", "113", "114", "115", "116", "117");
 }
 
 __device__ __forceinline__ void blend_pixel(uint32_t bxj, uint32_t byj, const TapRegs& t, uint32_t& oB, uint32_t& oG, uint32_t& oR)
@@ -444,9 +454,7 @@ __device__ __forceinline__ void gather_blend_sums(const uint32_t (&bx)[4], const
 #pragma unroll
     for (int j = 0; j < 4; j += 2) {
         TapRegs t0, t1;
-        taps_issue<PITCH>(bx[j], by[j], lds_origin, t0);
-        taps_issue<PITCH>(bx[j + 1], by[j + 1], lds_origin, t1);
-        taps_wait(t0, t1);
+        taps_pair<PITCH>(tap_address<PITCH>(bx[j], by[j], lds_origin), tap_address<PITCH>(bx[j + 1], by[j + 1], lds_origin), t0, t1);
         blend_pixel(bx[j], by[j], t0, oB[j], oG[j], oR[j]);
         blend_pixel(bx[j + 1], by[j + 1], t1, oB[j + 1], oG[j + 1], oR[j + 1]);
     }
