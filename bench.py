@@ -387,7 +387,9 @@ def main():
     # would be 2312 and config 3's 2178 series fill it): a sweep that fills the chip just takes the warp kernel's units away, and the
     # warp kernel's HIP-event time (the roofline figure) would then include the sweep.
     main_stream = torch.cuda.current_stream(device)
-    overlap_jacobi = int(d_disp[0].numel()) * max(1, -(-F // 320)) <= 1024
+    # (N > 1, and the one-GPU rehearsal of a rank of N: the replicated sweep grows with the clip -- 0.2 ms at 2400 frames -- and is what caps
+    # weak scaling, so it always goes under the previous step's warp there; that line's roofline figure then includes the interference.)
+    overlap_jacobi = int(d_disp[0].numel()) * max(1, -(-F // 320)) <= 1024 or world > 1 or args.as_rank_of > 1
     side = torch.cuda.Stream(device=device) if overlap_jacobi else main_stream
 
     def jacobi_fn():
