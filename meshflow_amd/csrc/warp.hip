@@ -1253,27 +1253,31 @@ __global__ void selftest_fast64_kernel(unsigned long long n, unsigned long long 
         // near-identity inverse homography with shift, shear and perspective terms up to what the certificates admit
         const double amp = (i & 3) == 0 ? 1.0 : 0.1;             // a quarter of the cases at the limits
         double Hi[9] = { 1.0 + 0.2 * amp * r[0], 0.2 * amp * r[1], 80.0 * r[2], 0.2 * amp * r[3], 1.0 + 0.2 * amp * r[4], 80.0 * r[5],
-                         2.0e-4 * amp * r[6], 2.0e-4 * amp * r[7], 1.0 };
+                         2.0e-4 * amp * r[6], 2.0e-4 * amp * r[7], 1.0 + 0.3 * amp * r[10] };
         const double xs0 = (double)(4 * (int)((r[8] * 0.5 + 0.5) * 2047.0)), yy = (double)(int)((r[9] * 0.5 + 0.5) * 8191.0);
-        // the premises, in float64 on the lane's four pixels (the plan checks them on the footprint's corners)
+        // the premises, in float64 on the lane's four pixels (the plan checks them on the footprint's corners); half of the cases
+        // step along y (the transposed lanes of the pair path)
+        const bool vert = ((i >> 2) & 1) != 0;
+        const double x0d = vert ? (double)(int)((r[8] * 0.5 + 0.5) * 8191.0) : xs0, y0d = vert ? (double)(4 * (int)((r[9] * 0.5 + 0.5) * 2047.0)) : yy;
         bool ok = true;
         for (int j = 0; j < 4 && ok; ++j) {
-            const double x = xs0 + j;
-            const double w = (x * Hi[6] + yy * Hi[7]) + Hi[8];
-            const double nx = (x * Hi[0] + yy * Hi[1]) + Hi[2], ny = (x * Hi[3] + yy * Hi[4]) + Hi[5];
-            ok = w > 0.52 && w < 1.9 && fabs(Hi[6]) <= 0.9 * RECIP_GUESS_LIMIT * (w * w) &&
-                 fabs(Hi[0]) * x + fabs(Hi[1]) * yy + fabs(Hi[2]) <= 8.0 * nx && fabs(Hi[3]) * x + fabs(Hi[4]) * yy + fabs(Hi[5]) <= 8.0 * ny &&
-                 fabs(Hi[6]) * x + fabs(Hi[7]) * yy + fabs(Hi[8]) <= 2.5 && nx / w >= 1.0 && ny / w >= 1.0 && nx / w < 32768.0 && ny / w < 32768.0;
+            const double x = vert ? x0d : x0d + j, y = vert ? y0d + j : y0d;
+            const double w = (x * Hi[6] + y * Hi[7]) + Hi[8];
+            const double nx = (x * Hi[0] + y * Hi[1]) + Hi[2], ny = (x * Hi[3] + y * Hi[4]) + Hi[5];
+            ok = w > 0.52 && w < 1.9 &&
+                 fabs(Hi[0]) * x + fabs(Hi[1]) * y + fabs(Hi[2]) <= 8.0 * nx && fabs(Hi[3]) * x + fabs(Hi[4]) * y + fabs(Hi[5]) <= 8.0 * ny &&
+                 fabs(Hi[6]) * x + fabs(Hi[7]) * y + fabs(Hi[8]) <= 2.5 && nx / w >= 1.0 && ny / w >= 1.0 && nx / w < 32768.0 && ny / w < 32768.0;
         }
         if (!ok) continue;
         float u[4], v[4];
         uint32_t keys[8];
-        (void)coords_fast(Hi, xs0, yy, u, v, keys);
+        if (vert) (void)coords_fast_dir<true>(Hi, x0d, y0d, u, v, keys);
+        else (void)coords_fast_dir<false>(Hi, x0d, y0d, u, v, keys);
         for (int j = 0; j < 4; ++j) {
-            const double x = xs0 + j;
-            const double w = (x * Hi[6] + yy * Hi[7]) + Hi[8];
+            const double x = vert ? x0d : x0d + j, y = vert ? y0d + j : y0d;
+            const double w = (x * Hi[6] + y * Hi[7]) + Hi[8];
             const double iw = 1.0 / w;
-            const float ue = (float)(((x * Hi[0] + yy * Hi[1]) + Hi[2]) * iw), ve = (float)(((x * Hi[3] + yy * Hi[4]) + Hi[5]) * iw);
+            const float ue = (float)(((x * Hi[0] + y * Hi[1]) + Hi[2]) * iw), ve = (float)(((x * Hi[3] + y * Hi[4]) + Hi[5]) * iw);
             tested += 2;
             if (keys[2 * j] < FAST64_NEAR) ++flagged; else if (__float_as_uint(ue) != __float_as_uint(u[j])) ++missed;
             if (keys[2 * j + 1] < FAST64_NEAR) ++flagged; else if (__float_as_uint(ve) != __float_as_uint(v[j])) ++missed;
