@@ -19,6 +19,8 @@
 //   median_blur_kernel     3x3 median of the raw velocities (replicated borders), one thread per (pair, vertex)
 //   accumulate_kernel      running sum over the pairs, one thread per (vertex, component): the additions must
 //                          stay sequential in time to round like the reference
+#include <stdlib.h>
+
 #include "mf_common.h"
 
 namespace mf {
@@ -255,6 +257,116 @@ __global__ __launch_bounds__(256) void vertex_median_kernel(const unsigned long 
     }
 }
 
+// The same result for a whole MESH ROW per wavefront (pair p, row r: its C + 1 vertices share the row's spans and the pair's two sorted
+// orders), reading every span ONCE per order instead of once per vertex and order:
+//   pass over the sorted-x order, 64 features at a time: every lane adds its feature's column interval to a difference array in LDS
+//     (two ds_add: +1 at `first`, -1 behind `last`), a wave prefix sum turns it into the chunk's count per column, and the running
+//     totals BEFORE each chunk go to a table cum[chunk][column]; the same over the sorted-y order;
+//   per column: the chunk that holds covering feature number (n-1)/2 (and n/2) is found in the table, and only that chunk is read
+//     again to pick the key -- statistics.median (mfs.py:338-353) of exactly the same features in exactly the same order as the
+//     per-vertex kernel above.
+// 17 x fewer span gathers at a 16 x 16 mesh.  For up to 64 chunks (4096 features per pair) and 64 columns; the per-vertex kernel
+// takes everything else.
+constexpr int kRowChunks = 64;
+// (workgroup = two wavefronts: wavefront 0 works through the sorted-x order, wavefront 1 through the sorted-y order, both the counting
+// pass and the per-column picks; they meet once, before the output)
+__global__ __launch_bounds__(128) void vertex_row_median_kernel(const unsigned long long* __restrict__ skey, const uint32_t* __restrict__ sidx,
+                                                                const Span* __restrict__ spans, const int32_t* __restrict__ offsets,
+                                                                const double* __restrict__ hom, int W, int H, int R, int C,
+                                                                size_t total_features, int npad, float2* __restrict__ raw)
+{
+    extern __shared__ int s_row[];                           // cum[2][nch + 1][C1] | diff[2][C1 + 1] | med[2][C1] (double)
+    const int lane = threadIdx.x & 63;
+    const int ax = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int C1 = C + 1;
+    const int p = blockIdx.x / (R + 1), r = blockIdx.x - p * (R + 1);
+    const int k0 = offsets[p], K = offsets[p + 1] - k0;
+    const int nch = (K + 63) >> 6;
+    const Span* __restrict__ row_spans = spans + (size_t)r * total_features + k0;
+    int* table = s_row + ax * (nch + 1) * C1;
+    int* diff = s_row + 2 * (nch + 1) * C1 + ax * (C1 + 1);
+    double* med = reinterpret_cast<double*>(s_row + ((2 * (nch + 1) * C1 + 2 * (C1 + 1) + 1) & ~1));
+    const unsigned long long* __restrict__ keys = skey + (size_t)(2 * p + ax) * npad;
+    const uint32_t* __restrict__ order = sidx + (size_t)(2 * p + ax) * npad;
+
+    int running = 0;                                         // lane c: covering features of column c so far
+    for (int i = 0; i < nch; ++i) {
+        if (lane < C1) table[i * C1 + lane] = running;
+        if (lane <= C1) diff[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (this wavefront's own LDS region: its LDS operations execute in order)
+        const int j = (i << 6) + lane;
+        if (j < K) {
+            const Span sp = row_spans[order[j]];
+            if (sp.first <= sp.last) {                       // (0 <= first <= last <= C for a non-empty span)
+                atomicAdd(&diff[sp.first], 1);
+                atomicAdd(&diff[sp.last + 1], -1);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (this wavefront's own LDS region: its LDS operations execute in order)
+        int v = lane < C1 ? diff[lane] : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(v, off);
+            if (lane >= off) v += t;
+        }
+        running += v;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (this wavefront's own LDS region: its LDS operations execute in order)
+    }
+    if (lane < C1) table[nch * C1 + lane] = running;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    double mine_med = 0.0;                                   // lane c keeps column c's median on this wavefront's axis
+    for (int c = 0; c < C1; ++c) {
+        const int n = table[nch * C1 + c];
+        if (n == 0) continue;                                 // (wave-uniform)
+        const int k1 = (n - 1) >> 1, k2 = n >> 1;
+        unsigned long long key[2];
+        for (int q = 0; q < 2; ++q) {
+            const int k = q ? k2 : k1;
+            if (q && k2 == k1) { key[1] = key[0]; continue; }
+            // the chunk with cum[i] <= k < cum[i + 1]
+            const bool here = lane < nch && table[lane * C1 + c] <= k && k < table[(lane + 1) * C1 + c];
+            const int i = __ffsll((long long)__ballot(here)) - 1;
+            const int before_chunk = table[i * C1 + c];
+            const int j = (i << 6) + lane;
+            bool cover = false;
+            unsigned long long kj = 0ull;
+            if (j < K) {
+                const Span sp = row_spans[order[j]];
+                cover = sp.first <= c && c <= sp.last;
+                kj = keys[j];
+            }
+            const unsigned long long m = __ballot(cover);
+            const int before = __popcll(m & ((1ull << lane) - 1ull));
+            const unsigned long long hit = __ballot(cover && before_chunk + before == k);
+            key[q] = __shfl(kj, __ffsll((long long)hit) - 1);
+        }
+        const double mv = (n & 1) ? value_of(key[0]) : (value_of(key[0]) + value_of(key[1])) / 2.0;
+        if (lane == c) mine_med = mv;
+    }
+    if (lane < C1) med[ax * C1 + lane] = mine_med;
+    __syncthreads();
+
+    // + the vertex's global motion (mfs.py:324-328, 354-355): lane c of wavefront 0 writes vertex (r, c)
+    if (ax == 0 && lane < C1) {
+        const int c = lane;
+        const double medx = med[c], medy = med[C1 + c];
+        const double* __restrict__ m = hom + 9 * (size_t)p;
+        const float gxf = (float)ceil((double)(W - 1) * ((double)c / (double)C));
+        const float gyf = (float)ceil((double)(H - 1) * ((double)r / (double)R));
+        const double gx = (double)gxf, gy = (double)gyf;
+        const double w = (gx * m[6] + gy * m[7]) + m[8];
+        float px = 0.0f, py = 0.0f;
+        if (fabs(w) > 1.1920928955078125e-07) {
+            const double iw = 1.0 / w;
+            px = (float)(((gx * m[0] + gy * m[1]) + m[2]) * iw);
+            py = (float)(((gx * m[3] + gy * m[4]) + m[5]) * iw);
+        }
+        const float globx = px - gxf, globy = py - gyf;
+        raw[(size_t)p * (R + 1) * C1 + (size_t)r * C1 + c] = make_float2((float)((double)globx + medx), (float)((double)globy + medy));
+    }
+}
+
 __device__ __forceinline__ void order(float& a, float& b)
 {
     const float lo = fminf(a, b), hi = fmaxf(a, b);
@@ -385,8 +497,16 @@ int launch_vertex_motion(const double* early, const double* late, const int32_t*
                 MF_HIP_TRY(hipGetLastError());
             }
         }
-        vertex_median_kernel<<<(P * V + 3) / 4, 256, 0, st>>>(w.skey, w.sidx, w.spans, offsets, hom, P, W, H, R, C,
-                                                            (size_t)total_features, npad, w.raw);
+        static const bool per_vertex = [] { const char* v = getenv("MF_MEDIAN_PER_VERTEX"); return v && *v == '1'; }();   // testing aid
+        const int nch_max = (max_per_pair + 63) / 64;
+        if (!per_vertex && nch_max <= kRowChunks && C + 1 <= 64) {
+            const size_t lds = ((size_t)2 * (nch_max + 1) * (C + 1) + 2 * (C + 2) + 2) * sizeof(int) + (size_t)2 * (C + 1) * sizeof(double);
+            vertex_row_median_kernel<<<P * (R + 1), 128, lds, st>>>(w.skey, w.sidx, w.spans, offsets, hom, W, H, R, C,
+                                                                   (size_t)total_features, npad, w.raw);
+        } else {
+            vertex_median_kernel<<<(P * V + 3) / 4, 256, 0, st>>>(w.skey, w.sidx, w.spans, offsets, hom, P, W, H, R, C,
+                                                                (size_t)total_features, npad, w.raw);
+        }
         MF_HIP_TRY(hipGetLastError());
         median_blur_kernel<<<(P * V + 255) / 256, 256, 0, st>>>(w.raw, (float2*)vel, P, R, C);
         MF_HIP_TRY(hipGetLastError());
