@@ -493,7 +493,7 @@ def main():
             torch.cuda.synchronize()
             ops.vertex_motion_check(status)
             motion_ms = m0.elapsed_time(m1) / 3
-            motion_row = {'kernels': 'feature_prep + bitonic sort + vertex_median + median_blur + accumulate',
+            motion_row = {'kernels': 'feature_prep + bitonic sort + vertex_row_median + median_blur + accumulate',
                           'avg_ms': motion_ms, 'frame_pairs': Fm - 1, 'features': int(early.shape[0]),
                           'pairs_per_s': (Fm - 1) / (motion_ms * 1e-3),
                           'note': 'outside the timed region; latency/ALU bound (no meaningful HBM roofline: 14 MB of features)'}

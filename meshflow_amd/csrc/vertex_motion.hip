@@ -13,6 +13,9 @@
 //                          mesh row, the column range its ellipse covers
 //   bitonic_*_kernel       per frame pair, the features' x keys and y keys sorted once (LDS bitonic network on
 //                          4096-element tiles; global compare-exchange steps only for pairs with more features)
+//   vertex_row_median_kernel  one workgroup per (pair, mesh row): per-chunk counts of covering features per column from a difference
+//                          array, then the median chunk of every column read once more -- statistics.median of every vertex of the
+//                          row with ONE gather per feature and order (the per-vertex kernel below remains for oversized inputs)
 //   vertex_median_kernel   one wavefront per (pair, vertex): counts the covering features, then walks the pair's
 //                          sorted order until the middle covering feature(s) -- statistics.median without building
 //                          or sorting a per-vertex list -- and adds the vertex's global motion
