@@ -292,6 +292,8 @@ def main():
                          '"clips" = N independent clips, one per GPU, no collective (BASELINE config 5); '
                          '"e2e" = host frames in -> host frames out, PCIe both ways (N independent clips when N > 1)')
     ap.add_argument('--no-e2e', action='store_true', help='skip the host-buffers-in / host-buffers-out side measurement (N = 1 only)')
+    ap.add_argument('--jacobi-stream', default='auto', choices=['auto', 'main', 'side'], help='tuning aid: where the Jacobi sweep of a step is issued '
+                    '(auto: the rule in main())')
     ap.add_argument('--checksum', action='store_true', help='add `frames_checksum` to the line: one position-weighted 63-bit sum per stabilized '
                     'frame of the last step (the gathered clip on rank 0 when the gather ran, else this rank\'s shard) -- for the tests')
     ap.add_argument('--as-rank-of', type=int, default=0, metavar='N',
@@ -387,9 +389,12 @@ def main():
     # would be 2312 and config 3's 2178 series fill it): a sweep that fills the chip just takes the warp kernel's units away, and the
     # warp kernel's HIP-event time (the roofline figure) would then include the sweep.
     main_stream = torch.cuda.current_stream(device)
+    gate = {'table_start': None}           # event on the main stream in front of the latest step's cell table
     # (N > 1, and the one-GPU rehearsal of a rank of N: the replicated sweep grows with the clip -- 0.2 ms at 2400 frames -- and is what caps
     # weak scaling, so it always goes under the previous step's warp there; that line's roofline figure then includes the interference.)
     overlap_jacobi = int(d_disp[0].numel()) * max(1, -(-F // 320)) <= 1024 or world > 1 or args.as_rank_of > 1
+    if args.jacobi_stream != 'auto':
+        overlap_jacobi = args.jacobi_stream == 'side'
     side = torch.cuda.Stream(device=device) if overlap_jacobi else main_stream
 
     def jacobi_fn():
@@ -402,6 +407,8 @@ def main():
                 jev[i][1].record()
             return d_stab
         with torch.cuda.stream(side):
+            if gate['table_start'] is not None:
+                side.wait_event(gate['table_start'])   # start with the previous step's cell table + plan, not earlier
             if i is not None:
                 jev[i][0].record(side)
             d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
@@ -415,6 +422,9 @@ def main():
 
     def warp_fn(lo_, hi_, d_stab):
         i = now['i']
+        if overlap_jacobi:
+            gate['table_start'] = torch.cuda.Event()
+            gate['table_start'].record()
         ops.cell_table(d_disp[lo_:hi_], d_stab[lo_:hi_], W, H, R, C, table=table, reset_status=False)
         if i is not None:
             ev[i][0].record()
@@ -432,6 +442,13 @@ def main():
                                                         collective=not clips_mode)
         return d_stab, bounds
 
+    # Clock spin-up, then the W warm-up steps, then the K timed ones back to back.  After an idle period (set-up: milliseconds) this
+    # GPU runs the launches of the following ~2-15 ms 5-25 % slower than in steady state (tools/resize_probe.py shows it launch by
+    # launch; MF_BENCH_PER_STEP=1 shows it here) -- a power-management transient, not a property of the kernels.  ~25 ms of the same
+    # step in front of the warm-up take it out of the timed region; the timed region is still exactly K steps.
+    spinup_steps = min(50, int(np.ceil(25e-3 / max(2.0 * (hi - lo) * H * W * 3 / 3.2e12, 1e-4))))
+    for _ in range(spinup_steps):
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -443,6 +460,8 @@ def main():
     elapsed = max_over_ranks(time.perf_counter() - t0)
 
     warp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if os.environ.get('MF_BENCH_PER_STEP') and rank == 0:          # tuning aid: the launches one by one (clock transients)
+        print('warp ms per step:', [round(a.elapsed_time(b), 3) for a, b in ev], file=sys.stderr)
     jac_ms = float(np.mean([a.elapsed_time(b) for a, b in jev]))
     # Jacobi kernel alone (the per-step figure above includes the host-side coefficient set-up), outside the timed region
     taps_d, lam_d, inv_on_d = stab._jacobi_coefficients_device(F, W, H, 0, hom, device)
@@ -464,14 +483,14 @@ def main():
         r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         scratch = torch.empty_like(d_frames)
         rect = bounds.tolist()                       # one D2H of the 4 bounds, outside the timed launches
-        for _ in range(3):                           # first touches of the fresh output stack + clocks
-            ops.crop_resize(d_out, rect, out=scratch)
+        for _ in range(30):                          # first touches of the fresh output stack + the clock transient after the
+            ops.crop_resize(d_out, rect, out=scratch)    # idle milliseconds of the allocation above (launches 3-20 run up to 40 % slow)
         r0.record()
-        for _ in range(10):
+        for _ in range(20):
             ops.crop_resize(d_out, rect, out=scratch)
         r1.record()
         torch.cuda.synchronize()
-        resize_ms = r0.elapsed_time(r1) / 10
+        resize_ms = r0.elapsed_time(r1) / 20
         del scratch
     # The row before the path, also outside the timed region: matched features -> vertex displacements
     # (mfs.py:236-452 after the tracker), synthetic features for the same number of frame pairs.
@@ -548,7 +567,7 @@ def main():
             'metric': 'frames/sec stabilize() hot path (Jacobi + mesh warp + crop scan), inputs resident in HBM -- the kernel-path figure of '
                       'BASELINE.json\'s metric; its host-to-host figure (PCIe both ways) is `end_to_end`, the warp kernel\'s %HBM-roofline is `roofline`',
             'value': (F * world if clips_mode else F) * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'warmup': args.warmup, 'spinup_steps': spinup_steps, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'dtype_note': 'float64 vertex paths and pixel coordinates (as the reference), integer fixed-point interpolation on uint8',
             'data': f'synthetic ({args.frames_kind} frames, injected random mesh motion, seed 0)',

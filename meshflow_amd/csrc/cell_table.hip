@@ -316,8 +316,8 @@ __device__ __forceinline__ void cell_range_1d(const int* g, int n, int extent, i
 
 // Classification + source region of ONE footprint.  `edge_of(k)` yields the 12 float32 edge coefficients of cell k of this
 // frame, `hi_of(k, out9)` its inverse homography as float32: from LDS when the workgroup staged its cell rows, else global.
-template <typename EdgeOf, typename HiOf, typename MarginOf>
-__device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, MarginOf margin_of, int c_lo, int c_hi, int r_lo, int r_hi,
+template <typename EdgeOf, typename HiOf, typename MarginOf, typename BoxOf>
+__device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, MarginOf margin_of, BoxOf box_of, int c_lo, int c_hi, int r_lo, int r_hi,
                                                    int xa, int xb, int ya, int yb, int W, int H, int C, FootPlan& p, FootRegion& region)
 {
     uint16_t codes[8];
@@ -333,9 +333,27 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
     float single_edge[2][3] = { { 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f } };   // the one uncertain edge of the first two entries
     bool single_ok[2] = { false, false };
     bool coded = true;                                         // every MIXED entry has a one- or two-edge code
-    for (int r = r_hi; r >= r_lo && !closed && !overflow; --r)
-        for (int c = c_hi; c >= c_lo && !closed && !overflow; --c) {
-            const int k = r * C + c;
+    // The candidate range comes from the FRAME's reach (the largest overhang of any cell's box over its grid rect); most of its cells
+    // have a box that does not meet this footprint.  A first cheap pass keeps the cells whose own box does (descending order kept;
+    // up to eight, 16 bits each -- more: the footprint is handed to the warp kernel's generic path like one with more than eight
+    // candidates), so that the classification below runs once per cell that can matter instead of once per cell of the range: the
+    // lanes of a wavefront then loop 1-2 times instead of 4.
+    uint64_t shortlist[2] = { 0, 0 };
+    int boxed = 0;
+    for (int r = r_hi; r >= r_lo; --r)
+        for (int c = c_hi; c >= c_lo; --c) {
+            const CellBox b = box_of(r * C + c);
+            if (b.x0 <= xb && b.x1 >= xa && b.y0 <= yb && b.y1 >= ya) {
+                const uint64_t entry = (uint64_t)(uint32_t)(r * C + c) << (16 * (boxed & 3));
+                if (boxed < 4) shortlist[0] |= entry;
+                else if (boxed < 8) shortlist[1] |= entry;
+                ++boxed;
+            }
+        }
+    overflow = boxed > 8;
+    for (int step = 0; step < boxed && !closed && !overflow; ++step) {
+        const int k = (int)(((step < 4 ? shortlist[0] : shortlist[1]) >> (16 * (step & 3))) & 0xFFFFu);
+        {
             const float* ed = edge_of(k);
             bool all_in = true, any_out = false;
             int uncertain = 0, which = 0, which2 = 0;
@@ -377,6 +395,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
                 vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
             }
         }
+    }
     if (!overflow && cnt <= 4)
         for (int i = 0; i < cnt; ++i) p.e[4 + i] = codes[i];      // short list: room for the per-entry edge codes
     if (cnt == 1 && closed && sane && wlo > 0.52f && whi < 1.9f && fabsf(h6_first) <= 0.9f * 2.5e-4f * (wlo * wlo))
@@ -482,7 +501,7 @@ constexpr int kPlanStageCells = 256;          // cells (whole mesh rows) a workg
 // footprints, which only meet a few mesh rows.  Those rows' edge functions and inverse homographies are staged in LDS once
 // (the per-footprint loops then run on LDS latency instead of dependent L2 round trips); when they do not fit, from global.
 __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __restrict__ uedges, const float* __restrict__ edges,
-                                                             const double* __restrict__ records,
+                                                             const double* __restrict__ records, const CellBox* __restrict__ boxes,
                                                              const int32_t* __restrict__ reach,
                                                              const int32_t* __restrict__ grid, int n, int W, int H, int R,
                                                              int C, FootPlan* __restrict__ plan, FootRegion* __restrict__ regions)
@@ -490,6 +509,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     __shared__ int s_gx[66], s_gy[66];
     __shared__ float s_edge[kPlanStageCells * MF_UEDGE_FLOATS];
     __shared__ float s_hi[kPlanStageCells * 9];
+    __shared__ CellBox s_box[kPlanStageCells];
     if ((int)threadIdx.x <= C) s_gx[threadIdx.x] = grid[threadIdx.x];
     if ((int)threadIdx.x <= R) s_gy[threadIdx.x] = grid[C + 1 + threadIdx.x];
     __syncthreads();
@@ -502,6 +522,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     const float* __restrict__ fedge = uedges + (size_t)f * R * C * MF_UEDGE_FLOATS;
     const float* __restrict__ fmargin = edges + (size_t)f * R * C * MF_EDGE_FLOATS + 12;      // the scaled set's error bounds
     const double* __restrict__ frec = records + (size_t)f * R * C * MF_CELL_DOUBLES;
+    const CellBox* __restrict__ fbox = boxes + (size_t)f * R * C;
 
     // mesh rows the workgroup's footprints can meet (same widening by the frame's reach as per footprint)
     const int ya0 = (rem0 / nfx) * MF_FOOT_H, yb1 = min((min(rem0 + 255, per_frame - 1) / nfx) * MF_FOOT_H + MF_FOOT_H - 1, H - 1);
@@ -513,6 +534,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     if (staged) {
         const int k0 = rb_lo * C;
         for (int i = threadIdx.x; i < staged_cells * MF_UEDGE_FLOATS; i += 256) s_edge[i] = fedge[(size_t)k0 * MF_UEDGE_FLOATS + i];
+        for (int i = threadIdx.x; i < staged_cells; i += 256) s_box[i] = fbox[k0 + i];
         for (int i = threadIdx.x; i < staged_cells * 9; i += 256) {
             const int cell = i / 9, j = i - 9 * cell;
             s_hi[i] = (float)frec[(size_t)(k0 + cell) * MF_CELL_DOUBLES + MF_CELL_OFF_HI + j];
@@ -552,6 +574,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
         plan_one_footprint([&](int k) { return (const float*)&s_edge[(k - k0) * MF_UEDGE_FLOATS]; },
                            [&](int k, float (&h)[9]) { for (int j = 0; j < 9; ++j) h[j] = s_hi[(k - k0) * 9 + j]; },
                            [&](int k, int e) { return fmargin[(size_t)k * MF_EDGE_FLOATS + e]; },
+                           [&](int k) { return s_box[k - k0]; },
                            c_lo, c_hi, r_lo, r_hi, xa, xb, ya, yb, W, H, C, p, region);
     } else {
         plan_one_footprint([&](int k) { return fedge + (size_t)k * MF_UEDGE_FLOATS; },
@@ -560,6 +583,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
                                for (int j = 0; j < 9; ++j) h[j] = (float)hi[j];
                            },
                            [&](int k, int e) { return fmargin[(size_t)k * MF_EDGE_FLOATS + e]; },
+                           [&](int k) { return fbox[k]; },
                            c_lo, c_hi, r_lo, r_hi, xa, xb, ya, yb, W, H, C, p, region);
     }
     const size_t gid = (size_t)f * per_frame + rem;
@@ -585,7 +609,7 @@ int launch_cell_table(const double* unstab, const double* stab, int n, int W, in
     int rc = hip_fail(hipGetLastError(), "cell_table_kernel launch");
     if (rc != MF_OK) return rc;
     const size_t per_frame = plan_count(1, W, H);
-    hipLaunchKernelGGL(footprint_plan_kernel, dim3((unsigned)(((per_frame + 255) / 256) * (size_t)n)), dim3(256), 0, st, tv.uedges, tv.edges, tv.records,
+    hipLaunchKernelGGL(footprint_plan_kernel, dim3((unsigned)(((per_frame + 255) / 256) * (size_t)n)), dim3(256), 0, st, tv.uedges, tv.edges, tv.records, tv.boxes,
                        tv.reach, tv.grid, n, W, H, R, C, tv.plan, tv.regions);
     return hip_fail(hipGetLastError(), "footprint_plan_kernel launch");
 }

@@ -31,3 +31,12 @@ scratch = torch.empty_like(d_frames)
 print('fresh scratch, per launch:', series(d_out, scratch))
 print('10 back to back          :', block(d_out, scratch), block(d_out, scratch))
 print('into d_frames            :', block(d_out, d_frames))
+# what bench.py does before its resize loop: a synchronize, six Jacobi launches (578 wavefronts: most of the chip idle), a synchronize
+import time
+taps_d, lam_d, inv_on_d = s._jacobi_coefficients_device(F, W, H, 0, hom, dev)
+b2d = d_disp.reshape(F, -1); x2d = torch.empty_like(b2d)
+for idle_ms in (0, 5, 50):
+    torch.cuda.synchronize()
+    for _ in range(6): ops.jacobi(b2d, taps_d, lam_d, inv_on_d, 10, 100, out=x2d)
+    torch.cuda.synchronize(); time.sleep(idle_ms * 1e-3)
+    print(f'after jacobi x6 + sync + {idle_ms} ms idle, per launch:', series(d_out, scratch, 24))
