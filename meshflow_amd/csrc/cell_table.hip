@@ -320,18 +320,16 @@ template <typename EdgeOf, typename HiOf, typename MarginOf, typename BoxOf>
 __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, MarginOf margin_of, BoxOf box_of, int c_lo, int c_hi, int r_lo, int r_hi,
                                                    int xa, int xb, int ya, int yb, int W, int H, int C, FootPlan& p, FootRegion& region)
 {
-    uint16_t codes[8];
-    for (int i = 0; i < 8; ++i) { p.e[i] = 0; codes[i] = 0; }
+    // list entries and their edge codes, four 16-bit fields per register pair (entries 4-7 in the second): a dynamically indexed
+    // uint16_t[8] would live in scratch memory
+    uint64_t ent[2] = { 0, 0 }, codes = 0;
     int cnt = 0;
     bool overflow = false, closed = false;
     const float cxs[2] = { (float)xa, (float)xb }, cys[2] = { (float)ya, (float)yb };
     const float cxm = 0.5f * (cxs[0] + cxs[1]), cxh = 0.5f * (cxs[1] - cxs[0]), cym = 0.5f * (cys[0] + cys[1]), cyh = 0.5f * (cys[1] - cys[0]);
     float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
     bool sane = true;
-    float wlo = 1e30f, whi = -1e30f, h6_first = 0.0f;          // denominator range of the FIRST listed cell over the footprint
-    float wlo_all = 1e30f, whi_all = -1e30f;                   // ... and of every listed cell
-    float single_edge[2][3] = { { 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f } };   // the one uncertain edge of the first two entries
-    bool single_ok[2] = { false, false };
+    float wlo_all = 1e30f, whi_all = -1e30f;                   // denominator range of every listed cell over the footprint
     bool coded = true;                                         // every MIXED entry has a one- or two-edge code
     // The candidate range comes from the FRAME's reach (the largest overhang of any cell's box over its grid rect); most of its cells
     // have a box that does not meet this footprint.  A first cheap pass keeps the cells whose own box does (descending order kept;
@@ -370,13 +368,12 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             }
             if (any_out) continue;
             if (cnt == 8) { overflow = true; break; }
-            if (cnt < 2 && uncertain == 1) {
-                single_ok[cnt] = true;
-                for (int q = 0; q < 3; ++q) single_edge[cnt][q] = ed[3 * which + q];
-            }
-            codes[cnt] = (uint16_t)(MF_PLAN_CODES | (uncertain == 1 ? which : uncertain == 2 ? (8 | which2 | (which << 4)) : 4));
+            const uint32_t code = MF_PLAN_CODES | (uint32_t)(uncertain == 1 ? which : uncertain == 2 ? (8 | which2 | (which << 4)) : 4);
+            if (cnt < 4) codes |= (uint64_t)code << (16 * cnt);
             coded = coded && (all_in || uncertain == 1 || uncertain == 2);
-            p.e[cnt++] = (uint16_t)(k | MF_PLAN_VALID | (all_in ? MF_PLAN_IN : 0u));
+            const uint64_t entry = (uint64_t)((uint32_t)k | MF_PLAN_VALID | (all_in ? MF_PLAN_IN : 0u)) << (16 * (cnt & 3));
+            if (cnt < 4) ent[0] |= entry; else ent[1] |= entry;
+            ++cnt;
             if (all_in) closed = true;
             // source position of the four footprint corners under this cell's inverse homography (float32 is ample:
             // the window keeps 1/16 pixel of slack, the float32 error at coordinates up to 8192 is below 0.01)
@@ -387,7 +384,6 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
                 const float w = h[6] * cx + h[7] * cy + h[8];
                 sane = sane && w > 0.25f && w < 4.0f;                     // (NaN fails)
                 const float nx = h[0] * cx + h[1] * cy + h[2], ny = h[3] * cx + h[4] * cy + h[5];
-                if (cnt == 1) { wlo = fminf(wlo, w); whi = fmaxf(whi, w); h6_first = h[6]; }
                 wlo_all = fminf(wlo_all, w); whi_all = fmaxf(whi_all, w);
                 const float iw = __builtin_amdgcn_rcpf(w);            // (1 ulp: the window keeps a sixteenth of a pixel of slack)
                 const float u = nx * iw, v = ny * iw;
@@ -396,10 +392,21 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             }
         }
     }
+    for (int i = 0; i < 4; ++i) { p.e[i] = (uint16_t)(ent[0] >> (16 * i)); p.e[4 + i] = (uint16_t)(ent[1] >> (16 * i)); }
     if (!overflow && cnt <= 4)
-        for (int i = 0; i < cnt; ++i) p.e[4 + i] = codes[i];      // short list: room for the per-entry edge codes
-    if (cnt == 1 && closed && sane && wlo > 0.52f && whi < 1.9f && fabsf(h6_first) <= 0.9f * 2.5e-4f * (wlo * wlo))
-        p.e[1] = (uint16_t)MF_PLAN_UNIT;                           // (float32 evaluation: 1e-6 of error against margins of 4 % and 10 %)
+        for (int i = 0; i < 4; ++i) p.e[4 + i] = (uint16_t)(codes >> (16 * i));      // short list: room for the per-entry edge codes
+    if (cnt == 1 && closed && sane) {
+        // one cell owns the footprint: its denominator range over the footprint (corners) and h6, for the warp kernel's reciprocal guess
+        float h[9];
+        hi_of((int)(p.e[0] & 0xFFFu), h);
+        float wlo = 1e30f, whi = -1e30f;
+        for (int q = 0; q < 4; ++q) {
+            const float w = h[6] * cxs[q & 1] + h[7] * cys[q >> 1] + h[8];
+            wlo = fminf(wlo, w); whi = fmaxf(whi, w);
+        }
+        if (wlo > 0.52f && whi < 1.9f && fabsf(h[6]) <= 0.9f * 2.5e-4f * (wlo * wlo))
+            p.e[1] = (uint16_t)MF_PLAN_UNIT;                       // (float32 evaluation: 1e-6 of error against margins of 4 % and 10 %)
+    }
     if (overflow) {
         // more than 8 candidates: hand the whole range to the warp kernel instead
         p.e[0] = (uint16_t)r_lo; p.e[1] = (uint16_t)r_hi; p.e[2] = (uint16_t)c_lo; p.e[3] = (uint16_t)c_hi;
@@ -409,14 +416,21 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
     // without owner would fail both, g0 <= m0 and g1 <= m1 (the kernel's float32 error bands of the two edges).  g0 + g1 is affine,
     // so if it exceeds m0 + m1 + 1 at the four corners it does everywhere and every pixel has an owner -- the footprint can be
     // certified like one whose list ends with an IN cell.
+    const uint32_t code0 = (uint32_t)codes & 0xFFFFu, code1 = (uint32_t)(codes >> 16) & 0xFFFFu;
+    const bool single_ok[2] = { cnt >= 1 && (code0 & 0xCu) == 0, cnt >= 2 && (code1 & 0xCu) == 0 };       // ONE uncertain edge: codes 0-3
+    float single_edge0[3] = { 0.0f, 0.0f, 0.0f };                  // the one uncertain edge of the first entry
     bool covered = closed;
-    if (!closed && !overflow && cnt == 2 && single_ok[0] && single_ok[1]) {
-        const float a = single_edge[0][0] + single_edge[1][0], b = single_edge[0][1] + single_edge[1][1];
-        const float c = single_edge[0][2] + single_edge[1][2];
-        const float gmin = (fminf(a * cxs[0], a * cxs[1]) + fminf(b * cys[0], b * cys[1])) + c;
-        // (the kernel's error bands of the two edges, in the same units: their cells and edge numbers are in the list)
-        const float m0 = margin_of(p.e[0] & 0xFFF, codes[0] & 3), m1 = margin_of(p.e[1] & 0xFFF, codes[1] & 3);
-        covered = gmin > m0 + m1 + 1.0f;
+    if (!overflow && cnt == 2 && single_ok[0]) {
+        const float* e0 = edge_of((int)(p.e[0] & 0xFFFu)) + 3 * (code0 & 3u);
+        for (int q = 0; q < 3; ++q) single_edge0[q] = e0[q];
+        if (!closed && single_ok[1]) {
+            const float* e1 = edge_of((int)(p.e[1] & 0xFFFu)) + 3 * (code1 & 3u);
+            const float a = e0[0] + e1[0], b = e0[1] + e1[1], c = e0[2] + e1[2];
+            const float gmin = (fminf(a * cxs[0], a * cxs[1]) + fminf(b * cys[0], b * cys[1])) + c;
+            // (the kernel's error bands of the two edges, in the same units: their cells and edge numbers are in the list)
+            const float m0 = margin_of(p.e[0] & 0xFFF, code0 & 3), m1 = margin_of(p.e[1] & 0xFFF, code1 & 3);
+            covered = gmin > m0 + m1 + 1.0f;
+        }
     }
     region.flags_origin = 0;
     region.src_dwords = 0;
@@ -482,7 +496,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
                 // PAIR_VERT: the deciding edge a x + b y + c runs closer to vertical (the warp kernel then transposes its lanes so that a
                 // lane's four pixels run ALONG the edge); PAIR_FAST: both cells satisfy the premises of the kernel's cheap coordinate
                 // chain -- as MF_PLAN_FAST64
-                const bool vert = fabsf(single_edge[0][0]) >= fabsf(single_edge[0][1]);
+                const bool vert = fabsf(single_edge0[0]) >= fabsf(single_edge0[1]);
                 const bool fast = cheap_all;
                 p.e[2] = (uint16_t)(MF_PLAN_HOT | (fast ? MF_PLAN_PAIR_FAST : 0u) | (vert ? MF_PLAN_PAIR_VERT : 0u));
             }
