@@ -379,11 +379,15 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             // the window keeps 1/16 pixel of slack, the float32 error at coordinates up to 8192 is below 0.01)
             float h[9];
             hi_of(k, h);
+            // (fused, the y part shared by the two corners of a footprint row: 18 operations for the twelve values instead of 48)
+            const float wy[2] = { __builtin_fmaf(h[7], cys[0], h[8]), __builtin_fmaf(h[7], cys[1], h[8]) };
+            const float nxy[2] = { __builtin_fmaf(h[1], cys[0], h[2]), __builtin_fmaf(h[1], cys[1], h[2]) };
+            const float nyy[2] = { __builtin_fmaf(h[4], cys[0], h[5]), __builtin_fmaf(h[4], cys[1], h[5]) };
             for (int q = 0; q < 4; ++q) {
-                const float cx = cxs[q & 1], cy = cys[q >> 1];
-                const float w = h[6] * cx + h[7] * cy + h[8];
+                const float cx = cxs[q & 1];
+                const float w = __builtin_fmaf(h[6], cx, wy[q >> 1]);
                 sane = sane && w > 0.25f && w < 4.0f;                     // (NaN fails)
-                const float nx = h[0] * cx + h[1] * cy + h[2], ny = h[3] * cx + h[4] * cy + h[5];
+                const float nx = __builtin_fmaf(h[0], cx, nxy[q >> 1]), ny = __builtin_fmaf(h[3], cx, nyy[q >> 1]);
                 wlo_all = fminf(wlo_all, w); whi_all = fmaxf(whi_all, w);
                 const float iw = __builtin_amdgcn_rcpf(w);            // (1 ulp: the window keeps a sixteenth of a pixel of slack)
                 const float u = nx * iw, v = ny * iw;
