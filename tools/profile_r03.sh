@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-3 rocprofv3 evidence, one call: for cfg2 / cfg3 / cfg4shard the kernel-trace stats of bench.py (50 + 5 steps) and the bench
-# line of an unprofiled run; then the L2-memory-side traffic of warp_kernel (size-resolved read requests + WRITE_SIZE, separate --pmc
+# Round-3 rocprofv3 evidence, one call: for cfg2 / cfg3 / cfg4shard the kernel-trace stats of bench.py (50 + 5 steps, + the spin-up steps) and the bench
+# line of an unprofiled run with the driver's flags (--gpus 1 --steps 20 --warmup 5); then the L2-memory-side traffic of warp_kernel (size-resolved read requests + WRITE_SIZE, separate --pmc
 # passes; cfg3 on a 150-frame slice: the PMC passes on the 600-frame launch crash rocprofv3 itself).  Output: gpurun_out/prof_r03/.
 tag=${1:-r03}
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$tag; mkdir -p $O; cd /tmp
 for W in cfg2 cfg3 cfg4shard; do
-  python3 $R/bench.py --workload $W --no-faithful > $O/bench_${tag}_$W.json 2> $O/bench_$W.err
+  python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --workload $W --no-faithful > $O/bench_${tag}_$W.json 2> $O/bench_$W.err
   rm -rf /tmp/ps
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -o r -- python3 $R/bench.py --steps 50 --warmup 5 --cpu-frames 0 --no-e2e --workload $W > $O/stats_$W.log 2>&1
   grep -E "\"Name\"|mf::" /tmp/ps/r_kernel_stats.csv > $O/${tag}_kernel_stats_$W.csv
