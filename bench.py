@@ -389,7 +389,7 @@ def main():
     # would be 2312 and config 3's 2178 series fill it): a sweep that fills the chip just takes the warp kernel's units away, and the
     # warp kernel's HIP-event time (the roofline figure) would then include the sweep.
     main_stream = torch.cuda.current_stream(device)
-    gate = {'table_start': None}           # event on the main stream in front of the latest step's cell table
+    ends = []                              # end-of-warp events of the last two steps issued
     # (N > 1, and the one-GPU rehearsal of a rank of N: the replicated sweep grows with the clip -- 0.2 ms at 2400 frames -- and is what caps
     # weak scaling, so it always goes under the previous step's warp there; that line's roofline figure then includes the interference.)
     overlap_jacobi = int(d_disp[0].numel()) * max(1, -(-F // 320)) <= 1024 or world > 1 or args.as_rank_of > 1
@@ -400,19 +400,20 @@ def main():
     def jacobi_fn():
         i = now['i']
         if not overlap_jacobi:
-            if i is not None:
+            if i is not None and not os.environ.get('MF_BENCH_NO_EVENTS'):
                 jev[i][0].record()
             d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
-            if i is not None:
+            if i is not None and not os.environ.get('MF_BENCH_NO_EVENTS'):
                 jev[i][1].record()
             return d_stab
         with torch.cuda.stream(side):
-            if gate['table_start'] is not None:
-                side.wait_event(gate['table_start'])   # start with the previous step's cell table + plan, not earlier
-            if i is not None:
+            if len(ends) >= 2:
+                side.wait_event(ends[-2])              # start when the previous step's cell table + plan start (= the warp kernel of the
+                                                       # step before it has ended), not earlier
+            if i is not None and not os.environ.get('MF_BENCH_NO_EVENTS'):
                 jev[i][0].record(side)
             d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
-            if i is not None:
+            if i is not None and not os.environ.get('MF_BENCH_NO_EVENTS'):
                 jev[i][1].record(side)
             done = torch.cuda.Event()
             done.record(side)
@@ -422,15 +423,16 @@ def main():
 
     def warp_fn(lo_, hi_, d_stab):
         i = now['i']
-        if overlap_jacobi:
-            gate['table_start'] = torch.cuda.Event()
-            gate['table_start'].record()
         ops.cell_table(d_disp[lo_:hi_], d_stab[lo_:hi_], W, H, R, C, table=table, reset_status=False)
-        if i is not None:
+        timed = i is not None and not os.environ.get('MF_BENCH_NO_EVENTS')
+        if timed:
             ev[i][0].record()
         ops.warp(d_frames, table, stab.color_outside_image_area_bgr, out=d_out)
-        if i is not None:
-            ev[i][1].record()
+        if timed or overlap_jacobi:                # (every marker on the stream costs the step ~5 us: one event serves as the end of the
+            end = ev[i][1] if timed else torch.cuda.Event()      # timed interval and as the gate of the sweep two steps on)
+            end.record()
+            ends.append(end)
+            del ends[:-2]
         return d_out, table.crop           # degenerate-mesh counter accumulates in table.status (checked below)
 
     def crop_reduce_fn(crop):
@@ -459,10 +461,11 @@ def main():
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
 
-    warp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if os.environ.get('MF_BENCH_PER_STEP') and rank == 0:          # tuning aid: the launches one by one (clock transients)
+    no_events = bool(os.environ.get('MF_BENCH_NO_EVENTS'))     # tuning aid: what the HIP events around the kernels cost the step
+    warp_ms = float('nan') if no_events else float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if os.environ.get('MF_BENCH_PER_STEP') and rank == 0 and not no_events:          # tuning aid: the launches one by one (clock transients)
         print('warp ms per step:', [round(a.elapsed_time(b), 3) for a, b in ev], file=sys.stderr)
-    jac_ms = float(np.mean([a.elapsed_time(b) for a, b in jev]))
+    jac_ms = float('nan') if no_events else float(np.mean([a.elapsed_time(b) for a, b in jev]))
     # Jacobi kernel alone (the per-step figure above includes the host-side coefficient set-up), outside the timed region
     taps_d, lam_d, inv_on_d = stab._jacobi_coefficients_device(F, W, H, 0, hom, device)
     b2d = d_disp.reshape(F, -1)

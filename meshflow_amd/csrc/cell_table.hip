@@ -609,6 +609,12 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     regions[gid] = region;
 }
 
+__global__ __launch_bounds__(256) void zero_reach_kernel(int32_t* __restrict__ reach, int count)
+{
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i < count) reach[i] = 0;
+}
+
 int launch_cell_table(const double* unstab, const double* stab, int n, int W, int H, int R, int C,
                       const TableView& tv, int32_t* crop, int32_t* status, hipStream_t st)
 {
@@ -616,8 +622,13 @@ int launch_cell_table(const double* unstab, const double* stab, int n, int W, in
         set_error("mf_cell_table_f64: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
         return MF_ERR_INVALID_ARG;
     }
-    hipError_t e = hipMemsetAsync(tv.reach, 0, (size_t)n * 4 * sizeof(int32_t), st);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(reach)");
+    // (a kernel of our own instead of hipMemsetAsync: the runtime's fill goes through its blit path and the next kernel then starts
+    // ~6 us after it instead of right away -- tools/step_timeline.py)
+    hipLaunchKernelGGL(zero_reach_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, st, tv.reach, n * 4);
+    {
+        const int rc0 = hip_fail(hipGetLastError(), "zero_reach_kernel launch");
+        if (rc0 != MF_OK) return rc0;
+    }
     const long long total = (long long)n * R * C;
     long long threads = total > n ? total : n;
     if (threads < 65) threads = 65;
