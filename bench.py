@@ -382,16 +382,18 @@ def main():
 
     # The three stages handed to dist.stabilize_sharded; HIP events bracket the Jacobi stage and the warp kernel on the
     # launch stream (torch's current stream IS the stream ops.* launch on).
-    # The Jacobi sweep of a step (578 one-wave workgroups at config 2: a fraction of the chip) is issued on a SIDE stream and joined
-    # by an event: issued back to back, step i+1's sweep then runs under step i's warp kernel instead of after it.  Everything else
-    # of a step stays on the main stream in order.
-    # Only when the sweep is a fraction of the chip (at most ~1024 wavefronts: config 2's 578, an 8-GPU clip's 2400 frames x 578 series
-    # would be 2312 and config 3's 2178 series fill it): a sweep that fills the chip just takes the warp kernel's units away, and the
-    # warp kernel's HIP-event time (the roofline figure) would then include the sweep.
+    # The Jacobi sweep of a step (578 one-wave workgroups at config 2: a fraction of the chip) is issued on a SIDE stream, gated so that step
+    # i+1's sweep starts when step i's cell table + plan start (= when the warp kernel of step i-1 has ended) and joined by an event in
+    # front of step i+1's cell table: it runs under those two kernels instead of after them and has ended when the warp kernel starts
+    # (tools/step_timeline.py).  Everything else of a step stays on the main stream in order.
+    # Only when the sweep is a fraction of the chip (at most ~1024 wavefronts: config 2's 578; config 3's 2178 series fill it): a sweep that
+    # fills the chip just takes the other kernels' units away and would run on into the warp kernel, whose HIP-event time (the roofline
+    # figure) would then include it.
     main_stream = torch.cuda.current_stream(device)
     ends = []                              # end-of-warp events of the last two steps issued
     # (N > 1, and the one-GPU rehearsal of a rank of N: the replicated sweep grows with the clip -- 0.2 ms at 2400 frames -- and is what caps
-    # weak scaling, so it always goes under the previous step's warp there; that line's roofline figure then includes the interference.)
+    # weak scaling, so it always goes to the side stream there; what does not fit under cell table + plan runs under the warp kernel, and that
+    # line's roofline figure then includes the interference.)
     overlap_jacobi = int(d_disp[0].numel()) * max(1, -(-F // 320)) <= 1024 or world > 1 or args.as_rank_of > 1
     if args.jacobi_stream != 'auto':
         overlap_jacobi = args.jacobi_stream == 'side'
@@ -586,7 +588,7 @@ def main():
                          'note': 'bound by vector and scalar instruction issue (float64 coordinates, integer blend, one wavefront per 32x8 footprint), not by HBM: DESIGN.md 4.3'},
             'jacobi': {'avg_ms_incl_host_setup': jac_ms, 'on_side_stream': overlap_jacobi, 'kernel_ms': jac_kernel_ms,
                        'note': 'avg_ms_incl_host_setup: HIP events around the stage on its stream -- on the side stream (on_side_stream) it runs under the '
-                               'previous step\'s warp kernel and the figure includes waiting for units; kernel_ms: the kernel alone, measured after the timed region', 'series': int(d_disp[0].numel()), 'frames': F,
+                               'previous step\'s cell table + plan kernels and the figure includes sharing the chip with them; kernel_ms: the kernel alone, measured after the timed region', 'series': int(d_disp[0].numel()), 'frames': F,
                        'bound': 'fp64 vector ALU + LDS (the state never leaves the chip)', 'achieved': jac_flops / (jac_kernel_ms * 1e-3) / 1e12,
                        'peak': 78.6, 'unit': 'TFLOP/s', 'frac': jac_flops / (jac_kernel_ms * 1e-3) / 78.6e12},
             'crop_bounds': [int(v) for v in bounds.tolist()],
