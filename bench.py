@@ -398,6 +398,10 @@ def main():
     if args.jacobi_stream != 'auto':
         overlap_jacobi = args.jacobi_stream == 'side'
     side = torch.cuda.Stream(device=device) if overlap_jacobi else main_stream
+    # The gate is for the one-GPU sweep (46 us, fits under cell table + plan).  The replicated sweep of an N-GPU clip (0.2 ms at 2400 frames, 39 KB
+    # of LDS per workgroup) is left ungated: gated, it would run alone and latency-bound next to every step's plan kernel and take its LDS
+    # (measured with --as-rank-of 8: 1.64 ms per step against 1.44); ungated, the queued sweeps of several steps fill the chip together.
+    gated = overlap_jacobi and world == 1 and args.as_rank_of <= 1
 
     def jacobi_fn():
         i = now['i']
@@ -409,7 +413,7 @@ def main():
                 jev[i][1].record()
             return d_stab
         with torch.cuda.stream(side):
-            if len(ends) >= 2:
+            if gated and len(ends) >= 2:
                 side.wait_event(ends[-2])              # start when the previous step's cell table + plan start (= the warp kernel of the
                                                        # step before it has ended), not earlier
             if i is not None and not os.environ.get('MF_BENCH_NO_EVENTS'):
