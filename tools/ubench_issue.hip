@@ -349,6 +349,29 @@ int main(int argc, char** argv)
     double h[16]; for (int q = 0; q < 16; ++q) h[q] = 1.0 + q * 0.001;
     hipMemcpy(g_in, h, sizeof(h), hipMemcpyHostToDevice);
     const int quick = argc > 1 && !strcmp(argv[1], "quick");
+    if (argc > 3 && !strcmp(argv[1], "power")) {
+        // power OP SECONDS: one instruction class back to back on the whole chip (8 wavefronts per SIMD) for SECONDS, for a sampler
+        // of socket power and shader clock beside it (tools/ubench_power.sh); prints the achieved rate
+        const double seconds = atof(argv[3]);
+        void (*kern)(double*, const double*, long long*) = nullptr;
+#define PICK(op) if (!strcmp(argv[2], #op)) kern = k_single<op>;
+        PICK(FMA_F64) PICK(MUL_F64) PICK(ADD_F64) PICK(RCP_F64) PICK(CVT_F32_F64) PICK(FMA_F32) PICK(AND_B32) PICK(ADD_U32) PICK(MAD_U24)
+        PICK(DOT2_U16) PICK(PERM_B32) PICK(LSHL_ADD) PICK(MAX3_U32) PICK(MOV_B32) PICK(DS_READ_B32) PICK(PK_MAD_U16) PICK(CVT_I32_F32)
+#undef PICK
+        if (!kern) { printf("unknown op %s\n", argv[2]); return 1; }
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        long launches = 0; float total = 0;
+        while (total < seconds * 1e3f) {
+            hipEventRecord(e0);
+            for (int q = 0; q < 50; ++q) hipLaunchKernelGGL(kern, dim3(1024 * 8), dim3(64), 0, 0, g_out, g_in, g_ticks);
+            hipEventRecord(e1); hipDeviceSynchronize();
+            float ms; hipEventElapsedTime(&ms, e0, e1); total += ms; launches += 50;
+        }
+        const double instr = (double)launches * 1024 * 8 * TRIPS * 32.0;       // wave64 instructions
+        printf("%-14s %.2f s  %.3f T wave-instr/s  (%.2f ns per instruction and SIMD)\n", argv[2], total * 1e-3, instr / (total * 1e-3) / 1e12,
+               total * 1e6 / (instr / 1024.0));
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "more")) {
         for (int w = 4; w <= 8; w *= 2) {
             SINGLE(AND_B32, w); SINGLE(OR_B32, w); SINGLE(XOR_B32, w); SINGLE(SUB_U32, w); SINGLE(ADD_U32, w); SINGLE(CNDMASK, w); SINGLE(CNDMASK_S, w); SINGLE(CMP_CND, w);
