@@ -1,6 +1,6 @@
 """profiles/traffic.json from the size-resolved read-request / WRITE_SIZE passes of tools/profile_r03.sh.
 
-    python tools/make_traffic_json.py profiles/r03d_traffic_rdreq.csv "end of round 3"
+    python tools/make_traffic_json.py profiles/r03e_traffic_rdreq.csv "end of round 3"
 """
 import csv
 import json
