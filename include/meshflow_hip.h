@@ -98,6 +98,15 @@ int mf_cell_table_f64(const double* d_unstab, const double* d_stab, int n, int W
 int mf_warp_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, int n, int W, int H,
                  int R, int C, const uint8_t border_bgr[3], int32_t* d_crop, void* stream);
 
+/* ---- the crop-boundary scan WITHOUT the pixels (mfs.py:1075-1098) ----
+ * The four per-frame edge scans look at the coordinate maps only, i.e. at nothing but the cell table: this fills
+ * d_crop[f] = {left, top, right, bottom} for the n frames of d_table exactly as mf_warp_u8c3 does (same ownership and coordinate
+ * arithmetic, atomic max/min into the defaults mf_cell_table_f64 wrote), visiting only the footprints that can set a flag (a few
+ * per cent: the ring along the frame border) and touching no frame.  With it the clip-level rectangle (mf_crop_reduce, and the
+ * 16-byte all-reduce of a sharded clip) is known BEFORE the first pixel moves, so _crop_frames (mfs.py:159) can follow the warp
+ * chunk by chunk.  Running mf_warp_u8c3 on the same d_crop afterwards changes nothing (max/min of equal values). */
+int mf_crop_scan_f64(const void* d_table, int n, int W, int H, int R, int C, int32_t* d_crop, void* stream);
+
 /* Clip-level crop bounds (mfs.py:1103-1106): {max left, max top, min right, min bottom} over n frames.
  * d_bounds: [4] int32. */
 int mf_crop_reduce(const int32_t* d_crop, int n, int W, int H, int32_t* d_bounds, void* stream);

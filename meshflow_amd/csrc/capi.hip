@@ -108,6 +108,14 @@ int mf_warp_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, i
     return launch_warp(d_frames, d_out, tv, n, W, H, R, C, pack_border(border_bgr), d_crop, (hipStream_t)stream);
 }
 
+int mf_crop_scan_f64(const void* d_table, int n, int W, int H, int R, int C, int32_t* d_crop, void* stream)
+{
+    if (!d_table || !d_crop) { set_error("mf_crop_scan_f64: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (n <= 0 || R <= 0 || C <= 0) { set_error("mf_crop_scan_f64: bad sizes"); return MF_ERR_INVALID_ARG; }
+    const TableView tv = table_view(const_cast<void*>(d_table), n, W, H, R, C);
+    return launch_crop_scan(tv, n, W, H, R, C, d_crop, (hipStream_t)stream);
+}
+
 int mf_crop_reduce(const int32_t* d_crop, int n, int W, int H, int32_t* d_bounds, void* stream)
 {
     if (!d_crop || !d_bounds) { set_error("mf_crop_reduce: null pointer"); return MF_ERR_INVALID_ARG; }

@@ -438,6 +438,16 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
     }
     region.flags_origin = 0;
     region.src_dwords = 0;
+    // NOFLAG (for the scan-only pass): every pixel's source coordinates stay between the corner values of the listed cells (below),
+    // known to 0.01: with u > 1 + 1/16 - 0.01 and u < W - 2 - 1/16 + 0.01 neither |u| < 1 nor |u - (W-1)| < 1 can hold (same for v;
+    // mfs.py:1075-1098); a pixel no cell covers sits at (W+1, H+1) and passes none of the tests either.
+    bool noflag = false;
+    if (sane && cnt > 0 && !overflow && umin > -1e6f && vmin > -1e6f && umax < 1e6f && vmax < 1e6f) {
+        const float slack = (W <= 8192 && H <= 8192) ? 0.0625f : 1.0f;
+        noflag = (int)floorf(umin - slack) >= 1 && (int)floorf(umax + slack) + 1 <= W - 2 &&
+                 (int)floorf(vmin - slack) >= 1 && (int)floorf(vmax + slack) + 1 <= H - 2;
+        if (noflag) region.flags_origin = MF_REGION_NOFLAG;
+    }
     if (sane && cnt > 0 && !overflow && (W & 3) == 0 && 3 * W >= MF_STAGE_PITCH && H > MF_STAGE_ROWS &&
         umin > -1e6f && vmin > -1e6f && umax < 1e6f && vmax < 1e6f) {
         // Taps of a pixel at (u, v): columns ix, ix + 1 with ix = rint(32 u) >> 5 in [floor(u - 1/64), floor(u + 1/64)], same for
@@ -462,7 +472,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             const bool interior = whole && ix_lo >= 1 && ix_hi <= W - 2 && iy_lo >= 1 && iy_hi <= H - 2;
             const bool deep = covered && interior;
             const uint32_t bs = (3u * (uint32_t)sx0) & ~3u;
-            region.flags_origin = MF_REGION_STAGED | (deep ? MF_REGION_DEEP : 0u) | ((uint32_t)sy0 * MF_STAGE_PITCH + bs);
+            region.flags_origin = MF_REGION_STAGED | (deep ? MF_REGION_DEEP : 0u) | (noflag ? MF_REGION_NOFLAG : 0u) | ((uint32_t)sy0 * MF_STAGE_PITCH + bs);
             region.src_dwords = ((uint32_t)sy0 * (3u * (uint32_t)W) + bs) >> 2;
             // The premises of the warp kernel's cheap coordinate chain (warp.hip, cheap_quotients) for EVERY listed cell on this footprint:
             // no cancellation in the numerators -- the sum of the magnitudes of a numerator's terms (largest at the far corner: x, y >= 0)
@@ -490,8 +500,10 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
                 // COMPACT window: 9 rows x 112 bytes hold every tap -> one global->LDS load instead of two
                 const uint32_t cbs = (3u * (uint32_t)ix_lo) & ~3u;
                 if (iy_hi - iy_lo + 1 <= MF_COMPACT_ROWS && 3u * (uint32_t)ix_hi + 3u <= cbs + MF_COMPACT_PITCH &&
-                    iy_lo + MF_COMPACT_ROWS <= H - 1) {                     // (the load's 64th chunk: first of row sy0 + 9)
-                    region.flags_origin = MF_REGION_STAGED | MF_REGION_DEEP | MF_REGION_COMPACT | ((uint32_t)iy_lo * MF_COMPACT_PITCH + cbs);
+                    iy_lo + MF_COMPACT_ROWS <= H - 1 && cbs + 16u <= 3u * (uint32_t)W) {      // (the load's 64th chunk: the first 16 bytes of
+                                                                                            // row sy0 + 9 from byte cbs -- inside that row, hence
+                                                                                            // inside the clip even on its last frame)
+                    region.flags_origin = MF_REGION_STAGED | MF_REGION_DEEP | MF_REGION_NOFLAG | MF_REGION_COMPACT | ((uint32_t)iy_lo * MF_COMPACT_PITCH + cbs);
                     region.src_dwords = ((uint32_t)iy_lo * (3u * (uint32_t)W) + cbs) >> 2;
                 }
             }

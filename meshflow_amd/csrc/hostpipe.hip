@@ -191,7 +191,7 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
     const int nchunks = (n + chunk - 1) / chunk;
     MF_HIP_TRY(pc.frames.need(fb * n)); MF_HIP_TRY(pc.out.need(fb * n));
     MF_HIP_TRY(pc.unstab.need(vb1 * n)); MF_HIP_TRY(pc.stab.need(vb1 * n));
-    MF_HIP_TRY(pc.table.need(table_bytes(chunk, W, H, R, C)));
+    MF_HIP_TRY(pc.table.need(table_bytes(n, W, H, R, C)));           // of the whole clip: built once, before the first chunk
     MF_HIP_TRY(pc.crop.need((size_t)n * 4 * sizeof(int32_t)));
     MF_HIP_TRY(pc.status.need(sizeof(int32_t)));
     MF_HIP_TRY(pc.bounds.need(4 * sizeof(int32_t)));
@@ -215,11 +215,46 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
     } guard{{&up_done, &warp_done, &resize_done, &t0, &t1}, &r0, &r1};
     for (int k = 0; k < nchunks; ++k) {
         MF_HIP_TRY(hipEventCreateWithFlags(&up_done[k], hipEventDisableTiming));
-        MF_HIP_TRY(hipEventCreateWithFlags(&warp_done[k], hipEventDisableTiming));
+        if (out) MF_HIP_TRY(hipEventCreateWithFlags(&warp_done[k], hipEventDisableTiming));
         if (cropped) MF_HIP_TRY(hipEventCreateWithFlags(&resize_done[k], hipEventDisableTiming));
         if (kernel_ms) { MF_HIP_TRY(hipEventCreate(&t0[k])); MF_HIP_TRY(hipEventCreate(&t1[k])); }
     }
-    if (kernel_ms && cropped) { MF_HIP_TRY(hipEventCreate(&r0)); MF_HIP_TRY(hipEventCreate(&r1)); }
+    if (kernel_ms) { MF_HIP_TRY(hipEventCreate(&r0)); MF_HIP_TRY(hipEventCreate(&r1)); }
+
+    // Before any frame moves: vertex paths up, the cell table + footprint plan of the WHOLE clip (0.1-0.4 ms), and -- with `cropped` --
+    // the clip-level crop rectangle from the table alone (mf_crop_scan_f64: the edge scans of mfs.py:1075-1098 look at the coordinate
+    // maps, not at pixels), so that _crop_frames can follow every chunk's warp directly.  A degenerate mesh or an empty rectangle
+    // (cv2.resize would fail on an empty source) ends the call here: no frame has been uploaded, no output page touched.
+    const uint32_t border = (uint32_t)border_bgr[0] | ((uint32_t)border_bgr[1] << 8) | ((uint32_t)border_bgr[2] << 16);
+    const TableView tv = table_view(pc.table.p, n, W, H, R, C);
+    int32_t status = 0;
+    int32_t rect[4] = { 0, 0, W - 1, H - 1 };
+    MF_HIP_TRY(hipMemsetAsync(pc.status.p, 0, sizeof(int32_t), pc.compute));
+    MF_HIP_TRY(hipMemcpyAsync(pc.unstab.p, unstab, vb1 * n, hipMemcpyHostToDevice, pc.compute));
+    MF_HIP_TRY(hipMemcpyAsync(pc.stab.p, stab, vb1 * n, hipMemcpyHostToDevice, pc.compute));
+    if (kernel_ms) MF_HIP_TRY(hipEventRecord(r0, pc.compute));
+    if (const int rc0 = launch_cell_table((const double*)pc.unstab.p, (const double*)pc.stab.p, n, W, H, R, C, tv, d_crop, (int32_t*)pc.status.p, pc.compute)) return rc0;
+    if (cropped) {
+        if (const int rc0 = launch_crop_scan(tv, n, W, H, R, C, d_crop, pc.compute)) return rc0;
+        if (const int rc0 = launch_crop_reduce(d_crop, n, W, H, (int32_t*)pc.bounds.p, pc.compute)) return rc0;
+    }
+    if (kernel_ms) MF_HIP_TRY(hipEventRecord(r1, pc.compute));
+    if (cropped) {
+        MF_HIP_TRY(hipMemcpyAsync(rect, pc.bounds.p, sizeof rect, hipMemcpyDeviceToHost, pc.compute));
+        MF_HIP_TRY(hipMemcpyAsync(&status, pc.status.p, sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute));
+        MF_HIP_TRY(hipStreamSynchronize(pc.compute));
+        if (bounds) for (int i = 0; i < 4; ++i) bounds[i] = rect[i];
+        if (status != 0) {
+            set_error("mf_warp_u8c3_host: %d degenerate mesh cell(s): no homography exists (cv2.findHomography would return None)", status);
+            return MF_ERR_DEGENERATE;
+        }
+        if (rect[2] < rect[0] || rect[3] < rect[1]) {
+            MF_HIP_TRY(hipMemcpy(crop, d_crop, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));       // (the per-frame values say which frame emptied it)
+            set_error("mf_warp_crop_u8c3_host_frames: empty crop rectangle (%d, %d, %d, %d): cv2.resize would fail on an empty source",
+                      rect[0], rect[1], rect[2], rect[3]);
+            return MF_ERR_INVALID_ARG;
+        }
+    }
 
     Shared sh;
     sh.up_ready.assign(nchunks, 0);
@@ -233,10 +268,10 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
     auto chunk_end = [&](int k) { return (k * chunk + chunk < n) ? k * chunk + chunk : n; };
     for (int t = 0; t < n_pop; ++t)
         workers.emplace_back([&, t] {
-            if (out)
-                for (int k = t; k < nchunks; k += n_pop) { populate_frames(out, k * chunk, chunk_end(k), fb); sh.mark(sh.populated, k); }
-            if (cropped)
-                for (int k = t; k < nchunks; k += n_pop) { populate_frames(cropped, k * chunk, chunk_end(k), fb); sh.mark(sh.populated2, k); }
+            for (int k = t; k < nchunks; k += n_pop) {       // chunk by chunk, in the order the downloads will need the pages
+                if (out) { populate_frames(out, k * chunk, chunk_end(k), fb); sh.mark(sh.populated, k); }
+                if (cropped) { populate_frames(cropped, k * chunk, chunk_end(k), fb); sh.mark(sh.populated2, k); }
+            }
         });
     for (int t = 0; t < n_up; ++t)
         workers.emplace_back([&, t] {
@@ -250,81 +285,65 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
                 { std::lock_guard<std::mutex> g(sh.m); if (sh.abort) return; }
             }
         });
+    // Cropped + resized chunk k is written where input chunk k was (the warp of chunk k, in front of it on the compute stream, was
+    // that chunk's only reader) and travels back while later chunks are still going up and being warped: ONE phase, both PCIe
+    // directions busy throughout.
     for (int t = 0; t < n_down; ++t)
         workers.emplace_back([&, t] {
             if (hipSetDevice(dev) != hipSuccess) { sh.fail(hipErrorInvalidDevice, "hipSetDevice (download thread)"); return; }
-            if (out)
-                for (int k = t; k < nchunks; k += n_down) {
+            for (int k = t; k < nchunks; k += n_down) {
+                if (out) {
                     if (!sh.wait(sh.warp_ready, k) || !sh.wait(sh.populated, k)) return;
                     hipError_t e = hipStreamWaitEvent(pc.down[t], warp_done[k], 0);
                     if (e == hipSuccess) e = copy_frames(d_out, out, k * chunk, chunk_end(k), fb, false, pc.down[t]);
                     if (e != hipSuccess) { sh.fail(e, "download of a frame chunk"); return; }
                 }
-            if (cropped)                               // second phase: the cropped + resized chunks (they sit in the input stack)
-                for (int k = t; k < nchunks; k += n_down) {
+                if (cropped) {
                     if (!sh.wait(sh.resize_ready, k) || !sh.wait(sh.populated2, k)) return;
                     hipError_t e = hipStreamWaitEvent(pc.down[t], resize_done[k], 0);
                     if (e == hipSuccess) e = copy_frames(d_frames, cropped, k * chunk, chunk_end(k), fb, false, pc.down[t]);
                     if (e != hipSuccess) { sh.fail(e, "download of a cropped frame chunk"); return; }
                 }
+            }
             hipError_t e = hipStreamSynchronize(pc.down[t]);
             if (e != hipSuccess) sh.fail(e, "hipStreamSynchronize (download stream)");
         });
 
-    // the calling thread: vertex paths up, then the kernels of every chunk as soon as its frames have landed
+    // the calling thread: the kernels of every chunk as soon as its frames have landed -- warp, then (with `cropped`) crop + resize
     int rc = MF_OK;
-    const uint32_t border = (uint32_t)border_bgr[0] | ((uint32_t)border_bgr[1] << 8) | ((uint32_t)border_bgr[2] << 16);
-    hipError_t e = hipMemsetAsync(pc.status.p, 0, sizeof(int32_t), pc.compute);
-    if (e == hipSuccess) e = hipMemcpyAsync(pc.unstab.p, unstab, vb1 * n, hipMemcpyHostToDevice, pc.compute);
-    if (e == hipSuccess) e = hipMemcpyAsync(pc.stab.p, stab, vb1 * n, hipMemcpyHostToDevice, pc.compute);
-    if (e != hipSuccess) { sh.fail(e, "upload of the vertex displacements"); }
+    hipError_t e = hipSuccess;
     for (int k = 0; k < nchunks && e == hipSuccess && rc == MF_OK; ++k) {
         if (!sh.wait(sh.up_ready, k)) break;
         const int i0 = k * chunk, i1 = chunk_end(k), m = i1 - i0;
         e = hipStreamWaitEvent(pc.compute, up_done[k], 0);
         if (e != hipSuccess) { sh.fail(e, "hipStreamWaitEvent"); break; }
         if (kernel_ms) (void)hipEventRecord(t0[k], pc.compute);
-        const TableView tv = table_view(pc.table.p, m, W, H, R, C);
-        rc = launch_cell_table((const double*)((const char*)pc.unstab.p + vb1 * i0), (const double*)((const char*)pc.stab.p + vb1 * i0), m,
-                               W, H, R, C, tv, d_crop + 4 * (size_t)i0, (int32_t*)pc.status.p, pc.compute);
-        if (rc == MF_OK) rc = launch_warp(d_frames + fb * i0, d_out + fb * i0, tv, m, W, H, R, C, border, d_crop + 4 * (size_t)i0, pc.compute);
+        rc = launch_warp(d_frames + fb * i0, d_out + fb * i0, table_slice(tv, i0, W, H, R, C), m, W, H, R, C, border, d_crop + 4 * (size_t)i0, pc.compute);
         if (rc != MF_OK) { sh.fail(hipErrorUnknown, "kernel launch"); break; }
+        if (out) {
+            e = hipEventRecord(warp_done[k], pc.compute);
+            if (e != hipSuccess) { sh.fail(e, "hipEventRecord"); break; }
+            sh.mark(sh.warp_ready, k);
+        }
+        if (cropped) {                                     // _crop_frames (mfs.py:1111-1157) of this chunk, its source still in the caches
+            rc = launch_crop_resize(d_out + fb * i0, d_frames + fb * i0, m, W, H, rect[0], rect[1], rect[2], rect[3], pc.work.p, pc.compute);
+            if (rc != MF_OK) { sh.fail(hipErrorUnknown, "kernel launch"); break; }
+            e = hipEventRecord(resize_done[k], pc.compute);
+            if (e != hipSuccess) { sh.fail(e, "hipEventRecord"); break; }
+            sh.mark(sh.resize_ready, k);
+        }
         if (kernel_ms) (void)hipEventRecord(t1[k], pc.compute);
-        e = hipEventRecord(warp_done[k], pc.compute);
-        if (e != hipSuccess) { sh.fail(e, "hipEventRecord"); break; }
-        sh.mark(sh.warp_ready, k);
     }
-    int32_t status = 0;
-    int32_t rect[4] = { 0, 0, W - 1, H - 1 };
-    bool bad_rect = false;
     if (!sh.abort) {
-        // clip-level crop rectangle (mfs.py:1103-1106) on the device, then per-frame values, rectangle and status in one wait
-        rc = launch_crop_reduce(d_crop, n, W, H, (int32_t*)pc.bounds.p, pc.compute);
+        // per-frame crop values (and, without the early scan, the clip-level rectangle and the degenerate-mesh count) in one wait
+        if (!cropped) rc = launch_crop_reduce(d_crop, n, W, H, (int32_t*)pc.bounds.p, pc.compute);
         if (rc != MF_OK) sh.fail(hipErrorUnknown, "kernel launch");
         else {
             e = hipMemcpyAsync(crop, d_crop, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute);
-            if (e == hipSuccess) e = hipMemcpyAsync(rect, pc.bounds.p, sizeof rect, hipMemcpyDeviceToHost, pc.compute);
-            if (e == hipSuccess) e = hipMemcpyAsync(&status, pc.status.p, sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute);
+            if (e == hipSuccess && !cropped) e = hipMemcpyAsync(rect, pc.bounds.p, sizeof rect, hipMemcpyDeviceToHost, pc.compute);
+            if (e == hipSuccess && !cropped) e = hipMemcpyAsync(&status, pc.status.p, sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute);
             if (e == hipSuccess) e = hipStreamSynchronize(pc.compute);
             if (e != hipSuccess) sh.fail(e, "download of the crop values");
-        }
-    }
-    if (!sh.abort && cropped) {
-        // _crop_frames (mfs.py:1111-1157): needs the rectangle of the WHOLE clip, hence a second phase.  A degenerate mesh or an
-        // empty rectangle (cv2.resize would fail on an empty source) ends the call before it.
-        bad_rect = rect[2] < rect[0] || rect[3] < rect[1];
-        if (status != 0 || bad_rect) sh.fail(hipSuccess, "");
-        else {
-            if (kernel_ms) (void)hipEventRecord(r0, pc.compute);
-            for (int k = 0; k < nchunks; ++k) {
-                const int i0 = k * chunk, m = chunk_end(k) - i0;
-                rc = launch_crop_resize(d_out + fb * i0, d_frames + fb * i0, m, W, H, rect[0], rect[1], rect[2], rect[3], pc.work.p, pc.compute);
-                if (rc != MF_OK) { sh.fail(hipErrorUnknown, "kernel launch"); break; }
-                e = hipEventRecord(resize_done[k], pc.compute);
-                if (e != hipSuccess) { sh.fail(e, "hipEventRecord"); break; }
-                sh.mark(sh.resize_ready, k);
-            }
-            if (kernel_ms && !sh.abort) (void)hipEventRecord(r1, pc.compute);
         }
     }
     for (auto& w : workers) w.join();
@@ -333,12 +352,6 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
         (void)hipDeviceSynchronize();
         set_error("mf_warp_u8c3_host: %d degenerate mesh cell(s): no homography exists (cv2.findHomography would return None)", status);
         return MF_ERR_DEGENERATE;
-    }
-    if (bad_rect) {
-        (void)hipDeviceSynchronize();
-        set_error("mf_warp_crop_u8c3_host_frames: empty crop rectangle (%d, %d, %d, %d): cv2.resize would fail on an empty source",
-                  rect[0], rect[1], rect[2], rect[3]);
-        return MF_ERR_INVALID_ARG;
     }
     if (sh.abort) {
         (void)hipDeviceSynchronize();
@@ -349,7 +362,7 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
         MF_HIP_TRY(hipStreamSynchronize(pc.compute));
         float total = 0.0f;
         for (int k = 0; k < nchunks; ++k) { float ms = 0.0f; MF_HIP_TRY(hipEventElapsedTime(&ms, t0[k], t1[k])); total += ms; }
-        if (cropped) { float ms = 0.0f; MF_HIP_TRY(hipEventElapsedTime(&ms, r0, r1)); total += ms; }
+        { float ms = 0.0f; MF_HIP_TRY(hipEventElapsedTime(&ms, r0, r1)); total += ms; }         // cell table + plan (+ scan + reduce)
         *kernel_ms = total;
     }
     return MF_OK;

@@ -5,6 +5,36 @@
 
 namespace mf {
 
+// The N sweeps of one thread's K frames.  SYM: the taps are symmetric (taps[OMEGA + d] == taps[OMEGA - d] bit for bit, as the
+// reference builds them: exp(-((3 / OMEGA) (t - r))^2), mfs.py:750-752) and `w` holds the OMEGA + 1 distinct values w[|d|] -- half the
+// scalar registers; the sum still runs over d = -OMEGA .. OMEGA in ascending order, so the bits are the same either way.
+template <int OMEGA, int K, int WAVES, bool SYM>
+__device__ __forceinline__ void jacobi_sweeps(double (&xs)[2][64 * WAVES * K + 2 * OMEGA], const double (&w)[SYM ? OMEGA + 1 : 2 * OMEGA + 1],
+                                              const double (&bt)[K], const double (&two_lam)[K], const double (&inv)[K], double (&xn)[K],
+                                              int lane, int iters)
+{
+    constexpr int NT = 2 * OMEGA + 1;
+    int cur = 0;
+    for (int it = 0; it < iters; ++it) {
+        double win[K + 2 * OMEGA];
+        const double* src = &xs[cur][lane * K];
+#pragma unroll
+        for (int j = 0; j < K + 2 * OMEGA; ++j) win[j] = src[j];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double acc = 0.0;
+#pragma unroll
+            for (int d = 0; d < NT; ++d) acc = __builtin_fma(w[SYM ? (d < OMEGA ? OMEGA - d : d - OMEGA) : d], win[k + d], acc);
+            xn[k] = inv[k] * __builtin_fma(two_lam[k], acc, bt[k]);
+        }
+        double* dst = &xs[cur ^ 1][OMEGA + lane * K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) dst[k] = xn[k];
+        cur ^= 1;
+        __syncthreads();
+    }
+}
+
 template <int OMEGA, int K, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* __restrict__ b, double* __restrict__ x_out,
                                                          const double* __restrict__ taps,
@@ -14,13 +44,13 @@ __global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* _
     constexpr int NT = 2 * OMEGA + 1;
     constexpr int NTHR = 64 * WAVES;
     constexpr int LEN = NTHR * K + 2 * OMEGA;
+    // Beyond ~45 taps the 2 NT scalar registers of the float64 taps do not fit next to everything else (OMEGA = 30: 122 of them,
+    // 110 spilled to vector-register lanes and restored every sweep); symmetric taps -- what the reference always has -- need
+    // OMEGA + 1 values.  Decided per launch by a wave-uniform bit comparison; anything else takes the full table.
+    constexpr bool TRY_SYM = NT > 45;
     __shared__ double xs[2][LEN];
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
-
-    double w[NT];
-#pragma unroll
-    for (int d = 0; d < NT; ++d) w[d] = taps[d];
 
     double bt[K], two_lam[K], inv[K];
 #pragma unroll
@@ -37,27 +67,28 @@ __global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* _
     for (int k = 0; k < K; ++k) xs[0][OMEGA + lane * K + k] = bt[k];   // x_start = b
     __syncthreads();
 
-    int cur = 0;
     double xn[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) xn[k] = bt[k];
-    for (int it = 0; it < iters; ++it) {
-        double win[K + 2 * OMEGA];
-        const double* src = &xs[cur][lane * K];
+    bool symmetric = false;
+    if (TRY_SYM) {
+        typedef const __attribute__((address_space(4))) unsigned long long* cbits_t;      // (scalar loads)
+        const cbits_t tb = (cbits_t)(uintptr_t)taps;
+        unsigned long long diff = 0;
 #pragma unroll
-        for (int j = 0; j < K + 2 * OMEGA; ++j) win[j] = src[j];
+        for (int d = 1; d <= OMEGA; ++d) diff |= tb[OMEGA + d] ^ tb[OMEGA - d];
+        symmetric = diff == 0;
+    }
+    if (TRY_SYM && symmetric) {
+        double w[OMEGA + 1];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            double acc = 0.0;
+        for (int d = 0; d <= OMEGA; ++d) w[d] = taps[OMEGA + d];
+        jacobi_sweeps<OMEGA, K, WAVES, true>(xs, w, bt, two_lam, inv, xn, lane, iters);
+    } else {
+        double w[NT];
 #pragma unroll
-            for (int d = 0; d < NT; ++d) acc = __builtin_fma(w[d], win[k + d], acc);
-            xn[k] = inv[k] * __builtin_fma(two_lam[k], acc, bt[k]);
-        }
-        double* dst = &xs[cur ^ 1][OMEGA + lane * K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) dst[k] = xn[k];
-        cur ^= 1;
-        __syncthreads();
+        for (int d = 0; d < NT; ++d) w[d] = taps[d];
+        jacobi_sweeps<OMEGA, K, WAVES, false>(xs, w, bt, two_lam, inv, xn, lane, iters);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {

@@ -100,6 +100,10 @@ struct alignas(8) FootRegion { uint32_t flags_origin, src_dwords; };
 // src_dwords then refer to that layout (origin = MF_COMPACT_PITCH sy0 + bs).
 #define MF_REGION_COMPACT 0x20000000u
 #define MF_COMPACT_PITCH 112
+// bit 28 = NOFLAG (with or without STAGED): no pixel of the footprint can pass one of the four crop-boundary tests of mfs.py:1075-1098
+// -- every source coordinate any listed cell can give it lies more than one pixel inside the frame's first / last column and row --
+// so the scan-only pass (crop_scan_kernel, warp.hip) skips it.  DEEP implies it.
+#define MF_REGION_NOFLAG 0x10000000u
 #define MF_COMPACT_ROWS 9
 #define MF_STAGE_CHUNKS 128            // two 16-byte chunks per lane: 12 rows x 10 chunks + 8 chunks of a 13th row (unused)
 struct TableView {
@@ -118,6 +122,17 @@ inline size_t table_bytes(int n, int W, int H, int R, int C)
 {
     return plan_offset(n, R, C) + plan_count(n, W, H) * (sizeof(FootPlan) + sizeof(FootRegion)) +
            (size_t)n * 4 * sizeof(int32_t) + (size_t)(R + C + 2) * sizeof(int32_t);
+}
+inline TableView table_view(void* blob, int n, int W, int H, int R, int C);
+// The part of a table that belongs to frames f0 ... (the per-frame sections advanced, the vertex grid shared): what launch_warp /
+// launch_crop_scan need to work on a chunk of a clip whose table was built in one go.
+inline TableView table_slice(const TableView& t, int f0, int W, int H, int R, int C)
+{
+    TableView v = t;
+    const size_t rec = table_records(f0, R, C), fp = (size_t)f0 * ((H + MF_FOOT_H - 1) / MF_FOOT_H) * ((W + MF_FOOT_W - 1) / MF_FOOT_W);
+    v.records += rec * MF_CELL_DOUBLES; v.boxes += rec; v.edges += rec * MF_EDGE_FLOATS; v.uedges += rec * MF_UEDGE_FLOATS;
+    v.plan += fp; v.regions += fp; v.reach += (size_t)f0 * 4;
+    return v;
 }
 inline TableView table_view(void* blob, int n, int W, int H, int R, int C)
 {
@@ -201,6 +216,7 @@ int launch_cell_table(const double* unstab, const double* stab, int n, int W, in
                       const TableView& tv, int32_t* crop, int32_t* status, hipStream_t st);
 int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n, int W, int H, int R, int C,
                 uint32_t border, int32_t* crop, hipStream_t st);
+int launch_crop_scan(const TableView& tv, int n, int W, int H, int R, int C, int32_t* crop, hipStream_t st);
 int check_d16_zero_fill(hipStream_t st);          // warp.hip: one-time device check the byte-tap kernels rely on
 int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t st);
 int launch_selftest_fast64(unsigned long long n, unsigned long long seed, unsigned long long* d_counters, hipStream_t st);

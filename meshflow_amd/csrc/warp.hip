@@ -528,34 +528,21 @@ __device__ __forceinline__ uint3 blend(const uint32_t (&bx)[4], const uint32_t (
 
 // STAGE_OK: the clip is 4-byte aligned, so the plan's STAGED windows can be copied by 16-byte global->LDS loads (always the case
 // for buffers from hipMalloc / torch; the other instantiation ignores the windows).
-template <bool STAGE_OK>
-__global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* __restrict__ plan, const FootRegion* __restrict__ regions,
-                                                               WarpGeom g, const uint8_t* __restrict__ frames,
-                                                               const double* __restrict__ records, uint8_t* __restrict__ out,
-                                                               const float* __restrict__ edges, int n, int W,
-                                                               int H, int C, uint32_t border, int32_t* __restrict__ crop)
+// SCAN: the crop-boundary scan ALONE (crop_scan_kernel below): the same ownership and coordinate code for footprint t of frame f,
+// then only the four edge tests of mfs.py:1075-1098 -- no window, no taps, no blend, no store.  The certified paths (hot, pair,
+// multi) are compiled out: their footprints cannot set a crop flag (MF_REGION_DEEP / MF_REGION_NOFLAG) and are never handed in.
+template <bool STAGE_OK, bool SCAN>
+__device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t t, const FootPlan* __restrict__ plan, const FootRegion* __restrict__ regions,
+                                               const WarpGeom& g, const uint8_t* __restrict__ frames,
+                                               const double* __restrict__ records, uint8_t* __restrict__ out,
+                                               const float* __restrict__ edges, int n, int W,
+                                               int H, int C, uint32_t border, int32_t* __restrict__ crop)
 {
     // inverse homographies of the footprint's candidate cells: [entry][Hi0..Hi8, pad] (80-byte rows)
     __shared__ __attribute__((aligned(16))) double s_hi[1][9][10];                // row 8: the "no cell" matrix, see OWN_NONE
     // source region of the footprint: MF_STAGE_ROWS rows of MF_STAGE_PITCH bytes (+ slack for the third dword of the last tap)
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[LDS_WINDOW_BYTES + 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[SCAN ? 16 : LDS_WINDOW_BYTES + 64];
     constexpr int wave = 0;
-    // XCD-aware footprint order.  Workgroups go to the 8 XCDs round-robin by linear id (blockIdx.x first: gridDim.x is a multiple of
-    // 8), and each XCD has its own L2: in raster order the four neighbours of a footprint -- whose staged windows overlap its own
-    // by 60 % -- would all run on other XCDs and each L2 would fetch the shared rows again.  Workgroup L of frame blockIdx.y
-    // therefore takes footprint (L % 8) * per_xcd + L / 8: every XCD sweeps one contiguous eighth of each frame in raster order.
-    // (Everything up to the plan is scalar, with host-made constants and 32-bit offsets: the scalar unit is as loaded as the vector
-    // unit in this kernel -- profiles/README.md -- and every s_ instruction here is paid by each of the 2.4 M wavefronts of a clip.)
-    const uint32_t f = blockIdx.y;
-#ifndef MF_NO_ROT
-    // The eighth an XCD sweeps ROTATES with the frame: the footprints along the top and bottom frame border are the expensive ones
-    // (per-tap path, crop flags: 2.5 x the average), and with a fixed assignment they all land on XCD 0 and XCD 7, which then
-    // finish 9 % after the others (-2.1 % kernel time at config 2, -4 % on the all-hot probe).
-    const uint32_t t = ((blockIdx.x + f) & 7u) * g.per_xcd + (blockIdx.x >> 3);
-#else
-    const uint32_t t = (blockIdx.x & 7u) * g.per_xcd + (blockIdx.x >> 3);
-#endif
-    if (t >= g.per_frame) return;
     const uint32_t ty = (__umulhi(t, g.div_m) + (t & g.div_pass)) >> g.div_s, tx = t - ty * g.nfx;
     const int xa = (int)(tx * (uint32_t)FOOT_W), ya = (int)(ty * (uint32_t)FOOT_H);
     const int lane = threadIdx.x;
@@ -568,7 +555,7 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
     const uint64_t region = *(cword2_t)rw;                               // both words in one load (the second is needed right after the first)
     const uint32_t rg = (uint32_t)region, src_dwords = (uint32_t)(region >> 32);
     const uint8_t* __restrict__ src = frames + (uint64_t)f * g.frame_bytes;
-    const bool staged = STAGE_OK && (rg & MF_REGION_STAGED) != 0;
+    const bool staged = STAGE_OK && !SCAN && (rg & MF_REGION_STAGED) != 0;
     if (staged) {
         // Source region -> LDS, asynchronously (global_load_lds: no VGPRs, no ds_write).  Two layouts, chosen by the plan:
         //   COMPACT (hot footprints whose taps fit 9 rows x 112 bytes: ~3/4 of them): ONE load, lane i fetches the i-th 16-byte
@@ -604,7 +591,7 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
     const int x0 = xa + (lane & 7) * 4;                                  // first of this lane's 4 pixels
     const double xs0 = (double)x0, yy = (double)y;
 
-    if (STAGE_OK && (pv.x & (MF_PLAN_HOT << 16)) != 0) {
+    if (STAGE_OK && !SCAN && (pv.x & (MF_PLAN_HOT << 16)) != 0) {
         // The plan certifies everything (~2/3 of the footprints at config-2 geometry): ONE cell owns all 256 pixels, its
         // denominator allows the trimmed reciprocal (UNIT), the footprint lies inside the frame, its window is staged and every
         // tap is at least two pixels inside the frame (DEEP: no crop flag either).  Straight-line code, all lanes active.
@@ -627,7 +614,7 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
     }
 
     const cedge_t fedge = (cedge_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(edges) + f * g.edge_frame_bytes);
-    if (STAGE_OK && (pv.y & MF_PLAN_HOT) != 0) {
+    if (STAGE_OK && !SCAN && (pv.y & MF_PLAN_HOT) != 0) {
         // Two cells share the footprint and the plan certifies the rest (a quarter of the footprints at config-2 geometry, 45 % at
         // config 3): the later cell wins wherever ONE of its mask edges passes -- one float32 fma per pixel -- and the other cell
         // owns what is left; denominators, window and interior as on the hot path.  Both inverse homographies go to LDS by
@@ -737,7 +724,7 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
         }
     }
 
-    if (STAGE_OK && (pv.z & MF_PLAN_HOT) != 0) {
+    if (STAGE_OK && !SCAN && (pv.z & MF_PLAN_HOT) != 0) {
         // Two to four cells, each MIXED one with one or two coded mask edges (the four cells around a mesh vertex, three of them, or a
         // pair the pair path did not take); window, interior and denominators certified, coverage not: a pixel that no listed cell
         // takes -- or one inside the float32 error band of an edge -- sends the wavefront to the general code.
@@ -1033,6 +1020,40 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
             }
         }
 
+        if (SCAN) {
+            // The crop-boundary scan alone, mfs.py:1075-1098 (the same tests as on the generic path below; there they run only when
+            // some pixel of the footprint is not deep inside the frame -- a pixel that is cannot pass any of them).
+            int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int x = x0 + j;
+                    if (x < W) {
+                        if (fabsf(u[j]) < 1.0f) c_left = max(c_left, x);
+                        if (fabsf(u[j] - fWm1) < 1.0f) c_right = min(c_right, x);
+                        if (fabsf(v[j]) < 1.0f) c_top = max(c_top, y);
+                        if (fabsf(v[j] - fHm1) < 1.0f) c_bottom = min(c_bottom, y);
+                    }
+                }
+            }
+            const bool any = c_left != 0 || c_top != 0 || c_right != W - 1 || c_bottom != H - 1;
+            if (__ballot(any) != 0) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    c_left = max(c_left, __shfl_xor(c_left, off));
+                    c_top = max(c_top, __shfl_xor(c_top, off));
+                    c_right = min(c_right, __shfl_xor(c_right, off));
+                    c_bottom = min(c_bottom, __shfl_xor(c_bottom, off));
+                }
+                if (lane == 0) {
+                    if (c_left != 0) atomicMax(&crop[4 * f + 0], c_left);
+                    if (c_top != 0) atomicMax(&crop[4 * f + 1], c_top);
+                    if (c_right != W - 1) atomicMin(&crop[4 * f + 2], c_right);
+                    if (c_bottom != H - 1) atomicMin(&crop[4 * f + 3], c_bottom);
+                }
+            }
+            return;
+        }
         // cv2.remap: 1/32-pixel fixed point (round half to even), bilinear gather, store.
         uint32_t bx[4], by[4];
         fixed_point(u, v, bx, by);
@@ -1189,6 +1210,58 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
     }
 }
 
+template <bool STAGE_OK>
+__global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* __restrict__ plan, const FootRegion* __restrict__ regions,
+                                                               WarpGeom g, const uint8_t* __restrict__ frames,
+                                                               const double* __restrict__ records, uint8_t* __restrict__ out,
+                                                               const float* __restrict__ edges, int n, int W,
+                                                               int H, int C, uint32_t border, int32_t* __restrict__ crop)
+{
+    // XCD-aware footprint order.  Workgroups go to the 8 XCDs round-robin by linear id (blockIdx.x first: gridDim.x is a multiple of
+    // 8), and each XCD has its own L2: in raster order the four neighbours of a footprint -- whose staged windows overlap its own
+    // by 60 % -- would all run on other XCDs and each L2 would fetch the shared rows again.  Workgroup L of frame blockIdx.y
+    // therefore takes footprint (L % 8) * per_xcd + L / 8: every XCD sweeps one contiguous eighth of each frame in raster order.
+    // (Everything up to the plan is scalar, with host-made constants and 32-bit offsets: the scalar unit is as loaded as the vector
+    // unit in this kernel -- profiles/README.md -- and every s_ instruction here is paid by each of the 2.4 M wavefronts of a clip.)
+    const uint32_t f = blockIdx.y;
+#ifndef MF_NO_ROT
+    // The eighth an XCD sweeps ROTATES with the frame: the footprints along the top and bottom frame border are the expensive ones
+    // (per-tap path, crop flags: 2.5 x the average), and with a fixed assignment they all land on XCD 0 and XCD 7, which then
+    // finish 9 % after the others (-2.1 % kernel time at config 2, -4 % on the all-hot probe).
+    const uint32_t t = ((blockIdx.x + f) & 7u) * g.per_xcd + (blockIdx.x >> 3);
+#else
+    const uint32_t t = (blockIdx.x & 7u) * g.per_xcd + (blockIdx.x >> 3);
+#endif
+    if (t >= g.per_frame) return;
+    footprint_body<STAGE_OK, false>(f, t, plan, regions, g, frames, records, out, edges, n, W, H, C, border, crop);
+}
+
+// The crop-boundary scan WITHOUT the pixels (mfs.py:1075-1106 depends on the coordinate maps only, i.e. on the cell table): fills
+// crop[f] exactly as warp_kernel does, from the footprints that can set a flag at all.  A wavefront looks at SCAN_GROUP consecutive
+// footprints (one lane each reads the footprint's region word: anything the plan certified as DEEP or NOFLAG cannot pass any of
+// the four tests) and then runs footprint_body<SCAN> -- ownership and coordinates of the general path, nothing else -- on the
+// remaining ones, one after the other: ~4 % of the footprints of a stabilised 1080p clip (the ring along the frame border).
+// A host that knows the clip-level rectangle before the first pixel moves can crop + resize each chunk right behind its warp
+// (csrc/hostpipe.hip) and, at N > 1, overlap the 16-byte all-reduce with the warp.
+constexpr uint32_t SCAN_GROUP = 16;
+__global__ __launch_bounds__(64) void crop_scan_kernel(const FootPlan* __restrict__ plan, const FootRegion* __restrict__ regions,
+                                                       WarpGeom g, const double* __restrict__ records, const float* __restrict__ edges,
+                                                       uint32_t total, int n, int W, int H, int C, int32_t* __restrict__ crop)
+{
+    const uint32_t base = blockIdx.x * SCAN_GROUP, mine = base + threadIdx.x;
+    bool need = false;
+    if (threadIdx.x < SCAN_GROUP && mine < total) need = (regions[mine].flags_origin & (MF_REGION_DEEP | MF_REGION_NOFLAG)) == 0;
+    uint64_t todo = __ballot(need);
+    while (todo) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t fp = __builtin_amdgcn_readfirstlane(base + bit);
+        const uint32_t f = fp / g.per_frame, t = fp - f * g.per_frame;
+        footprint_body<false, true>(f, t, plan, regions, g, nullptr, records, nullptr, edges, n, W, H, C, 0u, crop);
+        __builtin_amdgcn_wave_barrier();             // (the next footprint reuses the wavefront's s_hi rows)
+    }
+}
+
 // Self-test of recip_unit_range against IEEE division: counts mismatching bit patterns.
 __global__ void selftest_recip_kernel(unsigned long long n, unsigned long long seed, unsigned long long* mismatches)
 {
@@ -1330,16 +1403,10 @@ int check_d16_zero_fill(hipStream_t st)
     return MF_OK;
 }
 
-int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n, int W, int H, int R, int C,
-                uint32_t border, int32_t* crop, hipStream_t st)
+// Launch constants of warp_kernel / crop_scan_kernel; returns the frames one launch may cover (the grid's y extent, and 32-bit byte
+// offsets into the plan -- 16 B per footprint -- and the records), 0 when a single frame is already too large.
+static uint32_t make_warp_geom(int W, int H, int R, int C, WarpGeom& g)
 {
-    if (const int rc = check_d16_zero_fill(st)) return rc;
-    if (n <= 0 || n > 65535 || W < 2 || H < 2 || W > 32767 || H > 32767 || R <= 0 || C <= 0 || R > MAX_MESH ||
-        C > MAX_MESH) {
-        set_error("mf_warp_u8c3: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
-        return MF_ERR_INVALID_ARG;
-    }
-    WarpGeom g;
     const uint32_t nfx = (uint32_t)((W + FOOT_W - 1) / FOOT_W), nfy = (uint32_t)((H + FOOT_H - 1) / FOOT_H);
     const FastDiv by_row = make_fast_div(nfx);
     g.per_frame = nfx * nfy;
@@ -1350,11 +1417,24 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
     g.row_bytes = 3u * (uint32_t)W;
     g.rec_frame_bytes = (uint32_t)(R * C) * (uint32_t)(MF_CELL_DOUBLES * sizeof(double));
     g.edge_frame_bytes = (uint32_t)(R * C) * (uint32_t)(MF_EDGE_FLOATS * sizeof(float));
-    // frames per launch: the grid's y extent, and 32-bit byte offsets into the plan (16 B per footprint) and the records
     const uint64_t cap = 0xFFFFFFFFull;
     uint64_t per_launch = 65535;
     per_launch = per_launch < cap / (16ull * g.per_frame) ? per_launch : cap / (16ull * g.per_frame);
     per_launch = per_launch < cap / g.rec_frame_bytes ? per_launch : cap / g.rec_frame_bytes;
+    return (uint32_t)per_launch;
+}
+
+int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n, int W, int H, int R, int C,
+                uint32_t border, int32_t* crop, hipStream_t st)
+{
+    if (const int rc = check_d16_zero_fill(st)) return rc;
+    if (n <= 0 || n > 65535 || W < 2 || H < 2 || W > 32767 || H > 32767 || R <= 0 || C <= 0 || R > MAX_MESH ||
+        C > MAX_MESH) {
+        set_error("mf_warp_u8c3: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
+        return MF_ERR_INVALID_ARG;
+    }
+    WarpGeom g;
+    uint64_t per_launch = make_warp_geom(W, H, R, C, g);
     if (per_launch == 0) {
         set_error("mf_warp_u8c3: frame too large");
         return MF_ERR_INVALID_ARG;
@@ -1380,6 +1460,29 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
             hipLaunchKernelGGL(warp_kernel<false>, grid, dim3(64), 0, st, pl, rgn, g, fr, rec, o, ed, m, W, H, C, border, crop + 4 * (size_t)f0);
     }
     return hip_fail(hipGetLastError(), "warp_kernel launch");
+}
+
+int launch_crop_scan(const TableView& tv, int n, int W, int H, int R, int C, int32_t* crop, hipStream_t st)
+{
+    if (n <= 0 || n > 65535 * 64 || W < 2 || H < 2 || W > 32767 || H > 32767 || R <= 0 || C <= 0 || R > MAX_MESH || C > MAX_MESH) {
+        set_error("mf_crop_scan_f64: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
+        return MF_ERR_INVALID_ARG;
+    }
+    WarpGeom g;
+    const uint32_t per_launch = make_warp_geom(W, H, R, C, g);
+    if (per_launch == 0) {
+        set_error("mf_crop_scan_f64: frame too large");
+        return MF_ERR_INVALID_ARG;
+    }
+    for (int f0 = 0; f0 < n; f0 += (int)per_launch) {
+        const int m = n - f0 < (int)per_launch ? n - f0 : (int)per_launch;
+        const uint32_t total = (uint32_t)m * g.per_frame;                  // (per_launch keeps 16 B x total below 2^32)
+        hipLaunchKernelGGL(crop_scan_kernel, dim3((total + SCAN_GROUP - 1) / SCAN_GROUP), dim3(64), 0, st,
+                           tv.plan + (size_t)f0 * g.per_frame, tv.regions + (size_t)f0 * g.per_frame, g,
+                           tv.records + (size_t)f0 * R * C * MF_CELL_DOUBLES, tv.edges + (size_t)f0 * R * C * MF_EDGE_FLOATS, total, m, W, H, C,
+                           crop + 4 * (size_t)f0);
+    }
+    return hip_fail(hipGetLastError(), "crop_scan_kernel launch");
 }
 
 // Clip-level bounds, mfs.py:1103-1106.

@@ -103,6 +103,13 @@ def warp(frames, table, border_bgr=(0, 0, 255), out=None):
     return out
 
 
+def crop_scan(table):
+    """The four edge scans of mfs.py:1075-1098 from the cell table alone (no frame is touched): fills table.crop exactly as
+    `warp` would.  Returns table.crop, (n, 4) int32 {left, top, right, bottom}."""
+    _lib.check(_lib_.mf_crop_scan_f64(_ptr(table.buf), table.n, table.W, table.H, table.R, table.C, _ptr(table.crop), _stream()))
+    return table.crop
+
+
 def crop_reduce(crop, W, H):
     """Clip-level bounds (mfs.py:1103-1106): int32 tensor {left, top, right, bottom}."""
     _need(crop, torch.int32, 'crop')

@@ -212,7 +212,7 @@ def test_host_warp_crop_reports_empty_rectangle():
     stab[0, ..., 0] = 60.0       # content moves right by 60 px in frame 0 ...
     stab[1, ..., 0] = -60.0      # ... and left by 60 px in frame 1: left bound 60 > right bound W - 1 - 60
     border = (ctypes.c_uint8 * 3)(0, 0, 255)
-    outs = np.zeros_like(frames); crs = np.zeros_like(frames)
+    crs = np.full_like(frames, 0xAB)
     fb = H * W * 3
     pin = (ctypes.c_void_p * F)(*[frames.ctypes.data + i * fb for i in range(F)])
     pcr = (ctypes.c_void_p * F)(*[crs.ctypes.data + i * fb for i in range(F)])
@@ -221,6 +221,10 @@ def test_host_warp_crop_reports_empty_rectangle():
     rc = _lib.lib.mf_warp_crop_u8c3_host_frames(pin, None, pcr, _p(disp), _p(stab), F, W, H, R, C, border, _p(crop), bounds, None)
     assert rc == _lib.MF_ERR_INVALID_ARG and b'empty crop rectangle' in _lib.lib.mf_last_error()
     assert bounds[0] > bounds[2]
+    # the rectangle comes from the cell table alone (mf_crop_scan_f64), before any frame moves: no output byte has been touched, and
+    # the per-frame values say which frames emptied it
+    assert (crs == 0xAB).all()
+    assert crop[0].tolist() == [60, 0, W - 1, H - 1] and crop[1].tolist() == [0, 0, W - 1 - 60, H - 1]
     # and the pipeline works again afterwards
     stab[:] = 0.0
     _lib.check(_lib.lib.mf_warp_crop_u8c3_host_frames(pin, None, pcr, _p(disp), _p(stab), F, W, H, R, C, border, _p(crop), bounds, None))
@@ -260,6 +264,44 @@ def test_full_cfg2_clip_through_raw_c_abi_equals_device_path(dev):
     assert bad == 0
     np.testing.assert_array_equal(crop[sel], ref_crop)
     assert np.array_equal(out[sel], ref)
+
+
+def test_full_cfg2_clip_crop_pipeline_equals_device_path(dev):
+    """BASELINE config 2 at full size through mf_warp_crop_u8c3_host_frames -- rectangle from the scan-only pass, then every chunk
+    uploaded, warped, cropped + resized and downloaded in ONE phase -- equals the device-resident operators (warp of the whole clip,
+    rectangle from the warp's own scan, one crop + resize of the whole clip) byte for byte; the uncropped frames never come back."""
+    import torch
+    from meshflow_amd import _lib, ops, synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    H, W, F, R, C = 1080, 1920, 300, 16, 16
+    disp, hom = synthetic.motion(F, R, C, seed=0)
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=10, optimization_num_iterations=100)
+    d_disp = torch.from_numpy(disp).to(dev)
+    d_stab = s._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
+    stab = d_stab.cpu().numpy()
+    d_frames = synthetic.frames_torch(F, H, W, dev, seed=0, kind='pattern')
+    frames = d_frames.cpu().numpy()
+    table = ops.cell_table(d_disp, d_stab, W, H, R, C)
+    d_out = ops.warp(d_frames, table)
+    rect = ops.crop_reduce(table.crop, W, H).tolist()
+    assert rect[0] > 0 and rect[2] < W - 1                   # the clip really crops
+    want = ops.crop_resize(d_out, rect).cpu().numpy()
+    want_crop = table.crop.cpu().numpy()
+    del d_frames, d_out, table
+    torch.cuda.empty_cache()
+    got = np.empty_like(frames)
+    fb = H * W * 3
+    pin = (ctypes.c_void_p * F)(*[frames.ctypes.data + i * fb for i in range(F)])
+    pcr = (ctypes.c_void_p * F)(*[got.ctypes.data + i * fb for i in range(F)])
+    crop = np.zeros((F, 4), np.int32)
+    bounds = (ctypes.c_int32 * 4)()
+    for _ in range(2):
+        _lib.check(_lib.lib.mf_warp_crop_u8c3_host_frames(pin, None, pcr, _p(np.ascontiguousarray(disp)), _p(np.ascontiguousarray(stab)), F, W, H, R, C,
+                                                          (ctypes.c_uint8 * 3)(0, 0, 255), _p(crop), bounds, None))
+        assert list(bounds) == rect
+        np.testing.assert_array_equal(crop, want_crop)
+        assert np.array_equal(got, want)
+        got[:] = 0
 
 
 def test_host_pipeline_leaves_the_current_device_alone(dev):
