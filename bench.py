@@ -187,11 +187,25 @@ def end_to_end(stab, d_frames, disp, hom, F, runs=5):
     mfs.py:150-162 including _crop_frames (mfs.py:159), only the cropped + resized frames travelling back."""
     frames = [f.copy() for f in d_frames.cpu().numpy()]           # separate allocations, like a decoder's output
     res = {}
+    clip_bytes = float(d_frames.numel())
+    try:
+        pcie = pcie_probe(d_frames.device)
+    except Exception as e:                                       # (host memory for the pinned gigabytes)
+        pcie = {'error': f'{type(e).__name__}: {e}'}
+
+    def pcie_roofline(seconds):
+        # every frame goes up once and comes down once, both directions at the same time: the bound is the link's rate per direction
+        # with both directions busy
+        peak = pcie.get('both_GBps_per_direction')
+        ach = clip_bytes / seconds / 1e9
+        return {'bound': 'pcie', 'achieved': ach, 'peak_measured': peak, 'unit': 'GB/s per direction, both directions busy',
+                'frac': (ach / peak) if peak else None, 'bytes_each_way': clip_bytes}
     for key, kw in (('', {}), ('with_crop', {'crop': True, 'keep_uncropped': False})):
         host_clip(stab, frames, disp, hom, 1, **kw)
         t = host_clip(stab, frames, disp, hom, runs, **kw)
         mean, best = float(np.mean(t)), float(np.min(t))
-        r = {'value': F / mean, 'unit': 'frames/s', 'ms_per_clip': mean * 1e3, 'min_ms_per_clip': best * 1e3, 'best_value': F / best, 'runs': runs}
+        r = {'value': F / mean, 'unit': 'frames/s', 'ms_per_clip': mean * 1e3, 'min_ms_per_clip': best * 1e3, 'best_value': F / best, 'runs': runs,
+             'roofline': pcie_roofline(mean)}
         if key:
             r['what'] = ('stabilize_clip(crop=True, keep_uncropped=False): the same + clip-level crop rectangle + _crop_frames (mfs.py:159) on the '
                          'device in the same pipeline (mf_warp_crop_u8c3_host_frames); only the cropped + resized frames come back')
@@ -201,6 +215,75 @@ def end_to_end(stab, d_frames, disp, hom, F, runs=5):
                          f'overlapped PCIe staging below Python (csrc/hostpipe.hip, mf_warp_u8c3_host_frames); mean of {runs} runs after one '
                          'untimed run, min beside it')
             res.update(r)
+    res['pcie_probe'] = pcie
+    # The ceiling of the pageable path: the same clip through the C ABI with buffers from mf_malloc_host (pinned: the copies are
+    # truly asynchronous, no staging by the runtime), raw ctypes.
+    try:
+        import ctypes
+        from meshflow_amd import _lib
+        lib = _lib.lib
+        n, H, W = len(frames), frames[0].shape[0], frames[0].shape[1]
+        nbytes = n * H * W * 3
+        hin, hout = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.mf_malloc_host(ctypes.byref(hin), nbytes))
+        _lib.check(lib.mf_malloc_host(ctypes.byref(hout), nbytes))
+        try:
+            fb = H * W * 3
+            for i, f in enumerate(frames):
+                ctypes.memmove(hin.value + i * fb, f.ctypes.data, fb)
+            unstab = np.ascontiguousarray(disp, dtype=np.float64)
+            stab_paths = stab._get_stabilized_vertex_displacements(n, frames, 0, disp, hom)
+            crop = np.zeros((n, 4), np.int32)
+            border = (ctypes.c_uint8 * 3)(*[int(c) for c in stab.color_outside_image_area_bgr])
+            p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+            t = []
+            with __import__('torch').cuda.device(d_frames.device):
+                for k in range(4):
+                    t0 = time.perf_counter()
+                    _lib.check(lib.mf_warp_u8c3_host(hin, hout, p(unstab), p(np.ascontiguousarray(stab_paths)), n, W, H, stab.mesh_row_count,
+                                                     stab.mesh_col_count, border, p(crop), None))
+                    t.append(time.perf_counter() - t0)
+            t = t[1:]
+            res['pinned_buffers'] = {'value': F / float(np.mean(t)), 'unit': 'frames/s', 'ms_per_clip': float(np.mean(t)) * 1e3, 'runs': len(t),
+                                     'roofline': pcie_roofline(float(np.mean(t))),
+                                     'what': 'mf_warp_u8c3_host on buffers from mf_malloc_host (warp stage only: paths given): the ceiling of the pageable path'}
+        finally:
+            lib.mf_free_host(hin)
+            lib.mf_free_host(hout)
+    except Exception as e:
+        res['pinned_buffers'] = {'error': f'{type(e).__name__}: {e}'}
+    return res
+
+
+def pcie_probe(device, nbytes=1 << 30, reps=3):
+    """What this box's PCIe link gives pinned host memory: hipMemcpyAsync of `nbytes` host->device and device->host, each alone and both
+    at once on two streams (GB/s per direction, best of `reps`).  The roofline of the host-to-host figures: they move every frame up
+    once and down once, concurrently."""
+    import torch
+    pin_up = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    pin_dn = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    d_up = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    d_dn = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    pin_up.fill_(1)
+    s_up, s_dn = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+
+    def run(up, down):
+        best = 1e9
+        for _ in range(reps + 1):                                # first pass untimed in effect (best-of)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if up:
+                with torch.cuda.stream(s_up):
+                    d_up.copy_(pin_up, non_blocking=True)
+            if down:
+                with torch.cuda.stream(s_dn):
+                    pin_dn.copy_(d_dn, non_blocking=True)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return nbytes / best / 1e9
+    res = {'h2d_alone_GBps': run(True, False), 'd2h_alone_GBps': run(False, True), 'both_GBps_per_direction': run(True, True),
+           'bytes': nbytes, 'note': 'pinned host memory, one hipMemcpyAsync per direction, two streams; best of 3'}
+    del pin_up, pin_dn, d_up, d_dn
     return res
 
 
@@ -248,6 +331,8 @@ def launch_children(args):
     for rank in range(args.gpus):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        # (the host driver of this pool only supports dmabuf IPC: without this RCCL and cross-process tensor sharing fail with
+        # "hipIpcGetMemHandle: invalid argument" -- the build environment's own note; an operator's setting wins)
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cpus() // args.gpus)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
@@ -292,8 +377,12 @@ def main():
                          '"clips" = N independent clips, one per GPU, no collective (BASELINE config 5); '
                          '"e2e" = host frames in -> host frames out, PCIe both ways (N independent clips when N > 1)')
     ap.add_argument('--no-e2e', action='store_true', help='skip the host-buffers-in / host-buffers-out side measurement (N = 1 only)')
-    ap.add_argument('--jacobi-stream', default='auto', choices=['auto', 'main', 'side'], help='tuning aid: where the Jacobi sweep of a step is issued '
-                    '(auto: the rule in main())')
+    ap.add_argument('--pipeline', default='product', choices=['product', 'serial'],
+                    help='"product" = MeshFlowStabilizer.stabilize_resident\'s own overlap (sweep, tables, crop scan and rectangle on its prep '
+                         'stream beside the warp chunks); "serial" = every kernel of a clip in order on one stream')
+    ap.add_argument('--rectangle', default='', choices=['', 'fused', 'early'], help='MeshFlowStabilizer.resident_rectangle for this run')
+    ap.add_argument('--chunks', type=int, default=-1, help='MeshFlowStabilizer.resident_chunks for this run (-1 = the product default, 0: in order, '
+                    'the warp alone; k >= 1: k frame ranges with tables, crop scan and rectangle beside the warp)')
     ap.add_argument('--checksum', action='store_true', help='add `frames_checksum` to the line: one position-weighted 63-bit sum per stabilized '
                     'frame of the last step (the gathered clip on rank 0 when the gather ran, else this rank\'s shard) -- for the tests')
     ap.add_argument('--as-rank-of', type=int, default=0, metavar='N',
@@ -344,6 +433,14 @@ def main():
         t = torch.tensor([seconds], dtype=torch.float64, device=device)
         return float(mfdist.all_reduce_max(t).item())
 
+    if world > 1:                                    # pre-flight, to stderr: what a first multi-GPU run needs to be debugged from its log
+        try:
+            free_b, total_b = torch.cuda.mem_get_info(device)
+            ver = '.'.join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == 'nccl' else 'n/a'
+            print(f'[rank {rank}/{world}] {torch.cuda.get_device_name(device)} {device}: {free_b / 2**30:.1f} of {total_b / 2**30:.1f} GiB free; '
+                  f'backend {dist.get_backend()} (RCCL {ver}); HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}', file=sys.stderr)
+        except Exception as e:                       # never let the report take the run down
+            print(f'[rank {rank}] pre-flight report failed: {e}', file=sys.stderr)
     comm = {'world_size': dist.get_world_size() if world > 1 else 1,
             'backend': (dist.get_backend() if world > 1 else None),
             'note': 'world size as the torch.distributed communicator reports it ("nccl" is RCCL on ROCm)'}
@@ -375,81 +472,99 @@ def main():
         return
 
     d_out = torch.empty_like(d_frames)
-    table = ops.CellTable(hi - lo, W, H, R, C, device)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     jev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     now = {'i': None}                      # index of the timed step being issued (None during warm-up)
-
-    # The three stages handed to dist.stabilize_sharded; HIP events bracket the Jacobi stage and the warp kernel on the
-    # launch stream (torch's current stream IS the stream ops.* launch on).
-    # The Jacobi sweep of a step (578 one-wave workgroups at config 2: a fraction of the chip) is issued on a SIDE stream, gated so that step
-    # i+1's sweep starts when step i's cell table + plan start (= when the warp kernel of step i-1 has ended) and joined by an event in
-    # front of step i+1's cell table: it runs under those two kernels instead of after them and has ended when the warp kernel starts
-    # (tools/step_timeline.py).  Everything else of a step stays on the main stream in order.
-    # Only when the sweep is a fraction of the chip (at most ~1024 wavefronts: config 2's 578; config 3's 2178 series fill it): a sweep that
-    # fills the chip just takes the other kernels' units away and would run on into the warp kernel, whose HIP-event time (the roofline
-    # figure) would then include it.
+    no_events = bool(os.environ.get('MF_BENCH_NO_EVENTS'))     # tuning aid: what the HIP events around the kernels cost the step
     main_stream = torch.cuda.current_stream(device)
-    ends = []                              # end-of-warp events of the last two steps issued
-    # (N > 1, and the one-GPU rehearsal of a rank of N: the replicated sweep grows with the clip -- 0.2 ms at 2400 frames -- and is what caps
-    # weak scaling, so it always goes to the side stream there; what does not fit under cell table + plan runs under the warp kernel, and that
-    # line's roofline figure then includes the interference.)
-    overlap_jacobi = int(d_disp[0].numel()) * max(1, -(-F // 320)) <= 1024 or world > 1 or args.as_rank_of > 1
-    if args.jacobi_stream != 'auto':
-        overlap_jacobi = args.jacobi_stream == 'side'
-    side = torch.cuda.Stream(device=device) if overlap_jacobi else main_stream
-    # The gate is for the one-GPU sweep (46 us, fits under cell table + plan).  The replicated sweep of an N-GPU clip (0.2 ms at 2400 frames, 39 KB
-    # of LDS per workgroup) is left ungated: gated, it would run alone and latency-bound next to every step's plan kernel and take its LDS
-    # (measured with --as-rank-of 8: 1.64 ms per step against 1.44); ungated, the queued sweeps of several steps fill the chip together.
-    gated = overlap_jacobi and world == 1 and args.as_rank_of <= 1
+    if os.environ.get('MF_MAIN_PRIORITY'):                      # tuning aid: the warp's stream at another priority than the prep stream
+        torch.cuda.synchronize()
+        main_stream = torch.cuda.Stream(device=device, priority=int(os.environ['MF_MAIN_PRIORITY']))
+        torch.cuda.set_stream(main_stream)
+    if args.chunks >= 0:
+        stab.resident_chunks = args.chunks
+    if args.rectangle:
+        stab.resident_rectangle = args.rectangle   # 'early': the rectangle from the table on the prep stream (the all-reduce of a sharded clip
+                                                   # then runs beside the warp); the default takes it from the warp's own scan, behind the warp
+    exchange_on_prep = stab.resident_chunks > 0 or stab.resident_rectangle == 'early'
 
-    def jacobi_fn():
-        i = now['i']
-        if not overlap_jacobi:
-            if i is not None and not os.environ.get('MF_BENCH_NO_EVENTS'):
-                jev[i][0].record()
-            d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
-            if i is not None and not os.environ.get('MF_BENCH_NO_EVENTS'):
-                jev[i][1].record()
+    # The timed step is the PRODUCT's device-resident pipeline (MeshFlowStabilizer.stabilize_resident, here as its two stages handed to
+    # dist.stabilize_sharded).  Default arrangement (resident_chunks = 0): cell table + plan, then the warp ALONE, then the rectangle, in
+    # order on the main stream; the Jacobi sweep on the stabilizer's prep stream, gated so that the NEXT clip's sweep runs beside THIS
+    # clip's cell table + plan -- nothing runs beside the warp kernel (measured: whatever does costs the warp more than it takes alone).
+    # --chunks k >= 1: the clip in k frame ranges, tables + crop scan + rectangle on the prep stream beside the warp.  HIP events
+    # bracket the sweep on the prep stream and the clip's warp kernel(s) on the main stream (the stream each is launched on).
+    # --pipeline serial: the same kernels in order on ONE stream, no overlap of any kind (the figure comparable with rounds 1-2);
+    # reported beside the timed figure as `serial` in every default run.
+    inputs_ready = torch.cuda.Event()
+    inputs_ready.record(main_stream)
+    serial_table = {}
+
+    def make_fns(serial):
+        def jacobi_fn():
+            i = now['i']
+            timed = i is not None and not no_events
+            if serial:
+                if timed:
+                    jev[i][0].record()
+                d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
+                if timed:
+                    jev[i][1].record()
+                return d_stab
+            prep = stab._resident_state(device)['prep']
+            if timed:
+                jev[i][0].record(prep)
+            d_stab = stab._resident_jacobi(d_disp, W, H, 0, hom, inputs_ready=inputs_ready)
+            if timed:
+                jev[i][1].record(prep)
             return d_stab
-        with torch.cuda.stream(side):
-            if gated and len(ends) >= 2:
-                side.wait_event(ends[-2])              # start when the previous step's cell table + plan start (= the warp kernel of the
-                                                       # step before it has ended), not earlier
-            if i is not None and not os.environ.get('MF_BENCH_NO_EVENTS'):
-                jev[i][0].record(side)
-            d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
-            if i is not None and not os.environ.get('MF_BENCH_NO_EVENTS'):
-                jev[i][1].record(side)
-            done = torch.cuda.Event()
-            done.record(side)
-        main_stream.wait_event(done)
-        d_stab.record_stream(main_stream)      # allocated on the side stream, read on the main one
-        return d_stab
 
-    def warp_fn(lo_, hi_, d_stab):
-        i = now['i']
-        ops.cell_table(d_disp[lo_:hi_], d_stab[lo_:hi_], W, H, R, C, table=table, reset_status=False)
-        timed = i is not None and not os.environ.get('MF_BENCH_NO_EVENTS')
-        if timed:
-            ev[i][0].record()
-        ops.warp(d_frames, table, stab.color_outside_image_area_bgr, out=d_out)
-        if timed or overlap_jacobi:                # (every marker on the stream costs the step ~5 us: one event serves as the end of the
-            end = ev[i][1] if timed else torch.cuda.Event()      # timed interval and as the gate of the sweep two steps on)
-            end.record()
-            ends.append(end)
-            del ends[:-2]
-        return d_out, table.crop           # degenerate-mesh counter accumulates in table.status (checked below)
+        def warp_fn(lo_, hi_, d_stab):
+            i = now['i']
+            timed = i is not None and not no_events
+            if serial:
+                if 't' not in serial_table:
+                    serial_table['t'] = ops.CellTable(hi_ - lo_, W, H, R, C, device)
+                table = serial_table['t']
+                ops.cell_table(d_disp[lo_:hi_], d_stab[lo_:hi_], W, H, R, C, table=table, reset_status=False)
+                if timed:
+                    ev[i][0].record()
+                ops.warp(d_frames, table, stab.color_outside_image_area_bgr, out=d_out)
+                if timed:
+                    ev[i][1].record()
+                return d_out, table
+            _, table = stab._resident_warp(d_frames, d_disp[lo_:hi_], d_stab[lo_:hi_], out=d_out, warp_events=ev[i] if timed else None)
+            return d_out, table
 
-    def crop_reduce_fn(crop):
-        return ops.crop_reduce(crop, W, H)
+        def crop_reduce_fn(table):
+            if serial:
+                return ops.crop_reduce(table.crop, W, H)
+            return table.bounds                # already reduced on the prep stream (mf_warp_clip_u8c3), final before the warp ends
+        return jacobi_fn, warp_fn, crop_reduce_fn
 
-    def step(i=None):
-        now['i'] = i
-        _, bounds, d_stab, _ = mfdist.stabilize_sharded(F, jacobi_fn, warp_fn, crop_reduce_fn, gather=False, shard=shard,
-                                                        collective=not clips_mode)
-        return d_stab, bounds
+    def exchange_ctx():
+        # the 16-byte all-reduce of a sharded clip goes to the prep stream too: beside the warp, off the critical path
+        return torch.cuda.stream(stab._resident_state(device)['prep'])
 
+    def make_step(serial):
+        fns = make_fns(serial)
+
+        def step(i=None):
+            now['i'] = i
+            _, bounds, d_stab, _ = mfdist.stabilize_sharded(F, *fns, gather=False, shard=shard, collective=not clips_mode,
+                                                            exchange_ctx=exchange_ctx if (exchange_on_prep and not serial) else None)
+            return d_stab, bounds
+        return step
+
+    def check_tables():
+        for pair in stab._resident_state(device)['tables'].values():
+            for slot in pair:
+                slot['table'].check()
+        if 't' in serial_table:
+            serial_table['t'].check()
+
+    serial_mode = args.pipeline == 'serial'
+    step = make_step(serial_mode)
     # Clock spin-up, then the W warm-up steps, then the K timed ones back to back.  After an idle period (set-up: milliseconds) this
     # GPU runs the launches of the following ~2-15 ms 5-25 % slower than in steady state (tools/resize_probe.py shows it launch by
     # launch; MF_BENCH_PER_STEP=1 shows it here) -- a power-management transient, not a property of the kernels.  ~25 ms of the same
@@ -463,11 +578,41 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         d_stab, bounds = step(i)
-    table.check()                          # degenerate-mesh check of all K steps: one 4-byte D2H, inside the timing
+    check_tables()                         # degenerate-mesh check of all K steps: 4-byte D2H per table, inside the timing
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    bounds = bounds.clone()
 
-    no_events = bool(os.environ.get('MF_BENCH_NO_EVENTS'))     # tuning aid: what the HIP events around the kernels cost the step
+    # Beside the timed figure, outside the timed region (N = 1): the latency of ONE clip through the same pipeline from an idle GPU
+    # (synchronise, issue one clip, synchronise: the sweep and the first frame range's table cannot hide behind anything), and the
+    # K steps again with everything on one stream.
+    extra = {}
+    if world == 1 and not serial_mode and not os.environ.get('MF_BENCH_NO_EXTRAS'):
+        lat = []
+        for _ in range(7):
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        extra['latency_ms_single_clip'] = {'median': float(np.median(lat)), 'min': float(np.min(lat)),
+                                           'note': 'one clip through the product pipeline between two synchronisations, right after another clip '
+                                                   '(clocks up): host issue + Jacobi sweep + first table + warp chunks; median / min of 7'}
+        sstep = make_step(True)
+        for _ in range(max(args.warmup, 3)):
+            sstep()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            sstep()
+        check_tables()
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        extra['serial'] = {'ms_per_step': serial_ms, 'value': F / (serial_ms * 1e-3), 'unit': 'frames/s',
+                           'note': 'the same K steps with every kernel of a clip in order on ONE stream (Jacobi -> cell table + plan -> warp + scan '
+                                   '-> reduce), no overlap inside or across clips: the figure comparable with rounds 1-2'}
+
     warp_ms = float('nan') if no_events else float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if os.environ.get('MF_BENCH_PER_STEP') and rank == 0 and not no_events:          # tuning aid: the launches one by one (clock transients)
         print('warp ms per step:', [round(a.elapsed_time(b), 3) for a, b in ev], file=sys.stderr)
@@ -544,6 +689,16 @@ def main():
         checksum = frame_checksums(d_out)
     if world > 1 and not clips_mode and not args.no_gather:
         try:
+            # pre-flight: rank 0 receives G x ceil(F/G) frames next to its own shard, input and output; every rank agrees on whether it fits
+            per_rank = -(-F // world)
+            need = per_rank * H * W * 3 * (world if rank == 0 else 0) + (per_rank - (hi - lo)) * H * W * 3
+            free_b, _ = torch.cuda.mem_get_info(device)
+            fits = torch.tensor([1.0 if need < 0.9 * free_b else 0.0], dtype=torch.float64, device=device)
+            fits = -mfdist.all_reduce_max(-fits)                     # min over ranks
+            if rank == 0:
+                print(f'[rank 0] gather needs {need / 2**30:.1f} GiB on rank 0, {free_b / 2**30:.1f} GiB free', file=sys.stderr)
+            if float(fits.item()) < 0.5:
+                raise MemoryError(f'gather skipped: rank 0 needs {need / 2**30:.1f} GiB, {free_b / 2**30:.1f} GiB free')
             barrier()
             t1 = time.perf_counter()
             gathered = mfdist.gather_frames(d_out, F)
@@ -577,6 +732,12 @@ def main():
                       'BASELINE.json\'s metric; its host-to-host figure (PCIe both ways) is `end_to_end`, the warp kernel\'s %HBM-roofline is `roofline`',
             'value': (F * world if clips_mode else F) * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'spinup_steps': spinup_steps, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'pipeline': ('serial: every kernel of a clip in order on one stream' if serial_mode else
+                         ('product (MeshFlowStabilizer.stabilize_resident), in order: cell table + plan -> warp alone -> rectangle on the main stream, the Jacobi '
+                          'sweep on the prep stream (the NEXT clip\'s sweep runs beside THIS clip\'s table + plan, never beside a warp)' if stab.resident_chunks <= 0 else
+                          f'product (MeshFlowStabilizer.stabilize_resident), {stab.resident_chunks} frame ranges: sweep + tables + crop scan + rectangle on the prep '
+                          'stream beside the warp chunks on the main stream') +
+                         '; clips issued back to back, `spinup_steps` untimed steps in front of the warm-up; `latency_ms_single_clip` and `serial` beside it'),
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'dtype_note': 'float64 vertex paths and pixel coordinates (as the reference), integer fixed-point interpolation on uint8',
             'data': f'synthetic ({args.frames_kind} frames, injected random mesh motion, seed 0)',
@@ -589,16 +750,22 @@ def main():
                          'traffic': traffic, 'traffic_source': 'profiles/traffic.json (PMC: size-resolved TCC_EA0_RDREQ read requests + WRITE_SIZE)'
                          if traffic else None,
                          'algorithmic_bytes_per_launch': algo_bytes, 'avg_launch_ms': warp_ms,
+                         'launches': (1 if serial_mode or stab.resident_chunks <= 0 else min(stab.resident_chunks, hi - lo)),
+                         'launch_note': ('one "launch" = the warp of ALL the step\'s frames: HIP events on the main stream in front of the first and behind the '
+                                         'last of its `launches` warp kernels (frame ranges of the clip), so the figure includes the gaps between them and '
+                                         'the prep-stream kernels (next clip\'s sweep, tables, crop scan) sharing the chip; the kernel trace under profiles/ '
+                                         'gives the kernels alone'),
                          'note': 'bound by vector and scalar instruction issue (float64 coordinates, integer blend, one wavefront per 32x8 footprint), not by HBM: DESIGN.md 4.3'},
-            'jacobi': {'avg_ms_incl_host_setup': jac_ms, 'on_side_stream': overlap_jacobi, 'kernel_ms': jac_kernel_ms,
-                       'note': 'avg_ms_incl_host_setup: HIP events around the stage on its stream -- on the side stream (on_side_stream) it runs under the '
-                               'previous step\'s cell table + plan kernels and the figure includes sharing the chip with them; kernel_ms: the kernel alone, measured after the timed region', 'series': int(d_disp[0].numel()), 'frames': F,
+            'jacobi': {'avg_ms_in_pipeline': jac_ms, 'on_prep_stream': not serial_mode, 'kernel_ms': jac_kernel_ms,
+                       'note': 'avg_ms_in_pipeline: HIP events around the stage (coefficient upload + sweep) on the stream it is issued on -- on the prep '
+                               'stream it shares the chip with the previous clip\'s warp, so this is NOT the kernel\'s own time; kernel_ms: the kernel alone, measured after the timed region', 'series': int(d_disp[0].numel()), 'frames': F,
                        'bound': 'fp64 vector ALU + LDS (the state never leaves the chip)', 'achieved': jac_flops / (jac_kernel_ms * 1e-3) / 1e12,
                        'peak': 78.6, 'unit': 'TFLOP/s', 'frac': jac_flops / (jac_kernel_ms * 1e-3) / 78.6e12},
             'crop_bounds': [int(v) for v in bounds.tolist()],
             'communicator': comm,
             'cfg1': cfg1_status(),
         }
+        result.update(extra)
         if resize_ms is not None:
             result['next_rows'] = {'crop_resize': {'kernel': 'resize_kernel', 'avg_launch_ms': resize_ms, 'bound': 'hbm',
                                                    'achieved': algo_bytes / (resize_ms * 1e-3) / 1e9, 'unit': 'GB/s',

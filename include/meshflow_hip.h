@@ -107,6 +107,24 @@ int mf_warp_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, i
  * chunk by chunk.  Running mf_warp_u8c3 on the same d_crop afterwards changes nothing (max/min of equal values). */
 int mf_crop_scan_f64(const void* d_table, int n, int W, int H, int R, int C, int32_t* d_crop, void* stream);
 
+/* ---- kernels 2a + 2b + the rectangle for a clip RESIDENT in HBM, overlapped inside the clip (csrc/clippipe.hip) ----
+ * _get_stabilized_frames_and_crop_boundaries (mfs.py:909-1108) as ONE call: mf_cell_table_f64 + mf_crop_scan_f64 + mf_crop_reduce on a
+ * PREP stream, mf_warp_u8c3 on `stream`, the clip cut into `chunks` frame ranges (1..32; 4 is a good value) so that warp(k) waits for
+ * table(k) only and everything else runs beside the warp.  d_unstab / d_stab / d_frames / d_out / d_table / d_crop / d_status as for the
+ * three calls it replaces (d_status is incremented, not reset); d_bounds: [4] int32 = the clip-level rectangle {max left, max top,
+ * min right, min bottom} of these n frames, FINAL on the prep stream right after the tables -- long before the last warp ends (a
+ * sharded run issues its 16-byte all-reduce there).  prep_stream: the caller's (work already queued on it -- e.g. the Jacobi sweep that
+ * produces d_stab -- precedes the tables; `stream` is NOT waited for, so the caller orders reuse of d_table / d_crop itself), or NULL =
+ * an internal per-device stream that starts after everything queued on `stream` so far; prep_stream == stream: everything in order on
+ * one stream.  On return `stream` has been made to wait for the prep work: stream order implies d_out, d_crop and d_bounds are final.
+ * chunks <= 0: IN ORDER -- the whole table on `stream`, then the warp alone, then (prep_stream NULL or == stream) the rectangle from the
+ * warp's own scan by one reduction; with a prep stream of the caller's the rectangle is taken EARLY from the table there (crop scan +
+ * reduction beside the start of the warp), so that a sharded run's all-reduce hides behind the warp.  This is the faster arrangement on
+ * an MI355X (kernels running beside the warp kernel cost it more than they take alone); the chunked one gives the rectangle earliest. */
+int mf_warp_clip_u8c3(const uint8_t* d_frames, uint8_t* d_out, const double* d_unstab, const double* d_stab, int n, int W, int H,
+                      int R, int C, const uint8_t border_bgr[3], void* d_table, int32_t* d_crop, int32_t* d_bounds, int32_t* d_status,
+                      int chunks, void* prep_stream, void* stream);
+
 /* Clip-level crop bounds (mfs.py:1103-1106): {max left, max top, min right, min bottom} over n frames.
  * d_bounds: [4] int32. */
 int mf_crop_reduce(const int32_t* d_crop, int n, int W, int H, int32_t* d_bounds, void* stream);
@@ -163,7 +181,10 @@ int mf_selftest_fast64(uint64_t n, uint64_t seed, uint64_t counters[3]);
 
 /* ---- host-buffer convenience wrappers (synchronous; H2D, kernels, D2H on an internal stream) ----
  * These are what a ctypes stub inside the reference's two methods would call.
- * kernel_ms (optional) receives the device time of the kernels alone, measured with HIP events. */
+ * kernel_ms (optional) receives the device time of the kernels alone, measured with HIP events.
+ * The warp wrappers do NOT work in place: input and output frames may not overlap in memory (MF_ERR_INVALID_ARG), also for the
+ * contiguous mf_warp_u8c3_host.  On any error return the contents of the output buffers are undefined (a failure that is known
+ * before the first frame moves -- bad arguments, a degenerate mesh or an empty rectangle in the crop variant -- leaves them untouched). */
 int mf_jacobi_f64_host(const double* b, double* x, const double* taps, const double* lam,
                        const double* inv_on, int F, int S, int omega, int iters, float* kernel_ms);
 int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab, const double* stab,
@@ -182,12 +203,14 @@ int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab,
 int mf_warp_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* out, const double* unstab, const double* stab,
                              int n, int W, int H, int R, int C, const uint8_t border_bgr[3],
                              int32_t* crop /* [n][4] */, float* kernel_ms);
-/* ... followed by the next step of stabilize(), _crop_frames (mfs.py:159, 1111-1157), in the same pipeline: once every chunk
- * is warped the clip-level rectangle {max left, max top, min right, min bottom} (mfs.py:1103-1106) is reduced on the device,
- * written to bounds[4], and every chunk is cropped to it and resized back to W x H (mf_crop_resize_u8c3) on its way out:
- * cropped[i] receives frame i of what stabilize() hands to the encoder.  `out` (the uncropped stabilized frames) may be NULL:
- * they then never cross PCIe.  An empty rectangle is MF_ERR_INVALID_ARG (cv2.resize fails on an empty source); bounds[] is
- * written in either case. */
+/* ... followed by the next step of stabilize(), _crop_frames (mfs.py:159, 1111-1157), in the same pipeline: before any frame
+ * moves, the cell table of the whole clip is built and the clip-level rectangle {max left, max top, min right, min bottom}
+ * (mfs.py:1103-1106) taken from it (mf_crop_scan_f64 + mf_crop_reduce: the edge scans look at the coordinate maps only) and written to
+ * bounds[4]; then every chunk goes up, is warped, cropped to the rectangle and resized back to W x H (mf_crop_resize_u8c3) and comes
+ * down in ONE phase, both PCIe directions busy throughout: cropped[i] receives frame i of what stabilize() hands to the encoder.
+ * `out` (the uncropped stabilized frames) may be NULL: they then never cross PCIe.  A degenerate mesh (MF_ERR_DEGENERATE) or an empty
+ * rectangle (MF_ERR_INVALID_ARG: cv2.resize fails on an empty source) ends the call before any frame is uploaded or any output byte
+ * written; bounds[] and crop[] are written in the second case. */
 int mf_warp_crop_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* out /* may be NULL */, uint8_t* const* cropped,
                                   const double* unstab, const double* stab, int n, int W, int H, int R, int C,
                                   const uint8_t border_bgr[3], int32_t* crop /* [n][4] */, int32_t bounds[4], float* kernel_ms);

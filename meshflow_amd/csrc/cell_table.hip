@@ -183,12 +183,15 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
     }
     if (gid <= C) grid[gid] = (int32_t)ceil((double)(W - 1) * ((double)gid / (double)C));             // vertex x
     if (gid <= R) grid[C + 1 + gid] = (int32_t)ceil((double)(H - 1) * ((double)gid / (double)R));     // vertex y
-    // Lanes past the end repeat the last cell (identical values to identical addresses) so that the whole
-    // wavefront stays active for the cross-lane reduction at the end.
-    const bool live = gid < (long long)n * ncell;
-    const long long cid = live ? gid : (long long)n * ncell - 1;
-    const int f = (int)(cid / ncell);
-    const int k = (int)(cid % ncell);
+    // One wavefront = 64 consecutive cells of ONE frame (a frame takes reach_parts(R, C) wavefronts), so that the frame's reach is a
+    // plain per-wavefront maximum: no atomics, nothing to zero beforehand.  Lanes past the frame's last cell repeat it (identical
+    // values to identical addresses) so that the whole wavefront stays active for the cross-lane reduction at the end.
+    const int wpf = reach_parts(R, C);
+    const int f = (int)(blockIdx.x / (unsigned)wpf), part = (int)(blockIdx.x % (unsigned)wpf);
+    if (f >= n) return;                    // (a launch is padded to two wavefronts when n * wpf == 1: the grid needs 65 threads)
+    const bool live = part * 64 + (int)threadIdx.x < ncell;
+    const int k = live ? part * 64 + (int)threadIdx.x : ncell - 1;
+    const long long cid = (long long)f * ncell + k;
     const int r = k / C, c = k % C;
     const size_t vbase = (size_t)f * (R + 1) * (C + 1);
     double ub[8], sb[8];
@@ -268,24 +271,17 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
         has_reach = live && box.x0 <= box.x1;
     }
     boxes[cid] = box;
-    // Per-frame maxima of the reach bound the warp kernel's candidate search.  One atomic per wavefront and
-    // frame instead of one per cell: reduce over the lanes that share a frame first.
-    unsigned long long todo = __ballot(has_reach);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int fl = __shfl(f, leader);
-        const bool mine = has_reach && f == fl;
-        int a = mine ? rxlo : 0, b = mine ? rylo : 0, c2 = mine ? rxhi : 0, d = mine ? ryhi : 0;
+    // Per-frame maxima of the reach bound the plan kernel's candidate search: this wavefront's share, reduced over its lanes and
+    // written to the frame's slot `part` (the plan kernel takes the maximum over the frame's slots).
+    int a = has_reach ? rxlo : 0, b = has_reach ? rylo : 0, c2 = has_reach ? rxhi : 0, d = has_reach ? ryhi : 0;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            a = max(a, __shfl_xor(a, off)); b = max(b, __shfl_xor(b, off));
-            c2 = max(c2, __shfl_xor(c2, off)); d = max(d, __shfl_xor(d, off));
-        }
-        if ((int)(threadIdx.x & 63) == leader) {
-            atomicMax(&reach[4 * fl + 0], a); atomicMax(&reach[4 * fl + 1], b);
-            atomicMax(&reach[4 * fl + 2], c2); atomicMax(&reach[4 * fl + 3], d);
-        }
-        todo &= ~__ballot(mine);
+    for (int off = 32; off >= 1; off >>= 1) {
+        a = max(a, __shfl_xor(a, off)); b = max(b, __shfl_xor(b, off));
+        c2 = max(c2, __shfl_xor(c2, off)); d = max(d, __shfl_xor(d, off));
+    }
+    if (threadIdx.x == 0) {
+        int32_t* slot = reach + 4 * ((size_t)f * wpf + part);
+        slot[0] = a; slot[1] = b; slot[2] = c2; slot[3] = d;
     }
 }
 
@@ -497,6 +493,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
                 // the premises of the warp kernel's error bound for its cheap coordinate chain (warp.hip, cell_coords_fast)
                 const bool fast64 = cheap_all;
                 p.e[1] = (uint16_t)(MF_PLAN_UNIT | MF_PLAN_HOT | (fast64 ? MF_PLAN_FAST64 : 0u));
+#ifndef MF_NO_COMPACT            // (A/B switch shared with warp.hip: both sides must agree on the window layout)
                 // COMPACT window: 9 rows x 112 bytes hold every tap -> one global->LDS load instead of two
                 const uint32_t cbs = (3u * (uint32_t)ix_lo) & ~3u;
                 if (iy_hi - iy_lo + 1 <= MF_COMPACT_ROWS && 3u * (uint32_t)ix_hi + 3u <= cbs + MF_COMPACT_PITCH &&
@@ -506,6 +503,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
                     region.flags_origin = MF_REGION_STAGED | MF_REGION_DEEP | MF_REGION_NOFLAG | MF_REGION_COMPACT | ((uint32_t)iy_lo * MF_COMPACT_PITCH + cbs);
                     region.src_dwords = ((uint32_t)iy_lo * (3u * (uint32_t)W) + cbs) >> 2;
                 }
+#endif
             }
             // the pair shape (`covered`: the second cell is IN, or the two single-edge masks overlap across the footprint)
             if (deep && !overflow && cnt == 2 && single_ok[0] && !(p.e[0] & MF_PLAN_IN) && wlo_all > 0.52f && whi_all < 1.9f) {
@@ -548,7 +546,20 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     const int f = (int)(blockIdx.x / (unsigned)blocks_per_frame);
     if (f >= n) return;
     const int rem0 = ((int)blockIdx.x - f * blocks_per_frame) * 256, rem = rem0 + (int)threadIdx.x;
-    const int rxlo = reach[4 * f + 0], rylo = reach[4 * f + 1], rxhi = reach[4 * f + 2], ryhi = reach[4 * f + 3];
+    // the frame's reach = maximum over the slots its cell-table wavefronts wrote (at most 64 of them)
+    __shared__ int s_reach[4];
+    {
+        const int wpf = reach_parts(R, C);
+        int v = 0;
+        if ((int)threadIdx.x < 4 * wpf) v = reach[4 * (size_t)f * wpf + threadIdx.x];      // thread t: slot t / 4, component t % 4
+#pragma unroll
+        for (int off = 32; off >= 4; off >>= 1) v = max(v, __shfl_xor(v, off));              // lanes with equal t % 4 within a wavefront
+        if (threadIdx.x < 4) s_reach[threadIdx.x] = 0;
+        __syncthreads();
+        if ((threadIdx.x & 63) < 4 && (int)(threadIdx.x & ~63u) < 4 * wpf) atomicMax(&s_reach[threadIdx.x & 3], v);
+        __syncthreads();
+    }
+    const int rxlo = s_reach[0], rylo = s_reach[1], rxhi = s_reach[2], ryhi = s_reach[3];
     const float* __restrict__ fedge = uedges + (size_t)f * R * C * MF_UEDGE_FLOATS;
     const float* __restrict__ fmargin = edges + (size_t)f * R * C * MF_EDGE_FLOATS + 12;      // the scaled set's error bounds
     const double* __restrict__ frec = records + (size_t)f * R * C * MF_CELL_DOUBLES;
@@ -621,12 +632,6 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     regions[gid] = region;
 }
 
-__global__ __launch_bounds__(256) void zero_reach_kernel(int32_t* __restrict__ reach, int count)
-{
-    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
-    if (i < count) reach[i] = 0;
-}
-
 int launch_cell_table(const double* unstab, const double* stab, int n, int W, int H, int R, int C,
                       const TableView& tv, int32_t* crop, int32_t* status, hipStream_t st)
 {
@@ -634,18 +639,12 @@ int launch_cell_table(const double* unstab, const double* stab, int n, int W, in
         set_error("mf_cell_table_f64: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
         return MF_ERR_INVALID_ARG;
     }
-    // (a kernel of our own instead of hipMemsetAsync: the runtime's fill goes through its blit path and the next kernel then starts
-    // ~6 us after it instead of right away -- tools/step_timeline.py)
-    hipLaunchKernelGGL(zero_reach_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, st, tv.reach, n * 4);
-    {
-        const int rc0 = hip_fail(hipGetLastError(), "zero_reach_kernel launch");
-        if (rc0 != MF_OK) return rc0;
-    }
-    const long long total = (long long)n * R * C;
-    long long threads = total > n ? total : n;
-    if (threads < 65) threads = 65;
-    const unsigned blocks = (unsigned)((threads + 63) / 64);
-    hipLaunchKernelGGL(cell_table_kernel, dim3(blocks), dim3(64), 0, st, unstab, stab, n, W, H, R, C, tv.records, tv.boxes,
+    // reach_parts(R, C) wavefronts per frame (64 cells each); the grid also initialises the n crop rows and the R + C + 2 vertex
+    // coordinates by global thread index: at least max(n, 65) threads (R, C <= 64)
+    long long blocks = (long long)n * reach_parts(R, C);
+    if (blocks * 64 < n) blocks = (n + 63) / 64;              // (cannot happen: every frame has a wavefront; kept as a guard)
+    if (blocks < 2) blocks = 2;
+    hipLaunchKernelGGL(cell_table_kernel, dim3((unsigned)blocks), dim3(64), 0, st, unstab, stab, n, W, H, R, C, tv.records, tv.boxes,
                        tv.edges, tv.uedges, tv.reach, tv.grid, crop, status);
     int rc = hip_fail(hipGetLastError(), "cell_table_kernel launch");
     if (rc != MF_OK) return rc;

@@ -13,9 +13,64 @@
 // OMEGA = 10, 10 at OMEGA = 30); clips longer than 64 K frames spread each series over 2-8 wavefronts.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "jacobi_kernels.h"
 
 namespace mf {
+
+// A second stream per device for launches that run beside the caller's stream (jacobi_kernels.h), with the two events of the fork /
+// join.  Created on first use, kept for the life of the process (one small object per device).
+namespace {
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; int simds = 0; int state = 0; std::mutex busy; };
+SideStream g_side[64];
+std::mutex g_side_lock;
+SideStream* side_for_current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(g_side_lock);
+    SideStream& d = g_side[dev];
+    if (d.state == 0) {
+        int cus = 0;
+        d.state = -1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
+            hipStreamCreateWithFlags(&d.s, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&d.join, hipEventDisableTiming) == hipSuccess) {
+            d.simds = 4 * cus;
+            d.state = 1;
+        }
+    }
+    return d.state == 1 ? &d : nullptr;
+}
+}  // namespace
+
+int jacobi_simd_count()
+{
+    SideStream* d = side_for_current_device();
+    return d ? d->simds : 0;
+}
+int jacobi_side_fork(hipStream_t st, hipStream_t* side)
+{
+    SideStream* d = side_for_current_device();
+    if (!d) return MF_ERR_HIP;
+    d->busy.lock();                       // (the event pair is per device: one fork ... join at a time; released by jacobi_side_join)
+    hipError_t e = hipEventRecord(d->fork, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(d->s, d->fork, 0);
+    if (e != hipSuccess) { d->busy.unlock(); return hip_fail(e, "jacobi side stream fork"); }
+    *side = d->s;
+    return MF_OK;
+}
+int jacobi_side_join(hipStream_t st)
+{
+    SideStream* d = side_for_current_device();
+    if (!d) return MF_ERR_HIP;
+    hipError_t e = hipEventRecord(d->join, d->s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, d->join, 0);
+    d->busy.unlock();
+    return hip_fail(e, "jacobi side stream join");
+}
 
 // Any other radius (mfs.py:46 accepts every temporal_smoothing_radius): the same mapping with the radius at RUN time.  A thread
 // still owns K consecutive frames and all K accumulators, but instead of holding its whole K + 2 omega window in registers it

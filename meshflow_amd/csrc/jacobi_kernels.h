@@ -39,7 +39,7 @@ template <int OMEGA, int K, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* __restrict__ b, double* __restrict__ x_out,
                                                          const double* __restrict__ taps,
                                                          const double* __restrict__ lam,
-                                                         const double* __restrict__ inv_on, int F, int S, int iters)
+                                                         const double* __restrict__ inv_on, int F, int S, int iters, int s0)
 {
     constexpr int NT = 2 * OMEGA + 1;
     constexpr int NTHR = 64 * WAVES;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* _
     // OMEGA + 1 values.  Decided per launch by a wave-uniform bit comparison; anything else takes the full table.
     constexpr bool TRY_SYM = NT > 45;
     __shared__ double xs[2][LEN];
-    const int s = blockIdx.x;
+    const int s = s0 + (int)blockIdx.x;          // (series s0 .. s0 + gridDim.x - 1 of the S: a launch may cover a slice)
     const int lane = threadIdx.x;
 
     double bt[K], two_lam[K], inv[K];
@@ -99,12 +99,19 @@ __global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* _
 
 template <int OMEGA, int K, int WAVES>
 static inline int launch_wave(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
-                       int F, int S, int iters, hipStream_t st)
+                       int F, int S, int iters, hipStream_t st, int s0 = 0, int count = -1)
 {
-    hipLaunchKernelGGL((jacobi_wave_kernel<OMEGA, K, WAVES>), dim3(S), dim3(64 * WAVES), 0, st, b, x, taps, lam, inv_on, F, S,
-                       iters);
+    hipLaunchKernelGGL((jacobi_wave_kernel<OMEGA, K, WAVES>), dim3(count < 0 ? S : count), dim3(64 * WAVES), 0, st, b, x, taps, lam, inv_on, F, S,
+                       iters, s0);
     return hip_fail(hipGetLastError(), "jacobi_wave_kernel launch");
 }
+
+// jacobi.hip: a second stream of the current device for launches that should run BESIDE the ones on `st` (the tail of a sweep whose
+// series do not fill the chip's SIMDs evenly).  fork: everything queued on `st` so far precedes what is then queued on *side; join:
+// what was queued on the side stream precedes everything queued on `st` afterwards.  jacobi_simd_count: SIMDs of the current device.
+int jacobi_side_fork(hipStream_t st, hipStream_t* side);
+int jacobi_side_join(hipStream_t st);
+int jacobi_simd_count();
 
 
 // jacobi_spec.hip, compiled once per group of radii (MF_JACOBI_GROUP = 0..3, radii 8 g + 1 .. 8 g + 8): launches the

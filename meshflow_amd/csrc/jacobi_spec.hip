@@ -3,6 +3,8 @@
 // that keeps the window in registers (5 up to omega = 12, 8 up to 20, 10 beyond) x 1 / 2 / 4 / 8 wavefronts per series, i.e. clips of up
 // to 512 K frames; omega = 10 and 30 (BASELINE configs 2-4) also have the long-clip variants (K = 10, 19).  Longer clips and larger
 // radii take jacobi.hip's run-time-radius kernel.
+#include <stdlib.h>
+
 #include "jacobi_kernels.h"
 
 #ifndef MF_JACOBI_GROUP
@@ -27,6 +29,25 @@ int launch_radius(const double* b, double* x, const double* taps, const double* 
     if (OMEGA == 10 && want > 1) {
         if (F <= 256 * 2 && want >= 4) MF_JACOBI(10, 2, 4);
         if (F <= 128 * 3) MF_JACOBI(10, 3, 2);
+    }
+    // One wavefront per series, two resident per SIMD (the K = 10 kernels need ~236 vector registers), and one wavefront alone already
+    // fills a SIMD's float64 pipe: the sweep takes (series on the busiest SIMD) x (time of one series).  With S = q SIMDs + r series the
+    // last r run as a round of their own on r SIMDs while the others idle (config 3: 2178 series on 1024 SIMDs: 2048 take 652 us, the
+    // other 130 another 181 us).  A small remainder is therefore cut into four wavefronts per series (3 frames per lane, a workgroup
+    // barrier per sweep) and launched BESIDE the main launch on a second stream: 4 r short pieces spread over 4 r SIMDs instead of r
+    // long ones.  Same arithmetic per frame in the same order: same bits.
+    if (OMEGA > 20 && want == 1 && F <= 64 * K && F <= 256 * 3) {
+        static const bool no_tail = [] { const char* v = getenv("MF_JACOBI_NO_TAIL"); return v && *v == '1'; }();       // tuning aid
+        const int simds = jacobi_simd_count(), r = simds > 0 ? S % simds : 0;
+        hipStream_t side = nullptr;
+        if (!no_tail && S > simds && r > 0 && 4 * r <= simds && jacobi_side_fork(st, &side) == MF_OK) {
+            static const int tail_waves = [] { const char* v = getenv("MF_JACOBI_TAIL_WAVES"); return v && *v ? atoi(v) : 4; }();   // tuning aid
+            int rc = tail_waves == 8 ? launch_wave<OMEGA, 2, 8>(b, x, taps, lam, inv_on, F, S, iters, side, S - r, r)
+                                     : launch_wave<OMEGA, 3, 4>(b, x, taps, lam, inv_on, F, S, iters, side, S - r, r);
+            if (rc == MF_OK) rc = launch_wave<OMEGA, K, 1>(b, x, taps, lam, inv_on, F, S, iters, st, 0, S - r);
+            const int rj = jacobi_side_join(st);
+            return rc != MF_OK ? rc : rj;
+        }
     }
     if (F <= 64 * K) MF_JACOBI(OMEGA, K, 1);
     if (F <= 128 * K) MF_JACOBI(OMEGA, K, 2);

@@ -21,6 +21,8 @@ int hip_fail(hipError_t e, const char* what);
 struct alignas(8) CellBox { int16_t x0, y0, x1, y1; };
 
 inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
+// wavefronts (64 cells each) the cell-table kernel spends on one frame = reach slots per frame
+__host__ __device__ inline int reach_parts(int R, int C) { return (R * C + 63) / 64; }
 
 // Layout of the cell table blob (mf_cell_table_bytes): records | boxes | edges | uedges | plan | regions | reach | grid.
 //   records: n*R*C x MF_CELL_DOUBLES float64      (ABI, include/meshflow_hip.h)
@@ -29,7 +31,7 @@ inline size_t table_records(int n, int R, int C) { return (size_t)n * R * C; }
 //   uedges:  n*R*C x MF_UEDGE_FLOATS float32      the same 4 functions in units of 1/32 pixel (what the plan kernel classifies with)
 //   plan:    n x ceil(H/8) x ceil(W/32) x 16 B    per 32x8-pixel footprint: candidate cells, descending
 //   regions: n x ceil(H/8) x ceil(W/32) x 8 B     per footprint: source region the warp kernel stages in LDS
-//   reach:   n x 4 int32                          per-frame max extent of a box beyond its grid rect
+//   reach:   n x reach_parts(R, C) x 4 int32      per frame and cell-table wavefront: max extent of a box beyond its grid rect
 //   grid:    (C+1) + (R+1) int32                  vertex x / y pixel coordinates
 #define MF_EDGE_FLOATS 16
 #define MF_UEDGE_FLOATS 12
@@ -121,7 +123,7 @@ inline size_t plan_offset(int n, int R, int C)
 inline size_t table_bytes(int n, int W, int H, int R, int C)
 {
     return plan_offset(n, R, C) + plan_count(n, W, H) * (sizeof(FootPlan) + sizeof(FootRegion)) +
-           (size_t)n * 4 * sizeof(int32_t) + (size_t)(R + C + 2) * sizeof(int32_t);
+           (size_t)n * reach_parts(R, C) * 4 * sizeof(int32_t) + (size_t)(R + C + 2) * sizeof(int32_t);
 }
 inline TableView table_view(void* blob, int n, int W, int H, int R, int C);
 // The part of a table that belongs to frames f0 ... (the per-frame sections advanced, the vertex grid shared): what launch_warp /
@@ -131,7 +133,7 @@ inline TableView table_slice(const TableView& t, int f0, int W, int H, int R, in
     TableView v = t;
     const size_t rec = table_records(f0, R, C), fp = (size_t)f0 * ((H + MF_FOOT_H - 1) / MF_FOOT_H) * ((W + MF_FOOT_W - 1) / MF_FOOT_W);
     v.records += rec * MF_CELL_DOUBLES; v.boxes += rec; v.edges += rec * MF_EDGE_FLOATS; v.uedges += rec * MF_UEDGE_FLOATS;
-    v.plan += fp; v.regions += fp; v.reach += (size_t)f0 * 4;
+    v.plan += fp; v.regions += fp; v.reach += (size_t)f0 * reach_parts(R, C) * 4;
     return v;
 }
 inline TableView table_view(void* blob, int n, int W, int H, int R, int C)
@@ -145,7 +147,7 @@ inline TableView table_view(void* blob, int n, int W, int H, int R, int C)
     v.plan = (FootPlan*)((char*)blob + plan_offset(n, R, C));
     v.regions = (FootRegion*)(v.plan + plan_count(n, W, H));
     v.reach = (int32_t*)(v.regions + plan_count(n, W, H));
-    v.grid = v.reach + (size_t)n * 4;
+    v.grid = v.reach + (size_t)n * reach_parts(R, C) * 4;
     return v;
 }
 

@@ -52,6 +52,7 @@
 #include "mf_common.h"
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 // At most 80 scalar registers: a CU admits min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) workgroups of 256 threads
@@ -233,6 +234,13 @@ __device__ __forceinline__ void cell_coords(crec_t rec, double xs0, double yy, i
     }
 }
 
+// (A/B switches of tools/ab_warp.py: the lane-uniform pair path and the multi path's cheap chain are built on the FAST64 helpers)
+#if defined(MF_NO_FAST64) && !defined(MF_NO_FASTPAIR)
+#define MF_NO_FASTPAIR 1
+#endif
+#if defined(MF_NO_FAST64) && !defined(MF_NO_FASTMULTI)
+#define MF_NO_FASTMULTI 1
+#endif
 #ifndef MF_NO_FAST64
 // FAST COORDINATES.  cv2.perspectiveTransform's float64 chain -- (x h0 + y h1) + h2 with every product and sum rounded, the
 // correctly rounded 1 / w, the rounded product -- only matters through its float32 conversion.  A cheaper float64 chain (fused
@@ -1311,6 +1319,9 @@ int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigne
 // the exact chain's WITHOUT their midpoint key raising the flag (must be 0), `flagged` the values whose key did (the fallback rate).
 __global__ void selftest_fast64_kernel(unsigned long long n, unsigned long long seed, unsigned long long* counters)
 {
+#ifdef MF_NO_FAST64
+    (void)n; (void)seed; (void)counters;          // (A/B build without the cheap chain: nothing to test)
+#else
     unsigned long long missed = 0, flagged = 0, tested = 0;
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
@@ -1359,6 +1370,7 @@ __global__ void selftest_fast64_kernel(unsigned long long n, unsigned long long 
     if (missed) atomicAdd(&counters[0], missed);
     if (flagged) atomicAdd(&counters[1], flagged);
     if (tested) atomicAdd(&counters[2], tested);
+#endif
 }
 
 int launch_selftest_fast64(unsigned long long n, unsigned long long seed, unsigned long long* d_counters, hipStream_t st)
@@ -1385,7 +1397,7 @@ int check_d16_zero_fill(hipStream_t st)
 {
     // per DEVICE: 0 unknown, 1 fine, -1 refused  (benign race: every thread computes the same).  The probe synchronises, so
     // mf_set_device() runs it ahead of time; a launcher only gets here first when the host selected the device itself.
-    static int state[64] = {};
+    static std::atomic<int> state[64] = {};           // (per-device host threads may get here together)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hip_fail(hipErrorInvalidDevice, "d16 probe: hipGetDevice");
     if (state[dev] == 0) {

@@ -71,12 +71,18 @@ def all_reduce_max(t):
     return t
 
 
+_SIGN = {}
+
+
 def allreduce_crop(bounds):
     """bounds: int32 tensor {left, top, right, bottom} of this rank's frames -> clip-level bounds on every
     rank (max left, max top, min right, min bottom; mfs.py:1103-1106) with ONE 16-byte all-reduce."""
     if world_size() == 1:
         return bounds
-    sign = torch.tensor([1, 1, -1, -1], dtype=bounds.dtype, device=bounds.device)
+    key = (bounds.device, bounds.dtype)
+    sign = _SIGN.get(key)
+    if sign is None:          # (made once: torch.tensor(..., device=cuda) is a blocking copy -- per step it would drain the stream)
+        sign = _SIGN[key] = torch.tensor([1, 1, -1, -1], dtype=bounds.dtype, device=bounds.device)
     packed = bounds * sign
     all_reduce_max(packed)
     return packed * sign
@@ -108,7 +114,7 @@ def gather_frames(local_frames, num_frames, dst=0):
     return None
 
 
-def stabilize_sharded(num_frames, jacobi_fn, warp_fn, crop_reduce_fn, gather=False, shard=None, collective=True):
+def stabilize_sharded(num_frames, jacobi_fn, warp_fn, crop_reduce_fn, gather=False, shard=None, collective=True, exchange_ctx=None):
     """Frame-range sharded pass of the hot path -- the function bench.py's timed step calls (with the HIP operators) and
     tests/test_dist_gloo.py drives under gloo (with the oracle standing in for the kernels).
 
@@ -117,7 +123,8 @@ def stabilize_sharded(num_frames, jacobi_fn, warp_fn, crop_reduce_fn, gather=Fal
     crop_reduce_fn(per_frame_crop) -> int32 tensor {left, top, right, bottom} of this shard
     shard: (G, g) to take the frame range of rank g of G instead of this process's place in the process group (bench.py:
     independent clips = (1, 0); rehearsal of one rank of a larger job); collective=False skips the crop all-reduce
-    (independent clips need none).
+    (independent clips need none).  exchange_ctx: a callable returning a context manager under which the crop all-reduce is issued
+    (the HIP pipeline passes its prep stream: the rectangle is final there before the warp ends, so the exchange runs beside the warp).
     Returns (local or gathered frames, clip-level crop bounds tensor, stab_all, (lo, hi))."""
     if shard is None:
         G = world_size()
@@ -127,7 +134,11 @@ def stabilize_sharded(num_frames, jacobi_fn, warp_fn, crop_reduce_fn, gather=Fal
     frames, crop = warp_fn(lo, hi, stab_all)
     bounds = crop_reduce_fn(crop)
     if collective:
-        bounds = allreduce_crop(bounds)
+        if exchange_ctx is None:
+            bounds = allreduce_crop(bounds)
+        else:
+            with exchange_ctx():
+                bounds = allreduce_crop(bounds)
     if gather:
         frames = gather_frames(frames, num_frames)
     return frames, bounds, stab_all, (lo, hi)

@@ -55,6 +55,7 @@ class CellTable:
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.crop = torch.empty((n, 4), dtype=torch.int32, device=device)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self.bounds = None            # clip-level rectangle, filled by warp_clip
 
     def records(self):
         """(n, R*C, 32) float64 view of the records (for tests)."""
@@ -101,6 +102,32 @@ def warp(frames, table, border_bgr=(0, 0, 255), out=None):
     _lib.check(_lib_.mf_warp_u8c3(_ptr(frames), _ptr(out), _ptr(table.buf), n, W, H, table.R, table.C, border,
                                   _ptr(table.crop), _stream()))
     return out
+
+
+def warp_clip(frames, unstab, stab, table, border_bgr=(0, 0, 255), out=None, chunks=4, prep_stream=None):
+    """mfs.py:909-1108 for a clip resident in HBM as ONE call overlapped inside the clip (csrc/clippipe.hip): cell table + plan +
+    crop scan + clip rectangle on `prep_stream` (a torch stream; None = the library's own, forked from the current stream), the warp
+    of `chunks` frame ranges on torch's current stream, each waiting for its own table only.  chunks=0: in order on the current
+    stream -- table, warp alone, rectangle (early on `prep_stream` when one is given).  Returns (stabilized frames,
+    table.bounds): bounds = int32 {left, top, right, bottom} of the clip, final on the prep stream right after the tables (and on
+    the current stream after the call); per-frame values in table.crop; table.status accumulates degenerate cells."""
+    _need(frames, torch.uint8, 'frames')
+    _need(unstab, torch.float64, 'unstab')
+    _need(stab, torch.float64, 'stab')
+    n, H, W, ch = frames.shape
+    V2 = (table.R + 1) * (table.C + 1) * 2
+    if ch != 3 or (n, W, H) != (table.n, table.W, table.H) or unstab.numel() != n * V2 or stab.numel() != n * V2:
+        raise ValueError('frames / displacements do not match the cell table')
+    if out is None:
+        out = torch.empty_like(frames)
+    _need(out, torch.uint8, 'out')
+    if table.bounds is None:
+        table.bounds = torch.empty(4, dtype=torch.int32, device=frames.device)
+    border = (ctypes.c_uint8 * 3)(*[int(np.clip(round(float(v)), 0, 255)) for v in border_bgr[:3]])
+    prep = ctypes.c_void_p(prep_stream.cuda_stream) if prep_stream is not None else None
+    _lib.check(_lib_.mf_warp_clip_u8c3(_ptr(frames), _ptr(out), _ptr(unstab), _ptr(stab), n, W, H, table.R, table.C, border,
+                                       _ptr(table.buf), _ptr(table.crop), _ptr(table.bounds), _ptr(table.status), int(chunks), prep, _stream()))
+    return out, table.bounds
 
 
 def crop_scan(table):

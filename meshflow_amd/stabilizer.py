@@ -418,6 +418,132 @@ class MeshFlowStabilizer:
                        self.optimization_num_iterations)
         return x.view(d_disp.shape)
 
+    # ---- the device-resident pipeline ----
+
+    # How a resident clip is issued (measured on MI355X):
+    #   0  (default) IN ORDER: cell table + plan, then the warp ALONE, on the caller's stream; only the Jacobi sweep goes to the prep
+    #      stream, gated so that the NEXT clip's sweep runs beside THIS clip's table + plan (both leave most of the chip idle) and has
+    #      ended when the warp starts.  Kernels that run beside the warp kernel cost it more than they take by themselves.
+    #   k >= 1: the clip cut into k frame ranges, tables + crop scan + rectangle on the prep stream BESIDE the warp (warp(j) waits for
+    #      table(j) only): the rectangle is known earliest, the clip takes 2-8 % longer.
+    resident_chunks = 0
+    resident_rectangle = 'fused'     # 'early': rectangle from the table on the prep stream (a sharded run's all-reduce hides behind the warp)
+
+    def _resident_state(self, dev):
+        """Per-device plumbing of `stabilize_resident`: the PREP stream beside the caller's, two cell tables per clip shape taking
+        turns, the event after which a table is free again, and the gate of the next sweep."""
+        import torch
+        st = getattr(self, '_resident', None)
+        if st is None or st['device'] != dev:
+            st = {'device': dev, 'prep': torch.cuda.Stream(device=dev), 'tables': {}, 'turn': 0, 'gate': None}
+            self._resident = st
+        return st
+
+    def _resident_jacobi(self, d_disp, frame_width, frame_height, adaptive_weights_definition, homographies, inputs_ready=None):
+        """Stage 1 of the resident pipeline, on the prep stream: mfs.py:632-710.  `inputs_ready`: a torch.cuda.Event after which
+        d_disp (and the frames) are valid, or None = whatever is queued on the current stream right now (safe, but then this clip's
+        sweep cannot start before the previous clip's warp has ended).  In-order mode gates the sweep on the previous clip having
+        reached its cell table (= the warp before it has ended): it then runs beside that table + plan, not beside a warp."""
+        import torch
+        dev = d_disp.device
+        st = self._resident_state(dev)
+        prep = st['prep']
+        if inputs_ready is None:
+            inputs_ready = torch.cuda.Event()
+            inputs_ready.record(torch.cuda.current_stream(dev))
+        prep.wait_event(inputs_ready)
+        # The gate is for sweeps of one wavefront per series (clips of up to 64 K frames: config 2's 47 us fit under cell table + plan,
+        # config 3's 0.8 ms start there).  A longer clip spreads each series over 2-8 wavefronts with up to 40 KB of LDS per workgroup
+        # (the replicated sweep of an N-GPU job): gated, it runs on into the warp and crowds it out of the CUs (rehearsal of a rank of 8:
+        # 1.68 ms per step against 1.54 in order); left ungated, the queued sweeps of several clips fill the chip together (1.48).
+        radius = self.temporal_smoothing_radius
+        one_wave = d_disp.shape[0] <= 64 * (5 if radius <= 12 else 8 if radius <= 20 else 10)
+        if self.resident_chunks <= 0 and one_wave and st['gate'] is not None:
+            prep.wait_event(st['gate'])
+        with torch.cuda.stream(prep):
+            d_stab = self._stabilized_vertex_displacements_device(d_disp, frame_width, frame_height, adaptive_weights_definition, homographies)
+            st['swept'] = torch.cuda.Event()
+            st['swept'].record(prep)
+        d_stab.record_stream(torch.cuda.current_stream(dev))      # allocated on the prep stream, handed to the caller's
+        return d_stab
+
+    def _resident_warp(self, d_frames, d_unstab, d_stab, out=None, chunks=None, warp_events=None):
+        """Stages 2-4, mfs.py:909-1108, for the d_stab `_resident_jacobi` just produced.  Returns (stabilized frames, table):
+        table.crop per frame, table.bounds the clip-level rectangle, table.status the degenerate-cell counter.
+        warp_events: two torch events recorded on the current stream in front of and behind the warp kernel(s) (bench.py's roofline)."""
+        import torch
+        from . import ops
+        dev = d_frames.device
+        st = self._resident_state(dev)
+        main = torch.cuda.current_stream(dev)
+        chunks = self.resident_chunks if chunks is None else chunks
+        n, H, W, _ = d_frames.shape
+        key = (n, W, H, self.mesh_row_count, self.mesh_col_count)
+        pair = st['tables'].get(key)
+        if pair is None:
+            pair = st['tables'][key] = [{'table': ops.CellTable(n, W, H, self.mesh_row_count, self.mesh_col_count, dev), 'free': None} for _ in range(2)]
+        slot = pair[st['turn'] & 1]
+        st['turn'] += 1
+        if chunks <= 0:
+            if st.get('swept') is not None:
+                main.wait_event(st['swept'])                      # the sweep that produced d_stab
+            st['gate'] = torch.cuda.Event()
+            st['gate'].record(main)                               # "this clip has reached its cell table": the next sweep may start
+            # (the same launches as mf_warp_clip_u8c3 with chunks = 0, issued from here so that the warp kernel can be bracketed)
+            table = ops.cell_table(d_unstab, d_stab, W, H, self.mesh_row_count, self.mesh_col_count, table=slot['table'], reset_status=False)
+            early = self.resident_rectangle == 'early'
+            if early:                                             # rectangle from the table, on the prep stream, beside the start of the warp
+                tabled = torch.cuda.Event()
+                tabled.record(main)
+                st['prep'].wait_event(tabled)
+                with torch.cuda.stream(st['prep']):
+                    table.bounds = ops.crop_reduce(ops.crop_scan(table), W, H)
+                    scanned = torch.cuda.Event()
+                    scanned.record(st['prep'])
+                table.bounds.record_stream(main)
+            if warp_events:
+                warp_events[0].record(main)
+            out = ops.warp(d_frames, table, self.color_outside_image_area_bgr, out=out)
+            if warp_events:
+                warp_events[1].record(main)
+            if early:
+                main.wait_event(scanned)
+            else:
+                table.bounds = ops.crop_reduce(table.crop, W, H)
+        else:
+            if slot['free'] is not None:
+                st['prep'].wait_event(slot['free'])               # the warps that last read this table (two clips ago) have ended
+            if warp_events:
+                warp_events[0].record(main)
+            out, _ = ops.warp_clip(d_frames, d_unstab, d_stab, slot['table'], self.color_outside_image_area_bgr, out=out,
+                                   chunks=chunks, prep_stream=st['prep'])
+            if warp_events:
+                warp_events[1].record(main)
+        slot['free'] = torch.cuda.Event()
+        slot['free'].record(main)
+        return out, slot['table']
+
+    def stabilize_resident(self, d_frames, d_disp, homographies, adaptive_weights_definition=ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL,
+                           out=None, frame_range=None, inputs_ready=None, check=True):
+        """mfs.py:150-158 for a clip whose frames (n, H, W, 3) uint8 and vertex displacements (F, R+1, C+1, 2) float64 are RESIDENT in
+        HBM: Jacobi sweep -> cell tables -> warp + crop rectangle, nothing leaves the device, one call per clip.  The sweep runs on this
+        object's prep stream: calls issued back to back overlap the next clip's sweep with this clip's cell table + plan (see
+        `resident_chunks` for the other arrangement).
+        frame_range = (lo, hi): d_frames holds frames lo..hi-1 of the clip (a frame-range shard; the sweep still covers all F).
+        Returns (stabilized frames, clip-level crop bounds as a device int32 tensor {left, top, right, bottom}, stabilized vertex
+        displacements (F, R+1, C+1, 2)), all valid in current-stream order."""
+        self._check_definition(adaptive_weights_definition)
+        F = d_disp.shape[0]
+        lo, hi = frame_range if frame_range is not None else (0, F)
+        n, H, W, _ = d_frames.shape
+        if hi - lo != n:
+            raise ValueError(f'frame_range {lo, hi} does not match {n} frames')
+        d_stab = self._resident_jacobi(d_disp, W, H, adaptive_weights_definition, homographies, inputs_ready)
+        out, table = self._resident_warp(d_frames, d_disp[lo:hi], d_stab[lo:hi], out=out)
+        if check:
+            table.check()
+        return out, table.bounds, d_stab
+
     def _stabilized_frames_device(self, d_frames, d_unstab, d_stab, out=None, table=None):
         """d_frames: (n, H, W, 3) uint8; d_unstab/d_stab: (n, R+1, C+1, 2) float64, all in HBM.
         Returns (stabilized frames (n, H, W, 3) uint8, per-frame crop values (n, 4) int32), in HBM."""

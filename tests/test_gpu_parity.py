@@ -124,6 +124,30 @@ def test_jacobi_every_radius_bit_exact_vs_c_oracle(dev, omega):
         assert np.array_equal(got, want), (omega, F, S)
 
 
+@pytest.mark.parametrize('F,S,omega,iters,symmetric', [
+    (600, 1030, 30, 5, True), (600, 1030, 30, 5, False),     # 1024 SIMDs + 6: the remainder is cut into 4 wavefronts per series on a side stream
+    (300, 1100, 25, 4, True), (640, 2178, 30, 3, True),      # config 3's series count
+    (600, 40, 30, 6, False), (700, 9, 23, 5, False), (300, 20, 22, 5, True),       # asymmetric taps: the full table (no symmetric fast path)
+    (769, 1030, 30, 3, True),                                # too long for the 3-frames-per-lane remainder kernel: plain launch
+])
+def test_jacobi_wide_radius_tail_split_and_tap_symmetry(dev, F, S, omega, iters, symmetric):
+    """Radii beyond 22 keep the OMEGA + 1 distinct values of SYMMETRIC taps in scalar registers (what mfs.py:750-752 always
+    builds) and fall back to the full table for anything else; a series count just above a multiple of the chip's SIMDs sends the
+    remainder to a second, split launch.  All bit-identical to the C oracle."""
+    from meshflow_amd import synthetic
+    from oracle import clib
+    b = np.cumsum(2.0 * synthetic.normal(np.arange(F * S).reshape(F, S), seed=F + S), axis=0)
+    taps = np.exp(-np.square((3 / omega) * np.arange(-omega, omega + 1)))
+    if not symmetric:
+        taps = taps * (1.0 + 0.3 * synthetic.uniform01(np.arange(2 * omega + 1), seed=5))
+        assert not np.array_equal(taps, taps[::-1])
+    lam = 0.1 + 0.85 * synthetic.uniform01(np.arange(F), seed=omega)
+    inv_on = 1.0 / (1 + 2 * lam * taps.sum())
+    want = clib.jacobi_banded(b, taps, lam, inv_on, omega, iters, openmp=True)
+    got = _hip_jacobi(dev, b, taps, lam, inv_on, omega, iters)
+    assert np.array_equal(got, want)
+
+
 def test_jacobi_full_cfg3_properties(dev):
     """Full config-3 size (F=600, 32x32 mesh, omega=30, 200 sweeps): linearity and constant-path fixed point."""
     from meshflow_amd import synthetic

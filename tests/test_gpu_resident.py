@@ -1,0 +1,141 @@
+"""-m gpu: the device-resident clip pipeline -- `mf_warp_clip_u8c3` (csrc/clippipe.hip: cell tables, crop scan and clip rectangle on a
+prep stream, the warp in frame-range chunks on the caller's stream, each waiting for its own table only) and
+`MeshFlowStabilizer.stabilize_resident` on top of it (the sweep on the prep stream as well, consecutive clips overlapping).
+Everything must equal the plain sequence mf_cell_table_f64 -> mf_warp_u8c3 -> mf_crop_reduce, byte for byte, whatever the chunking
+and the stream arrangement."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: the -m gpu tests must run on an MI355X')
+    return torch.device('cuda:0')
+
+
+def _clip(F, H, W, R, C, seed, **kw):
+    from meshflow_amd import synthetic
+    from oracle import meshflow_oracle as mo
+    frames, disp, hom = synthetic.clip(F, H, W, R, C, seed=seed, kind='noise', **kw)
+    stab = mo.stabilized_vertex_displacements(W, H, 0, disp, hom, 3, 10)
+    return frames, disp, stab
+
+
+def _plain(dev, d_fr, d_un, d_st, R, C, border):
+    from meshflow_amd import ops
+    n, H, W, _ = d_fr.shape
+    table = ops.cell_table(d_un, d_st, W, H, R, C)
+    out = ops.warp(d_fr, table, border)
+    bounds = ops.crop_reduce(table.crop, W, H)
+    torch.cuda.synchronize()
+    table.check()
+    return out, table.crop.clone(), bounds
+
+
+@pytest.mark.parametrize('F,H,W,R,C', [(13, 72, 100, 3, 5), (16, 96, 128, 8, 8), (3, 48, 64, 2, 2), (40, 136, 256, 4, 4)])
+@pytest.mark.parametrize('chunks', [1, 3, 4, 32])
+@pytest.mark.parametrize('streams', ['internal', 'own', 'one'])
+def test_warp_clip_equals_the_three_calls(dev, F, H, W, R, C, chunks, streams):
+    from meshflow_amd import ops
+    from oracle import clib
+    frames, disp, stab = _clip(F, H, W, R, C, seed=F + W, jitter_sigma=0.8)
+    d_fr, d_un, d_st = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (frames, disp, stab))
+    want, want_crop, want_bounds = _plain(dev, d_fr, d_un, d_st, R, C, (5, 6, 7))
+    table = ops.CellTable(F, W, H, R, C, dev)
+    prep = {'internal': None, 'own': torch.cuda.Stream(device=dev), 'one': torch.cuda.current_stream(dev)}[streams]
+    if streams == 'own':
+        prep.wait_stream(torch.cuda.current_stream(dev))          # the uploads above
+    for _ in range(2):                                            # second call: the same table and events again
+        out, bounds = ops.warp_clip(d_fr, d_un, d_st, table, (5, 6, 7), chunks=chunks, prep_stream=prep)
+        torch.cuda.synchronize()
+        table.check()
+        assert torch.equal(out, want)
+        assert torch.equal(table.crop, want_crop)
+        assert torch.equal(bounds, want_bounds)
+    ref, ref_crop, bad = clib.warp_clip(frames, R, C, disp, stab, (5, 6, 7))
+    assert bad == 0
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    np.testing.assert_array_equal(table.crop.cpu().numpy(), ref_crop)
+
+
+def test_warp_clip_counts_degenerate_cells_and_checks_arguments(dev):
+    from meshflow_amd import _lib, ops, synthetic
+    F, H, W, R, C = 9, 64, 96, 4, 4
+    frames = synthetic.frames_numpy(F, H, W, seed=1)
+    z = np.zeros((F, R + 1, C + 1, 2))
+    s = z.copy()
+    grid_x = np.array([np.ceil((W - 1) * c / C) for c in range(C + 1)])
+    s[7, :, :, 0] = -grid_x[None, :]                   # frame 7 (third chunk of four): every vertex onto x = 0
+    d_fr, d_un, d_st = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (frames, z, s))
+    table = ops.CellTable(F, W, H, R, C, dev)
+    ops.warp_clip(d_fr, d_un, d_st, table, chunks=4)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match='degenerate'):
+        table.check()
+    with pytest.raises(ValueError):
+        ops.warp_clip(d_fr[:5], d_un, d_st, table)                                     # frames do not match the table
+    assert _lib.lib.mf_warp_clip_u8c3(None, None, None, None, 1, 64, 64, 2, 2, None, None, None, None, None, 4, None, None) == _lib.MF_ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize('mode', ['in order', 'early rectangle', '4 frame ranges'])
+@pytest.mark.parametrize('frame_range', [None, (10, 31)])
+def test_stabilize_resident_equals_the_staged_device_path(dev, frame_range, mode):
+    """Three clips back to back through the product's resident pipeline (the second clip's sweep and tables run beside the first
+    clip's warp; two tables take turns), whole clip and a frame-range shard: frames, rectangle and paths equal the staged methods."""
+    from meshflow_amd import ops, synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    F, H, W, R, C = 48, 136, 256, 4, 6
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=5, optimization_num_iterations=20, device=str(dev))
+    s.resident_chunks = 4 if mode == '4 frame ranges' else 0
+    s.resident_rectangle = 'early' if mode == 'early rectangle' else 'fused'
+    lo, hi = frame_range or (0, F)
+    clips = []
+    for seed in (1, 2, 3):
+        frames, disp, hom = synthetic.clip(F, H, W, R, C, seed=seed, kind='noise', jitter_sigma=0.6)
+        clips.append((torch.from_numpy(frames[lo:hi]).to(dev), torch.from_numpy(disp).to(dev), hom))
+    want = []
+    for d_fr, d_disp, hom in clips:
+        d_stab = s._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
+        out, crop = s._stabilized_frames_device(d_fr, d_disp[lo:hi], d_stab[lo:hi])
+        want.append((out.clone(), ops.crop_reduce(crop, W, H).clone(), d_stab.clone()))
+    torch.cuda.synchronize()
+    ready = torch.cuda.Event()
+    ready.record()
+    got = []
+    for d_fr, d_disp, hom in clips:                       # issued back to back, nothing synchronises in between
+        out, bounds, d_stab = s.stabilize_resident(d_fr, d_disp, hom, frame_range=frame_range, inputs_ready=ready, check=False)
+        got.append((out, bounds.clone(), d_stab))
+    torch.cuda.synchronize()
+    for (o, b, st), (wo, wb, wst) in zip(got, want):
+        assert torch.equal(o, wo) and torch.equal(b, wb) and torch.equal(st, wst)
+    # and with the default (safe) input ordering, checking the mesh
+    out, bounds, d_stab = s.stabilize_resident(*clips[0], frame_range=frame_range)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want[0][0]) and torch.equal(bounds, want[0][1])
+
+
+def test_stabilize_resident_full_cfg2(dev):
+    """BASELINE config 2 at full size through the resident pipeline, twice back to back: equal to the staged device path."""
+    from meshflow_amd import ops, synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    F, H, W, R, C = 300, 1080, 1920, 16, 16
+    s = MeshFlowStabilizer(device=str(dev))
+    disp, hom = synthetic.motion(F, R, C, seed=0)
+    d_disp = torch.from_numpy(disp).to(dev)
+    d_frames = synthetic.frames_torch(F, H, W, dev, seed=0, kind='pattern')
+    d_stab = s._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
+    want, crop = s._stabilized_frames_device(d_frames, d_disp, d_stab)
+    want_bounds = ops.crop_reduce(crop, W, H).clone()
+    torch.cuda.synchronize()
+    out = torch.empty_like(d_frames)
+    for chunks in (0, 0, 4):
+        s.resident_chunks = chunks
+        out.zero_()
+        got, bounds, stab2 = s.stabilize_resident(d_frames, d_disp, hom, out=out)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and torch.equal(bounds, want_bounds) and torch.equal(stab2, d_stab)
