@@ -312,8 +312,8 @@ __device__ __forceinline__ void cell_range_1d(const int* g, int n, int extent, i
 
 // Classification + source region of ONE footprint.  `edge_of(k)` yields the 12 float32 edge coefficients of cell k of this
 // frame, `hi_of(k, out9)` its inverse homography as float32: from LDS when the workgroup staged its cell rows, else global.
-template <typename EdgeOf, typename HiOf, typename MarginOf, typename BoxOf>
-__device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, MarginOf margin_of, BoxOf box_of, int c_lo, int c_hi, int r_lo, int r_hi,
+template <typename EdgeOf, typename HiOf, typename MarginOf, typename BoxOf, typename RectOf>
+__device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, MarginOf margin_of, BoxOf box_of, RectOf rect_of, int c_lo, int c_hi, int r_lo, int r_hi,
                                                    int xa, int xb, int ya, int yb, int W, int H, int C, FootPlan& p, FootRegion& region)
 {
     // list entries and their edge codes, four 16-bit fields per register pair (entries 4-7 in the second): a dynamically indexed
@@ -395,7 +395,8 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
     for (int i = 0; i < 4; ++i) { p.e[i] = (uint16_t)(ent[0] >> (16 * i)); p.e[4 + i] = (uint16_t)(ent[1] >> (16 * i)); }
     if (!overflow && cnt <= 4)
         for (int i = 0; i < 4; ++i) p.e[4 + i] = (uint16_t)(codes >> (16 * i));      // short list: room for the per-entry edge codes
-    if (cnt == 1 && closed && sane) {
+    bool unit1 = false;                                            // ONE listed cell whose denominator allows the reciprocal guess
+    if (cnt == 1 && sane) {
         // one cell owns the footprint: its denominator range over the footprint (corners) and h6, for the warp kernel's reciprocal guess
         float h[9];
         hi_of((int)(p.e[0] & 0xFFFu), h);
@@ -404,7 +405,8 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             const float w = h[6] * cxs[q & 1] + h[7] * cys[q >> 1] + h[8];
             wlo = fminf(wlo, w); whi = fmaxf(whi, w);
         }
-        if (wlo > 0.52f && whi < 1.9f && fabsf(h[6]) <= 0.9f * 2.5e-4f * (wlo * wlo))
+        unit1 = wlo > 0.52f && whi < 1.9f && fabsf(h[6]) <= 0.9f * 2.5e-4f * (wlo * wlo);
+        if (unit1 && closed)
             p.e[1] = (uint16_t)MF_PLAN_UNIT;                       // (float32 evaluation: 1e-6 of error against margins of 4 % and 10 %)
     }
     if (overflow) {
@@ -453,21 +455,57 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
         const float slack = (W <= 8192 && H <= 8192) ? 0.0625f : 1.0f;
         const int ix_lo = (int)floorf(umin - slack), ix_hi = (int)floorf(umax + slack) + 1;
         const int iy_lo = (int)floorf(vmin - slack), iy_hi = (int)floorf(vmax + slack) + 1;
+        const bool whole = xb - xa == MF_FOOT_W - 1 && yb - ya == MF_FOOT_H - 1;
+        // ONE listed cell: a pixel it COVERS passes the cell's mask test, i.e. maps (by M = inverse of the forward homography, which
+        // agrees with Hi to ~1e-9) more than 1/64 pixel inside the cell's grid rect widened by one pixel -- so its taps lie in columns
+        // L-1 .. Rt+1 and rows T-1 .. B+1 whatever the corner values say (the corners of a MIXED cell's footprint may lie far outside
+        // what the cell covers).  Pixels the cell does not cover get the border colour and no tap of theirs matters.
+        int tx_lo = ix_lo, tx_hi = ix_hi, ty_lo = iy_lo, ty_hi = iy_hi;
+        if (cnt == 1) {
+            int rl, rt, rr, rb;
+            rect_of((int)(p.e[0] & 0xFFFu), rl, rt, rr, rb);
+            tx_lo = max(tx_lo, rl - 1); tx_hi = min(tx_hi, rr + 1); ty_lo = max(ty_lo, rt - 1); ty_hi = min(ty_hi, rb + 1);
+        }
         // STAGED: the window holds every tap position CLAMPED into the frame -- for a footprint whose taps all lie inside the frame
         // that is every tap; for one on the frame border the warp kernel's per-tap path reads the clamped positions and paints the
         // taps outside in the border colour (cv2.remap BORDER_CONSTANT, mfs.py:1063-1069)
-        const int cx_lo = min(max(ix_lo, 0), W - 1), cx_hi = min(max(ix_hi, 0), W - 1);
-        const int cy_lo = min(max(iy_lo, 0), H - 1), cy_hi = min(max(iy_hi, 0), H - 1);
-        const int sx0 = min(cx_lo, (3 * W - MF_STAGE_PITCH) / 3), sy0 = min(cy_lo, H - MF_STAGE_ROWS - 1);
-        if (cx_hi <= sx0 + MF_STAGE_COLS - 1 && cy_hi <= sy0 + MF_STAGE_ROWS - 1)
+        const int cx_lo = min(max(tx_lo, 0), W - 1), cx_hi = min(max(tx_hi, 0), W - 1);
+        const int cy_lo = min(max(ty_lo, 0), H - 1), cy_hi = min(max(ty_hi, 0), H - 1);
+        // the window's first byte in a frame row: the dword that holds column cx_lo, but no later than PITCH bytes before the row's
+        // end (the copy never reads past a row: the last row of the last frame has nothing behind it); columns first_col .. last_col
+        // lie completely inside it
+        const uint32_t bs = min((3u * (uint32_t)cx_lo) & ~3u, 3u * (uint32_t)W - (uint32_t)MF_STAGE_PITCH);
+        const int last_col = (int)((bs + (uint32_t)MF_STAGE_PITCH - 3u) / 3u);
+#ifndef MF_NO_BORDER
+        // BORDER window (mf_common.h): one candidate, certified denominator, whole footprint, not a deep one.  The taps of covered
+        // pixels reach at most ONE pixel outside the frame (tx / ty ranges above: L >= 0, Rt <= W-1); what they reach there is painted
+        // into the window by the kernel, which needs the bytes in front of / behind the window rows to be free.
+        const uint32_t code0b = (uint32_t)codes & 0xFFFFu;
+        const bool one_coded = cnt == 1 && !overflow && (closed || (code0b & 0x3Fu) != 4u);
+        if (one_coded && unit1 && whole && tx_lo <= tx_hi && ty_lo <= ty_hi && !(covered && ix_lo >= 1 && ix_hi <= W - 2 && iy_lo >= 1 && iy_hi <= H - 2)) {
+            const bool pl = tx_lo < 0, pr = tx_hi > W - 1, pt = ty_lo < 0, pb = ty_hi > H - 1;
+            const int sy0b = pb ? H - MF_STAGE_ROWS : min(cy_lo, H - MF_STAGE_ROWS);
+            const bool fit = cx_hi <= last_col && cy_lo >= sy0b && cy_hi <= sy0b + MF_STAGE_ROWS - 1 &&
+                             (!pl || (bs == 0u && cx_hi <= 51)) &&                                         // bytes 156..159 of every row are free
+                             (!pr || (bs == 3u * (uint32_t)W - (uint32_t)MF_STAGE_PITCH && 3u * (uint32_t)cx_lo >= bs + 3u)) &&   // bytes 0..2 are
+                             (!pt || sy0b == 0) && !(pl && pr) && !(pt && pb);
+            if (fit) {
+                region.flags_origin = MF_REGION_STAGED | MF_REGION_BORDER | (noflag ? MF_REGION_NOFLAG : 0u) | (pl ? MF_REGION_PAINT_LEFT : 0u) | (pr ? MF_REGION_PAINT_RIGHT : 0u) |
+                                      (pt ? MF_REGION_PAINT_TOP : 0u) | (pb ? MF_REGION_PAINT_BOTTOM : 0u) | ((uint32_t)sy0b * MF_STAGE_PITCH + bs);
+                region.src_dwords = ((uint32_t)sy0b * (3u * (uint32_t)W) + bs) >> 2;
+                p.e[1] = (uint16_t)(p.e[1] | MF_PLAN_BORDER);
+                return;
+            }
+        }
+#endif
+        const int sy0 = min(cy_lo, H - MF_STAGE_ROWS - 1);
+        if (cx_hi <= last_col && cy_hi <= sy0 + MF_STAGE_ROWS - 1)
         {
             // DEEP also asks for a whole footprint (all 256 pixels inside the frame): its lanes are then all active.
             // Interior: every tap inside the frame (ix_lo >= 0, ix_hi <= W - 1) and no crop flag possible -- |u| < 1 needs
             // u < 1 but u >= ix_lo + 1/16 - 1/100; |u - (W-1)| < 1 needs u > W - 2 but u < ix_hi - 1/16 + 1/100 (mfs.py:1075-1098).
-            const bool whole = xb - xa == MF_FOOT_W - 1 && yb - ya == MF_FOOT_H - 1;
             const bool interior = whole && ix_lo >= 1 && ix_hi <= W - 2 && iy_lo >= 1 && iy_hi <= H - 2;
             const bool deep = covered && interior;
-            const uint32_t bs = (3u * (uint32_t)sx0) & ~3u;
             region.flags_origin = MF_REGION_STAGED | (deep ? MF_REGION_DEEP : 0u) | (noflag ? MF_REGION_NOFLAG : 0u) | ((uint32_t)sy0 * MF_STAGE_PITCH + bs);
             region.src_dwords = ((uint32_t)sy0 * (3u * (uint32_t)W) + bs) >> 2;
             // The premises of the warp kernel's cheap coordinate chain (warp.hip, cheap_quotients) for EVERY listed cell on this footprint:
@@ -616,6 +654,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
                            [&](int k, float (&h)[9]) { for (int j = 0; j < 9; ++j) h[j] = s_hi[(k - k0) * 9 + j]; },
                            [&](int k, int e) { return fmargin[(size_t)k * MF_EDGE_FLOATS + e]; },
                            [&](int k) { return s_box[k - k0]; },
+                           [&](int k, int& rl, int& rt, int& rr, int& rb) { const int r = k / C, c = k - r * C; rl = s_gx[c]; rr = s_gx[c + 1]; rt = s_gy[r]; rb = s_gy[r + 1]; },
                            c_lo, c_hi, r_lo, r_hi, xa, xb, ya, yb, W, H, C, p, region);
     } else {
         plan_one_footprint([&](int k) { return fedge + (size_t)k * MF_UEDGE_FLOATS; },
@@ -625,6 +664,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
                            },
                            [&](int k, int e) { return fmargin[(size_t)k * MF_EDGE_FLOATS + e]; },
                            [&](int k) { return fbox[k]; },
+                           [&](int k, int& rl, int& rt, int& rr, int& rb) { const int r = k / C, c = k - r * C; rl = s_gx[c]; rr = s_gx[c + 1]; rt = s_gy[r]; rb = s_gy[r + 1]; },
                            c_lo, c_hi, r_lo, r_hi, xa, xb, ya, yb, W, H, C, p, region);
     }
     const size_t gid = (size_t)f * per_frame + rem;

@@ -61,6 +61,12 @@ __host__ __device__ inline int reach_parts(int R, int C) { return (R * C + 63) /
 // cell_coords_fast): at every pixel of the footprint |h0| x + |h1| y + |h2| <= 8 (h0 x + h1 y + h2), the same for the second row,
 // and |h6| x + |h7| y + |h8| <= 2.5.
 #define MF_PLAN_FAST64 0x0002u
+// ... and MF_PLAN_BORDER in the same unused entry 1 of a ONE-entry list (with or without UNIT / IN; never with HOT): the "border" path of the
+// warp kernel.  The single candidate is IN or MIXED with a one- / two-edge code (e[4]), its denominator is certified like UNIT's, the
+// footprint is whole, and its region is STAGED | BORDER (below): every tap of every COVERED pixel lies in the window or on the one
+// ring of pixels around the frame that the kernel paints into the window in the border colour -- so these footprints (the ring along
+// the frame border of a stabilised clip, ~3 % of all) run the staged gather instead of clamped taps + selects.
+#define MF_PLAN_BORDER 0x1000u          // (bit 12: clear in the raw row / column numbers of an overflow list, like bit 13)
 // A list of exactly TWO cells leaves entries 2 and 3 unused; MF_PLAN_HOT in entry 2 then certifies the "pair" shape: the first
 // (later, winning) cell is MIXED with ONE mask edge that can fail inside the footprint (its code in e[4]); whatever it does not take
 // belongs to the second cell (which is IN, or single-edge with the pair covering every pixel); both denominators stay in
@@ -106,6 +112,17 @@ struct alignas(8) FootRegion { uint32_t flags_origin, src_dwords; };
 // -- every source coordinate any listed cell can give it lies more than one pixel inside the frame's first / last column and row --
 // so the scan-only pass (crop_scan_kernel, warp.hip) skips it.  DEEP implies it.
 #define MF_REGION_NOFLAG 0x10000000u
+// bit 27 = BORDER (only with STAGED, never with DEEP): the window of a border-path footprint (MF_PLAN_BORDER).  Rows sy0 .. sy0 + 11 lie
+// inside the frame (sy0 <= H - 12: the kernel does not fetch a 13th row for it); bits 23-26 say which pixels just OUTSIDE the frame the
+// taps can reach and the kernel therefore paints in the border colour after the copy: column -1 (the three bytes in front of each
+// window row; the window then starts at byte 0 of the frame rows and needs no column beyond 51), column W (the three bytes behind
+// column W-1; the window then ends with the frame rows), row -1 (the LDS row in front of the window, sy0 = 0), row H (the row behind
+// it, sy0 = H - 12).
+#define MF_REGION_BORDER 0x08000000u
+#define MF_REGION_PAINT_LEFT 0x04000000u
+#define MF_REGION_PAINT_RIGHT 0x02000000u
+#define MF_REGION_PAINT_TOP 0x01000000u
+#define MF_REGION_PAINT_BOTTOM 0x00800000u
 #define MF_COMPACT_ROWS 9
 #define MF_STAGE_CHUNKS 128            // two 16-byte chunks per lane: 12 rows x 10 chunks + 8 chunks of a 13th row (unused)
 struct TableView {

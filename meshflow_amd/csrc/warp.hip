@@ -86,6 +86,9 @@ constexpr float EDGE_BAND = 1.0f;
 constexpr uint32_t OWN_ROW = 80, OWN_NONE = 8 * OWN_ROW;
 constexpr int LDS_PITCH = MF_STAGE_PITCH;
 constexpr int LDS_WINDOW_BYTES = MF_STAGE_CHUNKS * 16;
+// In front of the window: room for the LDS row of frame row -1 (and the pixel of column -1 in front of it) that the border path paints
+// in the border colour; the row of frame row H lands behind row 11, inside the window's own bytes.
+constexpr int LDS_WINDOW_PAD = 176;
 
 // a * b + c on the 24-bit multiplier.  The empty asm makes `c` opaque so that the compiler keeps two chained
 // v_mad_u32_u24 instead of re-associating them into mul + mul + add3 (no instruction is emitted by it, so the
@@ -549,7 +552,8 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     // inverse homographies of the footprint's candidate cells: [entry][Hi0..Hi8, pad] (80-byte rows)
     __shared__ __attribute__((aligned(16))) double s_hi[1][9][10];                // row 8: the "no cell" matrix, see OWN_NONE
     // source region of the footprint: MF_STAGE_ROWS rows of MF_STAGE_PITCH bytes (+ slack for the third dword of the last tap)
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[SCAN ? 16 : LDS_WINDOW_BYTES + 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_src_all[SCAN ? 16 : LDS_WINDOW_PAD + LDS_WINDOW_BYTES + 64];
+    uint8_t* const s_src = &s_src_all[SCAN ? 0 : LDS_WINDOW_PAD];
     constexpr int wave = 0;
     const uint32_t ty = (__umulhi(t, g.div_m) + (t & g.div_pass)) >> g.div_s, tx = t - ty * g.nfx;
     const int xa = (int)(tx * (uint32_t)FOOT_W), ya = (int)(ty * (uint32_t)FOOT_H);
@@ -575,6 +579,18 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         const uint8_t* __restrict__ gbase = src + ((uint64_t)src_dwords << 2);
         // (one generic -> LDS conversion: each comes with a null check)
         __attribute__((address_space(3))) uint8_t* const window = (__attribute__((address_space(3))) uint8_t*)&s_src[0];
+#ifndef MF_NO_BORDER
+        if (rg & MF_REGION_BORDER) {
+            // BORDER window: the 12 rows only (its last row may be the frame's last: there is no 13th to fetch) -- chunks 0..63, then 64..119
+            uint32_t o0 = __umul24(((uint32_t)lane * 205u) >> 11, g.row_bytes - (uint32_t)MF_STAGE_PITCH) + ((uint32_t)lane << 4);
+            uint32_t o1 = __umul24((((uint32_t)lane + 64u) * 205u) >> 11, g.row_bytes - (uint32_t)MF_STAGE_PITCH) + (((uint32_t)lane << 4) + 1024u);
+            asm("" : "+v"(o0));
+            asm("" : "+v"(o1));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o0), (__attribute__((address_space(3))) void*)window, 16, 0, 0);
+            if (lane < MF_STAGE_ROWS * 10 - 64)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o1), (__attribute__((address_space(3))) void*)(window + 1024), 16, 0, 0);
+        } else
+#endif
 #ifndef MF_NO_COMPACT
         if (rg & MF_REGION_COMPACT) {
             uint32_t o0 = __umul24(((uint32_t)lane * 37u) >> 8, g.row_bytes - (uint32_t)MF_COMPACT_PITCH) + ((uint32_t)lane << 4);
@@ -622,6 +638,117 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     }
 
     const cedge_t fedge = (cedge_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(edges) + f * g.edge_frame_bytes);
+#ifndef MF_NO_BORDER
+    if (STAGE_OK && !SCAN && ((pv.x >> 16) & (MF_PLAN_VALID | MF_PLAN_BORDER)) == MF_PLAN_BORDER) {
+        // BORDER path (the ring of footprints along the frame border of a stabilised clip, and the odd footprint a single cell only partly
+        // covers: ~3 %): ONE candidate cell -- IN, or MIXED with one or two coded mask edges -- with a certified denominator; whole
+        // footprint; every tap of a covered pixel lies in the staged window or on the ring of pixels just outside the frame, which is
+        // painted into the window in the border colour here.  So the taps come from the staged gather like everywhere else: no
+        // clamping, no per-tap selects (cv2.remap BORDER_CONSTANT, mfs.py:1063-1069).  Pixels the cell does not cover get the border
+        // colour (the map template's (W+1, H+1), mfs.py:983-984) and take no part in the crop scan; a pixel inside the float32 error
+        // band of an edge sends the wavefront to the general code.
+        const uint32_t k0 = pv.x & 0xFFFu;
+        uint32_t cov = 0xFu;
+        bool decided = true;
+        if (!(pv.x & MF_PLAN_IN)) {
+            const uint32_t cd = pv.z & 0x3Fu;
+            const cedge_t ed = fedge + k0 * MF_EDGE_FLOATS;
+            const cedge_t e1 = ed + 3u * (cd & 3u);
+            const cedge_t e2 = ed + 3u * ((cd & 8u) ? ((cd >> 4) & 3u) : (cd & 3u));     // one-edge code: the same edge twice
+            const float yf = (float)y, xf0 = (float)x0;
+            const float r1 = __builtin_fmaf(e1[1], yf, e1[2]), r2 = __builtin_fmaf(e2[1], yf, e2[2]);
+            float near = 1e30f;
+            cov = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xf = xf0 + (float)j;
+                const float gq = fminf(__builtin_fmaf(e1[0], xf, r1), __builtin_fmaf(e2[0], xf, r2));
+                cov |= gq > EDGE_BAND ? (1u << j) : 0u;
+                near = fminf(near, fabsf(gq));
+            }
+            decided = __ballot(!(near > EDGE_BAND)) == 0;           // (NaN coefficients: undecided)
+        }
+        if (decided) {
+            float u[4], v[4];
+            cell_coords<false>(frec + k0 * MF_CELL_DOUBLES, xs0, yy, x0, 0xFu, u, v, true);
+            // crop-boundary scan of the covered pixels, mfs.py:1075-1098 (exact: Sterbenz, as on the generic path)
+            {
+                const float fWm1 = (float)(W - 1), fHm1 = (float)(H - 1);
+                int c_left = 0, c_top = 0, c_right = W - 1, c_bottom = H - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if ((cov >> j) & 1u) {
+                        const int x = x0 + j;
+                        if (fabsf(u[j]) < 1.0f) c_left = max(c_left, x);
+                        if (fabsf(u[j] - fWm1) < 1.0f) c_right = min(c_right, x);
+                        if (fabsf(v[j]) < 1.0f) c_top = max(c_top, y);
+                        if (fabsf(v[j] - fHm1) < 1.0f) c_bottom = min(c_bottom, y);
+                    }
+                }
+                const bool any = c_left != 0 || c_top != 0 || c_right != W - 1 || c_bottom != H - 1;
+                if (__ballot(any) != 0) {
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        c_left = max(c_left, __shfl_xor(c_left, off));
+                        c_top = max(c_top, __shfl_xor(c_top, off));
+                        c_right = min(c_right, __shfl_xor(c_right, off));
+                        c_bottom = min(c_bottom, __shfl_xor(c_bottom, off));
+                    }
+                    if (lane == 0) {
+                        if (c_left != 0) atomicMax(&crop[4 * f + 0], c_left);
+                        if (c_top != 0) atomicMax(&crop[4 * f + 1], c_top);
+                        if (c_right != W - 1) atomicMin(&crop[4 * f + 2], c_right);
+                        if (c_bottom != H - 1) atomicMin(&crop[4 * f + 3], c_bottom);
+                    }
+                }
+            }
+            uint32_t bx[4], by[4];
+            fixed_point(u, v, bx, by);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the window has landed in LDS
+            // Paint what lies just outside the frame: whole pixels (B, G, R) at the LDS address the gather will form for them -- tap
+            // (ix, iy) sits at LDS_PITCH iy + 3 ix - lds_origin.  Column -1 / W for the rows -1 .. 12 of the window (14 lanes each), row
+            // -1 / H for the columns that lie completely inside a window row (at most 53 lanes; no tap needs any other).  LDS operations of a wavefront execute
+            // in order: the gather below sees these bytes.
+            if (rg & (MF_REGION_PAINT_LEFT | MF_REGION_PAINT_RIGHT | MF_REGION_PAINT_TOP | MF_REGION_PAINT_BOTTOM)) {
+                // (window origin in the frame from its first dword: row sy0, byte bs of the row -- bs can exceed the LDS pitch, so the
+                // LDS origin does not split uniquely)
+                const uint32_t first = src_dwords << 2;
+                const int sy0 = (int)(first / g.row_bytes), bs = (int)(first - (uint32_t)sy0 * g.row_bytes);
+                const int col0 = (bs + 2) / 3;                           // first column that starts inside the window's rows
+                const auto paint = [&](int ix, int iy) {
+                    const uint32_t at = (uint32_t)LDS_PITCH * (uint32_t)iy + 3u * (uint32_t)ix - lds_origin;      // (mod 2^32, like tap_address)
+                    volatile __attribute__((address_space(3))) uint8_t* t = (volatile __attribute__((address_space(3))) uint8_t*)(uintptr_t)at;
+                    t[0] = (uint8_t)border; t[1] = (uint8_t)(border >> 8); t[2] = (uint8_t)(border >> 16);
+                };
+                // (only the columns whose three bytes lie inside the LDS row: a neighbour's would land on the last bytes of the row in front or
+                // the first of the row behind, which may be needed)
+                const int ncols = (bs + LDS_PITCH - 3) / 3 - col0 + 1;
+                if ((rg & MF_REGION_PAINT_TOP) && lane < ncols) paint(col0 + lane, -1);
+                if ((rg & MF_REGION_PAINT_BOTTOM) && lane < ncols) paint(col0 + lane, H);
+                // (the columns LAST: column -1 of a row shares its bytes with the end of the LDS row in front -- column 52, which no tap
+                // needs -- and column W with the start of the row behind; the row paints above reach into both)
+                if ((rg & MF_REGION_PAINT_LEFT) && lane < 14) paint(-1, sy0 - 1 + lane);
+                if ((rg & MF_REGION_PAINT_RIGHT) && lane < 14) paint(W, sy0 - 1 + lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+            uint3 d = gather_blend_staged(bx, by, lds_origin);
+            if (cov != 0xFu) {
+                // pixels the cell does not cover: the border colour.  The lane's 12 bytes are B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3.
+                const uint32_t b0 = border & 0xFFu, b1 = (border >> 8) & 0xFFu, b2 = (border >> 16) & 0xFFu;
+                const uint32_t w0 = b0 | b1 << 8 | b2 << 16 | b0 << 24, w1 = b1 | b2 << 8 | b0 << 16 | b1 << 24, w2 = b2 | b0 << 8 | b1 << 16 | b2 << 24;
+                const uint32_t m0 = ((cov & 1u) ? 0x00FFFFFFu : 0u) | ((cov & 2u) ? 0xFF000000u : 0u);
+                const uint32_t m1 = ((cov & 2u) ? 0x0000FFFFu : 0u) | ((cov & 4u) ? 0xFFFF0000u : 0u);
+                const uint32_t m2 = ((cov & 4u) ? 0x000000FFu : 0u) | ((cov & 8u) ? 0xFFFFFF00u : 0u);
+                d.x = (d.x & m0) | (w0 & ~m0);
+                d.y = (d.y & m1) | (w1 & ~m1);
+                d.z = (d.z & m2) | (w2 & ~m2);
+            }
+            uint8_t* __restrict__ dstb = out + (uint64_t)f * g.frame_bytes;
+            *reinterpret_cast<uint3*>(dstb + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;     // (STAGED implies W % 4 == 0; the footprint is whole)
+            return;
+        }
+    }
+#endif
     if (STAGE_OK && !SCAN && (pv.y & MF_PLAN_HOT) != 0) {
         // Two cells share the footprint and the plan certifies the rest (a quarter of the footprints at config-2 geometry, 45 % at
         // config 3): the later cell wins wherever ONE of its mask edges passes -- one float32 fma per pixel -- and the other cell
