@@ -86,6 +86,11 @@ int mf_jacobi_f64(const double* d_b, double* d_x, const double* d_taps, const do
  * per-frame defaults {0, 0, W-1, H-1} = {left, top, right, bottom} (mfs.py:992-995).
  * d_status: one int32, incremented once per degenerate cell (zero it before the call). */
 size_t mf_cell_table_bytes(int n, int W, int H, int R, int C);
+/* Byte offset, inside the table blob, of the CLIP-LEVEL rectangle of the table's n frames: 4 int32 {max left, max top, min right,
+ * min bottom} (mfs.py:1103-1106).  mf_cell_table_f64 sets it to the defaults {0, 0, W-1, H-1}; every mf_warp_u8c3 / mf_crop_scan_f64 on
+ * the table folds its frames' values into it next to the per-frame rows of d_crop -- after the warp (or the scan) of all n frames it
+ * equals what mf_crop_reduce computes from d_crop, without that launch. */
+size_t mf_cell_table_bounds_offset(int n, int W, int H, int R, int C);
 int mf_cell_table_f64(const double* d_unstab, const double* d_stab, int n, int W, int H, int R, int C,
                       void* d_table, int32_t* d_crop, int32_t* d_status, void* stream);
 

@@ -34,6 +34,7 @@ SIGNATURES = {
     'mf_stream_synchronize': (_i, [_vp]),
     'mf_jacobi_f64': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mf_cell_table_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'mf_cell_table_bounds_offset': (_sz, [_i, _i, _i, _i, _i]),
     'mf_cell_table_f64': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'mf_warp_u8c3': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mf_crop_scan_f64': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

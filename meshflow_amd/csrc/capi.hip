@@ -89,6 +89,14 @@ size_t mf_cell_table_bytes(int n, int W, int H, int R, int C)
     return table_bytes(n, W, H, R, C);
 }
 
+size_t mf_cell_table_bounds_offset(int n, int W, int H, int R, int C)
+{
+    if (n <= 0 || R <= 0 || C <= 0 || W <= 0 || H <= 0) return 0;
+    alignas(16) static char origin[16];                    // (any address: only the offset of the section is wanted)
+    const TableView tv = table_view(origin, n, W, H, R, C);
+    return (size_t)((const char*)tv.bounds - origin);
+}
+
 int mf_cell_table_f64(const double* d_unstab, const double* d_stab, int n, int W, int H, int R, int C,
                       void* d_table, int32_t* d_crop, int32_t* d_status, void* stream)
 {

@@ -174,13 +174,14 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
                                                         int C, double* __restrict__ records,
                                                         CellBox* __restrict__ boxes, float* __restrict__ edges, float* __restrict__ uedges,
                                                         int32_t* __restrict__ reach, int32_t* __restrict__ grid,
-                                                        int32_t* __restrict__ crop, int32_t* __restrict__ status)
+                                                        int32_t* __restrict__ crop, int32_t* __restrict__ status, int32_t* __restrict__ bounds)
 {
     const int ncell = R * C;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < n) {                         // per-frame crop defaults, meshflowstabilizer.py:992-995
         crop[4 * gid + 0] = 0; crop[4 * gid + 1] = 0; crop[4 * gid + 2] = W - 1; crop[4 * gid + 3] = H - 1;
     }
+    if (gid < 4 && bounds) bounds[gid] = gid < 2 ? 0 : (gid == 2 ? W - 1 : H - 1);                      // clip-level defaults (mfs.py:992-995, 1103-1106)
     if (gid <= C) grid[gid] = (int32_t)ceil((double)(W - 1) * ((double)gid / (double)C));             // vertex x
     if (gid <= R) grid[C + 1 + gid] = (int32_t)ceil((double)(H - 1) * ((double)gid / (double)R));     // vertex y
     // One wavefront = 64 consecutive cells of ONE frame (a frame takes reach_parts(R, C) wavefronts), so that the frame's reach is a
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
 }
 
 int launch_cell_table(const double* unstab, const double* stab, int n, int W, int H, int R, int C,
-                      const TableView& tv, int32_t* crop, int32_t* status, hipStream_t st)
+                      const TableView& tv, int32_t* crop, int32_t* status, hipStream_t st, bool first_of_table)
 {
     if (n <= 0 || R <= 0 || C <= 0 || W < 2 || H < 2 || W > 32767 || H > 32767 || R > 64 || C > 64) {
         set_error("mf_cell_table_f64: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
@@ -685,7 +686,7 @@ int launch_cell_table(const double* unstab, const double* stab, int n, int W, in
     if (blocks * 64 < n) blocks = (n + 63) / 64;              // (cannot happen: every frame has a wavefront; kept as a guard)
     if (blocks < 2) blocks = 2;
     hipLaunchKernelGGL(cell_table_kernel, dim3((unsigned)blocks), dim3(64), 0, st, unstab, stab, n, W, H, R, C, tv.records, tv.boxes,
-                       tv.edges, tv.uedges, tv.reach, tv.grid, crop, status);
+                       tv.edges, tv.uedges, tv.reach, tv.grid, crop, status, first_of_table ? tv.bounds : nullptr);
     int rc = hip_fail(hipGetLastError(), "cell_table_kernel launch");
     if (rc != MF_OK) return rc;
     const size_t per_frame = plan_count(1, W, H);

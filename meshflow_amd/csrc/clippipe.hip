@@ -110,7 +110,7 @@ extern "C" int mf_warp_clip_u8c3(const uint8_t* d_frames, uint8_t* d_out, const 
     for (int i0 = 0; i0 < n; i0 += per, ++nk) {
         const int m = n - i0 < per ? n - i0 : per;
         if (const int rc = launch_cell_table(d_unstab + vb1 * i0, d_stab + vb1 * i0, m, W, H, R, C, table_slice(tv, i0, W, H, R, C),
-                                             d_crop + 4 * (size_t)i0, d_status, prep)) return rc;
+                                             d_crop + 4 * (size_t)i0, d_status, prep, i0 == 0)) return rc;
         if (!one_stream) MF_HIP_TRY(hipEventRecord(side->ready[nk], prep));
     }
     if (const int rc = launch_crop_scan(tv, n, W, H, R, C, d_crop, prep)) return rc;

@@ -33,6 +33,8 @@ __host__ __device__ inline int reach_parts(int R, int C) { return (R * C + 63) /
 //   regions: n x ceil(H/8) x ceil(W/32) x 8 B     per footprint: source region the warp kernel stages in LDS
 //   reach:   n x reach_parts(R, C) x 4 int32      per frame and cell-table wavefront: max extent of a box beyond its grid rect
 //   grid:    (C+1) + (R+1) int32                  vertex x / y pixel coordinates
+//   bounds:  4 int32                              clip-level rectangle {left, top, right, bottom} of the table's frames: set to the defaults
+//                                                 by the cell-table kernel, folded into by every warp / crop-scan launch on the table
 #define MF_EDGE_FLOATS 16
 #define MF_UEDGE_FLOATS 12
 #define MF_FOOT_W 32
@@ -126,7 +128,7 @@ struct alignas(8) FootRegion { uint32_t flags_origin, src_dwords; };
 #define MF_COMPACT_ROWS 9
 #define MF_STAGE_CHUNKS 128            // two 16-byte chunks per lane: 12 rows x 10 chunks + 8 chunks of a 13th row (unused)
 struct TableView {
-    double* records; CellBox* boxes; float* edges; float* uedges; FootPlan* plan; FootRegion* regions; int32_t* reach; int32_t* grid;
+    double* records; CellBox* boxes; float* edges; float* uedges; FootPlan* plan; FootRegion* regions; int32_t* reach; int32_t* grid; int32_t* bounds;
 };
 inline size_t plan_count(int n, int W, int H)
 {
@@ -140,7 +142,7 @@ inline size_t plan_offset(int n, int R, int C)
 inline size_t table_bytes(int n, int W, int H, int R, int C)
 {
     return plan_offset(n, R, C) + plan_count(n, W, H) * (sizeof(FootPlan) + sizeof(FootRegion)) +
-           (size_t)n * reach_parts(R, C) * 4 * sizeof(int32_t) + (size_t)(R + C + 2) * sizeof(int32_t);
+           (size_t)n * reach_parts(R, C) * 4 * sizeof(int32_t) + (size_t)(R + C + 2) * sizeof(int32_t) + 4 * sizeof(int32_t);
 }
 inline TableView table_view(void* blob, int n, int W, int H, int R, int C);
 // The part of a table that belongs to frames f0 ... (the per-frame sections advanced, the vertex grid shared): what launch_warp /
@@ -165,6 +167,7 @@ inline TableView table_view(void* blob, int n, int W, int H, int R, int C)
     v.regions = (FootRegion*)(v.plan + plan_count(n, W, H));
     v.reach = (int32_t*)(v.regions + plan_count(n, W, H));
     v.grid = v.reach + (size_t)n * reach_parts(R, C) * 4;
+    v.bounds = v.grid + (R + C + 2);
     return v;
 }
 
@@ -232,7 +235,9 @@ struct WarpGeom {
 int launch_jacobi(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
                   int F, int S, int omega, int iters, hipStream_t st);
 int launch_cell_table(const double* unstab, const double* stab, int n, int W, int H, int R, int C,
-                      const TableView& tv, int32_t* crop, int32_t* status, hipStream_t st);
+                      const TableView& tv, int32_t* crop, int32_t* status, hipStream_t st, bool first_of_table = true);
+// (first_of_table: this launch also resets the table's clip-level rectangle -- false for the later frame ranges of a table that is
+// built in several launches)
 int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n, int W, int H, int R, int C,
                 uint32_t border, int32_t* crop, hipStream_t st);
 int launch_crop_scan(const TableView& tv, int n, int W, int H, int R, int C, int32_t* crop, hipStream_t st);

@@ -547,7 +547,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
                                                const WarpGeom& g, const uint8_t* __restrict__ frames,
                                                const double* __restrict__ records, uint8_t* __restrict__ out,
                                                const float* __restrict__ edges, int n, int W,
-                                               int H, int C, uint32_t border, int32_t* __restrict__ crop)
+                                               int H, int C, uint32_t border, int32_t* __restrict__ crop, int32_t* __restrict__ clip)
 {
     // inverse homographies of the footprint's candidate cells: [entry][Hi0..Hi8, pad] (80-byte rows)
     __shared__ __attribute__((aligned(16))) double s_hi[1][9][10];                // row 8: the "no cell" matrix, see OWN_NONE
@@ -695,10 +695,11 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
                         c_bottom = min(c_bottom, __shfl_xor(c_bottom, off));
                     }
                     if (lane == 0) {
-                        if (c_left != 0) atomicMax(&crop[4 * f + 0], c_left);
-                        if (c_top != 0) atomicMax(&crop[4 * f + 1], c_top);
-                        if (c_right != W - 1) atomicMin(&crop[4 * f + 2], c_right);
-                        if (c_bottom != H - 1) atomicMin(&crop[4 * f + 3], c_bottom);
+                        // (per frame, mfs.py:1075-1098, and straight into the clip-level rectangle, mfs.py:1103-1106)
+                        if (c_left != 0) { atomicMax(&crop[4 * f + 0], c_left); atomicMax(&clip[0], c_left); }
+                        if (c_top != 0) { atomicMax(&crop[4 * f + 1], c_top); atomicMax(&clip[1], c_top); }
+                        if (c_right != W - 1) { atomicMin(&crop[4 * f + 2], c_right); atomicMin(&clip[2], c_right); }
+                        if (c_bottom != H - 1) { atomicMin(&crop[4 * f + 3], c_bottom); atomicMin(&clip[3], c_bottom); }
                     }
                 }
             }
@@ -1181,10 +1182,11 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
                     c_bottom = min(c_bottom, __shfl_xor(c_bottom, off));
                 }
                 if (lane == 0) {
-                    if (c_left != 0) atomicMax(&crop[4 * f + 0], c_left);
-                    if (c_top != 0) atomicMax(&crop[4 * f + 1], c_top);
-                    if (c_right != W - 1) atomicMin(&crop[4 * f + 2], c_right);
-                    if (c_bottom != H - 1) atomicMin(&crop[4 * f + 3], c_bottom);
+                    // (per frame, mfs.py:1075-1098, and straight into the clip-level rectangle, mfs.py:1103-1106)
+                    if (c_left != 0) { atomicMax(&crop[4 * f + 0], c_left); atomicMax(&clip[0], c_left); }
+                    if (c_top != 0) { atomicMax(&crop[4 * f + 1], c_top); atomicMax(&clip[1], c_top); }
+                    if (c_right != W - 1) { atomicMin(&crop[4 * f + 2], c_right); atomicMin(&clip[2], c_right); }
+                    if (c_bottom != H - 1) { atomicMin(&crop[4 * f + 3], c_bottom); atomicMin(&clip[3], c_bottom); }
                 }
             }
             return;
@@ -1322,10 +1324,11 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
                     c_bottom = min(c_bottom, __shfl_xor(c_bottom, off));
                 }
                 if (lane == 0) {
-                    if (c_left != 0) atomicMax(&crop[4 * f + 0], c_left);
-                    if (c_top != 0) atomicMax(&crop[4 * f + 1], c_top);
-                    if (c_right != W - 1) atomicMin(&crop[4 * f + 2], c_right);
-                    if (c_bottom != H - 1) atomicMin(&crop[4 * f + 3], c_bottom);
+                    // (per frame, mfs.py:1075-1098, and straight into the clip-level rectangle, mfs.py:1103-1106)
+                    if (c_left != 0) { atomicMax(&crop[4 * f + 0], c_left); atomicMax(&clip[0], c_left); }
+                    if (c_top != 0) { atomicMax(&crop[4 * f + 1], c_top); atomicMax(&clip[1], c_top); }
+                    if (c_right != W - 1) { atomicMin(&crop[4 * f + 2], c_right); atomicMin(&clip[2], c_right); }
+                    if (c_bottom != H - 1) { atomicMin(&crop[4 * f + 3], c_bottom); atomicMin(&clip[3], c_bottom); }
                 }
             }
         }
@@ -1350,7 +1353,7 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
                                                                WarpGeom g, const uint8_t* __restrict__ frames,
                                                                const double* __restrict__ records, uint8_t* __restrict__ out,
                                                                const float* __restrict__ edges, int n, int W,
-                                                               int H, int C, uint32_t border, int32_t* __restrict__ crop)
+                                                               int H, int C, uint32_t border, int32_t* __restrict__ crop, int32_t* __restrict__ clip)
 {
     // XCD-aware footprint order.  Workgroups go to the 8 XCDs round-robin by linear id (blockIdx.x first: gridDim.x is a multiple of
     // 8), and each XCD has its own L2: in raster order the four neighbours of a footprint -- whose staged windows overlap its own
@@ -1368,7 +1371,7 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
     const uint32_t t = (blockIdx.x & 7u) * g.per_xcd + (blockIdx.x >> 3);
 #endif
     if (t >= g.per_frame) return;
-    footprint_body<STAGE_OK, false>(f, t, plan, regions, g, frames, records, out, edges, n, W, H, C, border, crop);
+    footprint_body<STAGE_OK, false>(f, t, plan, regions, g, frames, records, out, edges, n, W, H, C, border, crop, clip);
 }
 
 // The crop-boundary scan WITHOUT the pixels (mfs.py:1075-1106 depends on the coordinate maps only, i.e. on the cell table): fills
@@ -1381,7 +1384,7 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
 constexpr uint32_t SCAN_GROUP = 16;
 __global__ __launch_bounds__(64) void crop_scan_kernel(const FootPlan* __restrict__ plan, const FootRegion* __restrict__ regions,
                                                        WarpGeom g, const double* __restrict__ records, const float* __restrict__ edges,
-                                                       uint32_t total, int n, int W, int H, int C, int32_t* __restrict__ crop)
+                                                       uint32_t total, int n, int W, int H, int C, int32_t* __restrict__ crop, int32_t* __restrict__ clip)
 {
     const uint32_t base = blockIdx.x * SCAN_GROUP, mine = base + threadIdx.x;
     bool need = false;
@@ -1392,7 +1395,7 @@ __global__ __launch_bounds__(64) void crop_scan_kernel(const FootPlan* __restric
         todo &= todo - 1;
         const uint32_t fp = __builtin_amdgcn_readfirstlane(base + bit);
         const uint32_t f = fp / g.per_frame, t = fp - f * g.per_frame;
-        footprint_body<false, true>(f, t, plan, regions, g, nullptr, records, nullptr, edges, n, W, H, C, 0u, crop);
+        footprint_body<false, true>(f, t, plan, regions, g, nullptr, records, nullptr, edges, n, W, H, C, 0u, crop, clip);
         __builtin_amdgcn_wave_barrier();             // (the next footprint reuses the wavefront's s_hi rows)
     }
 }
@@ -1594,9 +1597,9 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
         const FootPlan* pl = tv.plan + (size_t)f0 * g.per_frame;
         const FootRegion* rgn = tv.regions + (size_t)f0 * g.per_frame;
         if (stage_ok)
-            hipLaunchKernelGGL(warp_kernel<true>, grid, dim3(64), 0, st, pl, rgn, g, fr, rec, o, ed, m, W, H, C, border, crop + 4 * (size_t)f0);
+            hipLaunchKernelGGL(warp_kernel<true>, grid, dim3(64), 0, st, pl, rgn, g, fr, rec, o, ed, m, W, H, C, border, crop + 4 * (size_t)f0, tv.bounds);
         else
-            hipLaunchKernelGGL(warp_kernel<false>, grid, dim3(64), 0, st, pl, rgn, g, fr, rec, o, ed, m, W, H, C, border, crop + 4 * (size_t)f0);
+            hipLaunchKernelGGL(warp_kernel<false>, grid, dim3(64), 0, st, pl, rgn, g, fr, rec, o, ed, m, W, H, C, border, crop + 4 * (size_t)f0, tv.bounds);
     }
     return hip_fail(hipGetLastError(), "warp_kernel launch");
 }
@@ -1619,7 +1622,7 @@ int launch_crop_scan(const TableView& tv, int n, int W, int H, int R, int C, int
         hipLaunchKernelGGL(crop_scan_kernel, dim3((total + SCAN_GROUP - 1) / SCAN_GROUP), dim3(64), 0, st,
                            tv.plan + (size_t)f0 * g.per_frame, tv.regions + (size_t)f0 * g.per_frame, g,
                            tv.records + (size_t)f0 * R * C * MF_CELL_DOUBLES, tv.edges + (size_t)f0 * R * C * MF_EDGE_FLOATS, total, m, W, H, C,
-                           crop + 4 * (size_t)f0);
+                           crop + 4 * (size_t)f0, tv.bounds);
     }
     return hip_fail(hipGetLastError(), "crop_scan_kernel launch");
 }

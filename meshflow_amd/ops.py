@@ -56,6 +56,10 @@ class CellTable:
         self.crop = torch.empty((n, 4), dtype=torch.int32, device=device)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
         self.bounds = None            # clip-level rectangle, filled by warp_clip
+        off = _lib_.mf_cell_table_bounds_offset(n, W, H, R, C)
+        # the same rectangle as the kernels fold it together inside the table blob (valid after the warp / crop scan of all n frames;
+        # overwritten by the next cell_table on this object)
+        self.clip_bounds = self.buf[off:off + 16].view(torch.int32)
 
     def records(self):
         """(n, R*C, 32) float64 view of the records (for tests)."""

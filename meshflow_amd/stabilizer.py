@@ -435,7 +435,7 @@ class MeshFlowStabilizer:
         import torch
         st = getattr(self, '_resident', None)
         if st is None or st['device'] != dev:
-            st = {'device': dev, 'prep': torch.cuda.Stream(device=dev), 'tables': {}, 'turn': 0, 'gate': None}
+            st = {'device': dev, 'prep': torch.cuda.Stream(device=dev), 'tables': {}, 'turn': 0, 'ends': []}
             self._resident = st
         return st
 
@@ -458,8 +458,8 @@ class MeshFlowStabilizer:
         # 1.68 ms per step against 1.54 in order); left ungated, the queued sweeps of several clips fill the chip together (1.48).
         radius = self.temporal_smoothing_radius
         one_wave = d_disp.shape[0] <= 64 * (5 if radius <= 12 else 8 if radius <= 20 else 10)
-        if self.resident_chunks <= 0 and one_wave and st['gate'] is not None:
-            prep.wait_event(st['gate'])
+        if self.resident_chunks <= 0 and one_wave and len(st['ends']) >= 2:
+            prep.wait_event(st['ends'][-2])       # the warp two clips back has ended = the previous clip has reached its cell table
         with torch.cuda.stream(prep):
             d_stab = self._stabilized_vertex_displacements_device(d_disp, frame_width, frame_height, adaptive_weights_definition, homographies)
             st['swept'] = torch.cuda.Event()
@@ -487,8 +487,8 @@ class MeshFlowStabilizer:
         if chunks <= 0:
             if st.get('swept') is not None:
                 main.wait_event(st['swept'])                      # the sweep that produced d_stab
-            st['gate'] = torch.cuda.Event()
-            st['gate'].record(main)                               # "this clip has reached its cell table": the next sweep may start
+            # (every marker on a stream costs the step ~5 us -- DESIGN.md section 5 -- so ONE event per clip, recorded behind its warp,
+            # serves as the end of a timed interval, as "this table is free again" and, two clips on, as the gate of a sweep)
             # (the same launches as mf_warp_clip_u8c3 with chunks = 0, issued from here so that the warp kernel can be bracketed)
             table = ops.cell_table(d_unstab, d_stab, W, H, self.mesh_row_count, self.mesh_col_count, table=slot['table'], reset_status=False)
             early = self.resident_rectangle == 'early'
@@ -497,19 +497,24 @@ class MeshFlowStabilizer:
                 tabled.record(main)
                 st['prep'].wait_event(tabled)
                 with torch.cuda.stream(st['prep']):
-                    table.bounds = ops.crop_reduce(ops.crop_scan(table), W, H)
+                    ops.crop_scan(table)
+                    table.bounds = table.clip_bounds      # (the scan folds the clip-level rectangle together as well)
                     scanned = torch.cuda.Event()
                     scanned.record(st['prep'])
-                table.bounds.record_stream(main)
             if warp_events:
                 warp_events[0].record(main)
             out = ops.warp(d_frames, table, self.color_outside_image_area_bgr, out=out)
-            if warp_events:
-                warp_events[1].record(main)
+            end = warp_events[1] if warp_events else torch.cuda.Event()
+            end.record(main)
+            st['ends'].append(end)
+            del st['ends'][:-2]
+            slot['free'] = end
             if early:
                 main.wait_event(scanned)
             else:
-                table.bounds = ops.crop_reduce(table.crop, W, H)
+                table.bounds = table.clip_bounds       # folded together by the warp kernel itself (no reduction launch); it lives in the
+                                                       # table: valid until this table's next turn, two clips on
+            return out, slot['table']
         else:
             if slot['free'] is not None:
                 st['prep'].wait_event(slot['free'])               # the warps that last read this table (two clips ago) have ended

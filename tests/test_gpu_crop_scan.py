@@ -31,10 +31,15 @@ def _scan_and_warp(dev, frames, R, C, unstab, stab, border=(0, 0, 255)):
     d_fr = torch.from_numpy(frames).to(dev)
     table = ops.cell_table(d_un, d_st, W, H, R, C)
     scanned = ops.crop_scan(table).clone()
+    # the clip-level rectangle the kernels fold together inside the table blob (no reduction launch) equals mf_crop_reduce's
+    assert torch.equal(table.clip_bounds, ops.crop_reduce(scanned, W, H))
     out = ops.warp(d_fr, table, border)
     after = table.crop.clone()
+    assert torch.equal(table.clip_bounds, ops.crop_reduce(after, W, H))
     table2 = ops.cell_table(d_un, d_st, W, H, R, C)
+    assert table2.clip_bounds.tolist() == [0, 0, W - 1, H - 1]
     ops.warp(d_fr, table2, border)
+    assert torch.equal(table2.clip_bounds, ops.crop_reduce(table2.crop, W, H))
     torch.cuda.synchronize()
     table.check()
     return scanned.cpu().numpy(), after.cpu().numpy(), table2.crop.cpu().numpy(), out.cpu().numpy()

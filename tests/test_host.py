@@ -107,7 +107,9 @@ def test_library_exports_every_symbol_in_the_header():
     for name in declared:
         assert hasattr(_lib.lib, name), name
     assert _lib.lib.mf_abi_version() == 1
-    assert _lib.lib.mf_cell_table_bytes(2, 96, 64, 4, 4) == 2 * 16 * (32 * 8 + 8 + 28 * 4) + 2 * 8 * 3 * (16 + 8) + 2 * 16 + 10 * 4
+    # records + boxes + two edge sets | plan + regions per footprint | one reach slot per frame (16 cells = 1 wavefront) | grid | clip rectangle
+    assert _lib.lib.mf_cell_table_bytes(2, 96, 64, 4, 4) == 2 * 16 * (32 * 8 + 8 + 28 * 4) + 2 * 8 * 3 * (16 + 8) + 2 * 16 + 10 * 4 + 16
+    assert _lib.lib.mf_cell_table_bounds_offset(2, 96, 64, 4, 4) == _lib.lib.mf_cell_table_bytes(2, 96, 64, 4, 4) - 16
 
 
 def test_product_never_imports_the_oracle():

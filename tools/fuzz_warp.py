@@ -45,6 +45,7 @@ def run(cases, seed, verbose=True, large=False):
       d_fr = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
       try:
           table = ops.cell_table(torch.from_numpy(unstab).to(dev), torch.from_numpy(np.ascontiguousarray(stab)).to(dev), W, H, R, C)
+          scanned = ops.crop_scan(table).clone()                  # the scan-only pass (mf_crop_scan_f64) must fill the same values
           out = ops.warp(d_fr, table, (0, 0, 255))
           torch.cuda.synchronize()
           table.check()
@@ -58,7 +59,7 @@ def run(cases, seed, verbose=True, large=False):
           bad_total += 1
           continue
       diff = int((out.cpu().numpy() != want).sum())
-      cdiff = int((table.crop.cpu().numpy() != want_crop).sum())
+      cdiff = int((table.crop.cpu().numpy() != want_crop).sum()) + int((scanned.cpu().numpy() != want_crop).sum())
       if diff or cdiff:
           bad_total += 1
           print(f'case {case}: {W}x{H} mesh {R}x{C} n={n} style {style:.2f}: {diff} bytes, {cdiff} crop values differ  <-- MISMATCH')
