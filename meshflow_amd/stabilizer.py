@@ -216,6 +216,10 @@ class MeshFlowStabilizer:
         import torch
         from . import pipeline
         self._check_definition(adaptive_weights_definition)
+        if chunk_frames != 16 or io_threads != 3:
+            import warnings
+            warnings.warn('stabilize_clip: chunk_frames / io_threads are ignored since the frames travel through the C pipeline '
+                          '(csrc/hostpipe.hip); tune it with MF_PIPE_CHUNK / MF_PIPE_UP / MF_PIPE_DOWN in the environment', DeprecationWarning, stacklevel=2)
         num_frames = len(unstabilized_frames)
         dev = self._torch_device()
         unstab = np.ascontiguousarray(vertex_unstabilized_displacements_by_frame_index, dtype=np.float64)

@@ -38,7 +38,7 @@ def _plain(dev, d_fr, d_un, d_st, R, C, border):
 
 
 @pytest.mark.parametrize('F,H,W,R,C', [(13, 72, 100, 3, 5), (16, 96, 128, 8, 8), (3, 48, 64, 2, 2), (40, 136, 256, 4, 4)])
-@pytest.mark.parametrize('chunks', [1, 3, 4, 32])
+@pytest.mark.parametrize('chunks', [0, 1, 3, 4, 32])           # 0: in order (rectangle behind the warp, or early on a prep stream of the caller's)
 @pytest.mark.parametrize('streams', ['internal', 'own', 'one'])
 def test_warp_clip_equals_the_three_calls(dev, F, H, W, R, C, chunks, streams):
     from meshflow_amd import ops
