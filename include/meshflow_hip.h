@@ -201,7 +201,7 @@ int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab,
  * eight threads that fault the output pages in ahead of the downloads); a chunk is warped as soon as it has landed and
  * travels back while later chunks are still going up (pageable memory is fine; memory from mf_malloc_host makes the
  * copies truly asynchronous).  MF_PIPE_CHUNK / MF_PIPE_UP / MF_PIPE_DOWN / MF_PIPE_POPULATE in the environment retune it
- * (read at every call).  Input and output frames must NOT overlap in memory (MF_ERR_INVALID_ARG): output pages are touched
+ * (read at every call; MF_PIPE_TRACE=1 prints the call's wall-clock milestones on stderr).  Input and output frames must NOT overlap in memory (MF_ERR_INVALID_ARG): output pages are touched
  * while the input is still being read.  Device buffers and streams are kept between calls, grow-only, ONE CACHE PER DEVICE
  * (the calling thread's current device, mf_set_device): calls on one device are serialised, calls on different devices
  * from different host threads run concurrently; mf_host_cache_release() frees all of them. */

@@ -19,7 +19,10 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <stdio.h>
+
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -256,6 +259,10 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
         }
     }
 
+    // MF_PIPE_TRACE=1: wall-clock milestones of the call on stderr (where a slow host loses its time: page population, uploads, downloads)
+    const bool trace = env_int("MF_PIPE_TRACE", 0, 0, 1) != 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     Shared sh;
     sh.up_ready.assign(nchunks, 0);
     sh.warp_ready.assign(nchunks, 0);
@@ -271,6 +278,7 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
             for (int k = t; k < nchunks; k += n_pop) {       // chunk by chunk, in the order the downloads will need the pages
                 if (out) { populate_frames(out, k * chunk, chunk_end(k), fb); sh.mark(sh.populated, k); }
                 if (cropped) { populate_frames(cropped, k * chunk, chunk_end(k), fb); sh.mark(sh.populated2, k); }
+                if (trace && (k == nchunks - 1 || k == 0)) fprintf(stderr, "[mf pipe] %8.2f ms  pages of chunk %d populated\n", since(), k);
             }
         });
     for (int t = 0; t < n_up; ++t)
@@ -282,6 +290,7 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
                 if (e == hipSuccess) e = hipEventRecord(up_done[k], pc.up[t]);
                 if (e != hipSuccess) { sh.fail(e, "upload of a frame chunk"); return; }
                 sh.mark(sh.up_ready, k);
+                if (trace && (k == nchunks - 1 || k < 2)) fprintf(stderr, "[mf pipe] %8.2f ms  upload of chunk %d issued\n", since(), k);
                 { std::lock_guard<std::mutex> g(sh.m); if (sh.abort) return; }
             }
         });
@@ -306,6 +315,7 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
                 }
             }
             hipError_t e = hipStreamSynchronize(pc.down[t]);
+            if (trace) fprintf(stderr, "[mf pipe] %8.2f ms  download thread %d drained\n", since(), t);
             if (e != hipSuccess) sh.fail(e, "hipStreamSynchronize (download stream)");
         });
 
@@ -346,7 +356,9 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
             if (e != hipSuccess) sh.fail(e, "download of the crop values");
         }
     }
+    if (trace) fprintf(stderr, "[mf pipe] %8.2f ms  every chunk's kernels issued\n", since());
     for (auto& w : workers) w.join();
+    if (trace) fprintf(stderr, "[mf pipe] %8.2f ms  done (%d frames of %d x %d, %d chunks)\n", since(), n, W, H, nchunks);
     if (bounds) for (int i = 0; i < 4; ++i) bounds[i] = rect[i];
     if (status != 0) {
         (void)hipDeviceSynchronize();

@@ -1,0 +1,45 @@
+"""The single-phase crop pipeline (mf_warp_crop_u8c3_host_frames) at config 2 under different MF_PIPE_* settings: fresh output array per
+call (as stabilize_clip allocates it), separate input frames.   python tools/time_e2e_crop.py sweep | one"""
+import ctypes, os, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
+    for up, down, chunk in ((4, 4, 16), (4, 4, 8), (4, 4, 12), (4, 4, 24), (3, 3, 16), (6, 6, 16), (6, 6, 8), (4, 6, 16), (6, 4, 16), (8, 8, 8), (2, 2, 16)):
+        env = dict(os.environ, MF_PIPE_UP=str(up), MF_PIPE_DOWN=str(down), MF_PIPE_CHUNK=str(chunk))
+        out = subprocess.run([sys.executable, __file__, 'one'], env=env, capture_output=True, text=True).stdout.strip().splitlines()
+        print(f'up={up} down={down} chunk={chunk}:', ' | '.join(out), flush=True)
+    sys.exit(0)
+
+from meshflow_amd import _lib, synthetic
+F, H, W, R, C = 300, 1080, 1920, 16, 16
+base = synthetic.frames_numpy(4, H, W, seed=0)
+frames = [np.ascontiguousarray(base[i % 4]).copy() for i in range(F)]
+disp, hom = synthetic.motion(F, R, C, seed=0)
+from meshflow_amd.stabilizer import MeshFlowStabilizer
+stab = np.ascontiguousarray(MeshFlowStabilizer(device='cuda:0')._get_stabilized_vertex_displacements(F, frames, 0, disp, hom))      # config 2's own paths
+p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+border = (ctypes.c_uint8 * 3)(0, 0, 255)
+crop = np.zeros((F, 4), np.int32)
+fb = H * W * 3
+pin = (ctypes.c_void_p * F)(*[f.ctypes.data for f in frames])
+bounds = (ctypes.c_int32 * 4)()
+
+
+def call(with_crop):
+    out = np.empty((F, H, W, 3), np.uint8)
+    pout = (ctypes.c_void_p * F)(*[out.ctypes.data + i * fb for i in range(F)])
+    ms = ctypes.c_float(0)
+    if with_crop:
+        _lib.check(_lib.lib.mf_warp_crop_u8c3_host_frames(pin, None, pout, p(disp), p(stab), F, W, H, R, C, border, p(crop), bounds, ctypes.byref(ms)))
+    else:
+        _lib.check(_lib.lib.mf_warp_u8c3_host_frames(pin, pout, p(disp), p(stab), F, W, H, R, C, border, p(crop), ctypes.byref(ms)))
+    return ms.value, out          # (the caller drops `out` OUTSIDE the timed interval: unmapping 1.87 GB costs ~100 ms by itself)
+
+
+for label, wc in (('warp', False), ('warp+crop', True)):
+    t = []
+    for _ in range(7):
+        t0 = time.perf_counter(); kms, keep = call(wc); t.append(time.perf_counter() - t0); del keep
+    t = t[1:]
+    print(f'{label}: mean {np.mean(t) * 1e3:.1f} min {np.min(t) * 1e3:.1f} ms ({F / np.mean(t):.0f} fps; kernels {kms:.2f} ms, rectangle {list(bounds)})', flush=True)
