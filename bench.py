@@ -766,7 +766,9 @@ def main():
                          if traffic else None,
                          'algorithmic_bytes_per_launch': algo_bytes, 'avg_launch_ms': warp_ms,
                          'launches': (1 if serial_mode or stab.resident_chunks <= 0 else min(stab.resident_chunks, hi - lo)),
-                         'launch_note': ('one "launch" = the warp of ALL the step\'s frames: HIP events on the main stream in front of the first and behind the '
+                         'launch_note': ('HIP events on the stream the warp kernel is launched on, directly in front of and behind it (nothing runs beside it in this '
+                                         'arrangement)' if (serial_mode or stab.resident_chunks <= 0) else
+                                         'one "launch" = the warp of ALL the step\'s frames: HIP events on the main stream in front of the first and behind the '
                                          'last of its `launches` warp kernels (frame ranges of the clip), so the figure includes the gaps between them and '
                                          'the prep-stream kernels (next clip\'s sweep, tables, crop scan) sharing the chip; the kernel trace under profiles/ '
                                          'gives the kernels alone'),
