@@ -39,7 +39,18 @@ def _worker(rank, world, port, F, gather, q):
             return torch.tensor([0, 0, W - 1, H - 1], dtype=torch.int32)
         return torch.stack([crop[:, 0].max(), crop[:, 1].max(), crop[:, 2].min(), crop[:, 3].min()]).to(torch.int32)
 
-    out, bounds, stab_all, (lo, hi) = mfdist.stabilize_sharded(F, jacobi_fn, warp_fn, crop_reduce_fn, gather=gather)
+    entered = []
+
+    class _Ctx:                 # stands in for the HIP pipeline's prep-stream context (the crop all-reduce is issued under it)
+        def __enter__(self):
+            entered.append(1)
+
+        def __exit__(self, *exc):
+            return False
+
+    out, bounds, stab_all, (lo, hi) = mfdist.stabilize_sharded(F, jacobi_fn, warp_fn, crop_reduce_fn, gather=gather,
+                                                             exchange_ctx=_Ctx if F % 2 else None)
+    assert len(entered) == (1 if F % 2 else 0)
     assert (lo, hi) == host.shard_range(F, world, rank)
     res = {'rank': rank, 'bounds': bounds.tolist(), 'lo': lo, 'hi': hi}
     if gather:
