@@ -6,10 +6,11 @@
 //
 // cv2.findHomography with 4 points is the normalised DLT (OpenCV calib3d/fundam.cpp runKernel): inputs
 // rounded to float32, zero-centroid / unit-mean-absolute-deviation normalisation, 8 equations in 9
-// unknowns, de-normalisation invHnorm * H0 * Hnorm2 and scaling by 1/H[2][2].  The null vector is taken
-// here by Gaussian elimination with partial pivoting on the 8x8 system with h8 = 1, in a fixed operation
-// order shared with the CPU oracle, float64, no FMA contraction (the file is compiled with
-// -ffp-contract=off) so the table is bit-identical to the oracle's.
+// unknowns, de-normalisation invHnorm * H0 * Hnorm2 and scaling by 1/H[2][2].  With exactly four points the 8 equations have one
+// solution; it is taken here in closed form -- square -> quad of the normalised destination points times the adjugate of square ->
+// quad of the normalised source points (Heckbert) -- in a fixed operation order shared with the CPU oracle, float64, no FMA
+// contraction (the file is compiled with -ffp-contract=off), so the table is bit-identical to the oracle's.  (Rounds 1-3 solved the
+// 8 x 8 system by Gaussian elimination with predicated row exchanges: ~3,500 dependent instructions per homography against ~500.)
 //
 // The work is tiny (2*R*C 8x8 solves per frame); the kernel exists so that the Jacobi output never leaves
 // the device between the two halves of the path.
@@ -17,51 +18,31 @@
 
 namespace mf {
 
-// Fully unrolled so that every index is a compile-time constant and the 8x9 system lives in registers
-// (a dynamically indexed local array would go to scratch memory); the row exchange of partial pivoting is a
-// predicated swap against each candidate row.  Arithmetic and its order are unchanged.
-__device__ static bool solve8(double A[8][8], double r[8], double h[8])
+// Unit square (0,0), (1,0), (1,1), (0,1) -> p0, p1, p2, p3 (Heckbert 1989: the 8 equations of the 4-point problem solved by hand):
+// row-major {a, b, c, d, e, f, g, h, 1}; false when p1, p2, p3 are collinear.  Operation order = oracle/warp_oracle.c square_to_quad.
+__device__ static bool square_to_quad(const double p0[2], const double p1[2], const double p2[2], const double p3[2], double S[9])
 {
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        int p = k;
-        double best = fabs(A[k][k]);
-#pragma unroll
-        for (int i = k + 1; i < 8; ++i) {
-            const double v = fabs(A[i][k]);
-            if (v > best) { best = v; p = i; }
-        }
-        ok = ok && best != 0.0;
-#pragma unroll
-        for (int i = k + 1; i < 8; ++i) {
-            const bool sw = p == i;
-#pragma unroll
-            for (int j = k; j < 8; ++j) {                // columns < k are already zero in both rows
-                const double a = A[k][j], b = A[i][j];
-                A[k][j] = sw ? b : a;
-                A[i][j] = sw ? a : b;
-            }
-            const double a = r[k], b = r[i];
-            r[k] = sw ? b : a;
-            r[i] = sw ? a : b;
-        }
-#pragma unroll
-        for (int i = k + 1; i < 8; ++i) {
-            const double f = A[i][k] / A[k][k];
-#pragma unroll
-            for (int j = k + 1; j < 8; ++j) A[i][j] = A[i][j] - f * A[k][j];
-            r[i] = r[i] - f * r[k];
-        }
-    }
-#pragma unroll
-    for (int i = 7; i >= 0; --i) {
-        double s = r[i];
-#pragma unroll
-        for (int j = i + 1; j < 8; ++j) s = s - A[i][j] * h[j];
-        h[i] = s / A[i][i];
-    }
+    const double sx = ((p0[0] - p1[0]) + p2[0]) - p3[0];
+    const double sy = ((p0[1] - p1[1]) + p2[1]) - p3[1];
+    const double dx1 = p1[0] - p2[0], dx2 = p3[0] - p2[0];
+    const double dy1 = p1[1] - p2[1], dy2 = p3[1] - p2[1];
+    const double den = dx1 * dy2 - dx2 * dy1;
+    const bool ok = den != 0.0;
+    const double g = (sx * dy2 - dx2 * sy) / den;
+    const double h = (dx1 * sy - sx * dy1) / den;
+    S[0] = (p1[0] - p0[0]) + g * p1[0]; S[1] = (p3[0] - p0[0]) + h * p3[0]; S[2] = p0[0];
+    S[3] = (p1[1] - p0[1]) + g * p1[1]; S[4] = (p3[1] - p0[1]) + h * p3[1]; S[5] = p0[1];
+    S[6] = g; S[7] = h; S[8] = 1.0;
     return ok;
+}
+
+// adjugate of a row-major 3 x 3 whose last entry is 1
+__device__ static void adjugate3(const double S[9], double A[9])
+{
+    const double a = S[0], b = S[1], c = S[2], d = S[3], e = S[4], f = S[5], g = S[6], h = S[7];
+    A[0] = e - f * h; A[1] = c * h - b; A[2] = b * f - c * e;
+    A[3] = f * g - d; A[4] = a - c * g; A[5] = c * d - a * f;
+    A[6] = d * h - e * g; A[7] = b * g - a * h; A[8] = a * e - b * d;
 }
 
 __device__ static void matmul3(const double a[9], const double b[9], double c[9])
@@ -91,20 +72,22 @@ __device__ static bool homography4(const double src[8], const double dst[8], dou
     smx = 4 / smx; smy = 4 / smy; sMx = 4 / sMx; sMy = 4 / sMy;
     const double invHnorm[9] = { 1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1 };
     const double Hnorm2[9] = { sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1 };
-    double A[8][8], r[8], h[8];
+    // the 4-point problem in normalised coordinates, in closed form: corners arrive as TL, TR, BL, BR; the unit square's cyclic order is
+    // points 0, 1, 3, 2
+    double nm[4][2], nM[4][2];
     for (int i = 0; i < 4; ++i) {
-        const double x = (dst[2 * i] - cmx) * smx, y = (dst[2 * i + 1] - cmy) * smy;
-        const double X = (src[2 * i] - cMx) * sMx, Y = (src[2 * i + 1] - cMy) * sMy;
-        const double Lx[9] = { X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x };
-        const double Ly[9] = { 0, 0, 0, X, Y, 1, -y * X, -y * Y, -y };
-        for (int j = 0; j < 8; ++j) { A[2 * i][j] = Lx[j]; A[2 * i + 1][j] = Ly[j]; }
-        r[2 * i] = -Lx[8]; r[2 * i + 1] = -Ly[8];
+        nm[i][0] = (dst[2 * i] - cmx) * smx; nm[i][1] = (dst[2 * i + 1] - cmy) * smy;
+        nM[i][0] = (src[2 * i] - cMx) * sMx; nM[i][1] = (src[2 * i + 1] - cMy) * sMy;
     }
-    if (!solve8(A, r, h)) return false;
-    const double H0[9] = { h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], 1.0 };
+    double Sd[9], Ss[9], As[9], H0[9];
+    const bool okd = square_to_quad(nm[0], nm[1], nm[3], nm[2], Sd), oks = square_to_quad(nM[0], nM[1], nM[3], nM[2], Ss);
+    if (!okd || !oks) return false;
+    adjugate3(Ss, As);
+    matmul3(Sd, As, H0);
     double Ht[9], Hd[9];
     matmul3(invHnorm, H0, Ht);
     matmul3(Ht, Hnorm2, Hd);
+    if (Hd[8] == 0.0) return false;
     const double sc = 1.0 / Hd[8];
     for (int i = 0; i < 9; ++i) H[i] = Hd[i] * sc;
     return true;

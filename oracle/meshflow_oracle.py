@@ -226,7 +226,34 @@ def solve8_partial_pivot(A, rhs):
     return h
 
 
-def find_homography_4pt(src_pts, dst_pts, solver='gauss'):
+def _square_to_quad(p0, p1, p2, p3):
+    """The homography that maps the unit square's corners (0,0), (1,0), (1,1), (0,1) onto p0, p1, p2, p3 (Heckbert, "Fundamentals of
+    texture mapping and image warping", 1989, section 2.2.3: the 8 equations of the 4-point problem solved by hand), as the row-major
+    [a, b, c, d, e, f, g, h, 1]; None when p1, p2, p3 are collinear.  Fixed operation order, shared with oracle/warp_oracle.c and the
+    HIP cell-table kernel (no FMA contraction anywhere): all three agree bit for bit."""
+    sx = ((p0[0] - p1[0]) + p2[0]) - p3[0]
+    sy = ((p0[1] - p1[1]) + p2[1]) - p3[1]
+    dx1 = p1[0] - p2[0]; dx2 = p3[0] - p2[0]
+    dy1 = p1[1] - p2[1]; dy2 = p3[1] - p2[1]
+    den = dx1 * dy2 - dx2 * dy1
+    if den == 0.0:
+        return None
+    g = (sx * dy2 - dx2 * sy) / den
+    h = (dx1 * sy - sx * dy1) / den
+    return [(p1[0] - p0[0]) + g * p1[0], (p3[0] - p0[0]) + h * p3[0], p0[0],
+            (p1[1] - p0[1]) + g * p1[1], (p3[1] - p0[1]) + h * p3[1], p0[1],
+            g, h, 1.0]
+
+
+def _adjugate3(S):
+    """Adjugate of a row-major 3x3 whose last entry is 1 (S times its adjugate = det(S) * identity)."""
+    a, b, c, d, e, f, g, h, _ = S
+    return [[e - f * h, c * h - b, b * f - c * e],
+            [f * g - d, a - c * g, c * d - a * f],
+            [d * h - e * g, b * g - a * h, a * e - b * d]]
+
+
+def find_homography_4pt(src_pts, dst_pts, solver='closed'):
     """cv2.findHomography(src, dst) for exactly 4 points, method 0 (mfs.py:1041-1042).
 
     Restates OpenCV's HomographyEstimatorCallback::runKernel (calib3d/fundam.cpp): both point sets
@@ -236,11 +263,13 @@ def find_homography_4pt(src_pts, dst_pts, solver='gauss'):
     refinement.
 
     OpenCV extracts the null vector as the eigenvector of the smallest eigenvalue of L^T L
-    (Jacobi eigen-solver).  `solver='gauss'` instead solves the same 8 equations with h8 = 1 by
-    Gaussian elimination (mathematically the same null vector; differs from the eigen route by
-    ~1e-12 relative, and OpenCV's own iteration is not reproducible bit-for-bit across builds).
-    `solver='eigh'` follows the L^T L route with numpy's symmetric eigen-solver and exists to
-    cross-check the substitution in tests.
+    (Jacobi eigen-solver); its iteration is not reproducible bit-for-bit across builds, and with exactly 4 points the 8 equations
+    have ONE solution, so any exact solver restates it to rounding.  `solver='closed'` (what the C oracle and the HIP kernel compute,
+    since round 4) takes that solution in closed form -- square -> quad of the normalised destination points times the adjugate of
+    square -> quad of the normalised source points (Heckbert): ~1,000 instructions per cell and direction on the GPU instead of ~3,500
+    for an 8 x 8 elimination with predicated row exchanges; `solver='gauss'` (rounds 1-3) solves the 8 equations with h8 = 1 by Gaussian
+    elimination with partial pivoting; `solver='eigh'` follows the L^T L route with numpy's symmetric eigen-solver.  The three agree to
+    ~1e-12 relative (tests/test_oracle_warp_kat.py); the last two exist to cross-check the first.
     """
     M = np.asarray(src_pts, dtype=np.float64).reshape(4, 2).astype(np.float32).astype(np.float64)
     m = np.asarray(dst_pts, dtype=np.float64).reshape(4, 2).astype(np.float32).astype(np.float64)
@@ -270,7 +299,17 @@ def find_homography_4pt(src_pts, dst_pts, solver='gauss'):
         X = (M[i][0] - cM[0]) * sM[0]; Y = (M[i][1] - cM[1]) * sM[1]
         L[2 * i] = [X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x]
         L[2 * i + 1] = [0, 0, 0, X, Y, 1, -y * X, -y * Y, -y]
-    if solver == 'gauss':
+    if solver == 'closed':
+        # corner order: the reference hands the corners over as TL, TR, BL, BR (mfs.py:1039-1040); the unit square's cyclic order is
+        # (0,0), (1,0), (1,1), (0,1) = points 0, 1, 3, 2 -- any labelling works as long as both sets use the same one
+        nm = [((m[i][0] - cm[0]) * sm[0], (m[i][1] - cm[1]) * sm[1]) for i in range(count)]
+        nM = [((M[i][0] - cM[0]) * sM[0], (M[i][1] - cM[1]) * sM[1]) for i in range(count)]
+        s_dst = _square_to_quad(nm[0], nm[1], nm[3], nm[2])
+        s_src = _square_to_quad(nM[0], nM[1], nM[3], nM[2])
+        if s_dst is None or s_src is None:
+            return None
+        H0 = np.array(_matmul3([s_dst[0:3], s_dst[3:6], s_dst[6:9]], _adjugate3(s_src)))
+    elif solver == 'gauss':
         h = solve8_partial_pivot(L[:, :8], -L[:, 8])
         if h is None:
             return None
@@ -282,6 +321,8 @@ def find_homography_4pt(src_pts, dst_pts, solver='gauss'):
         raise ValueError(solver)
     Htemp = _matmul3(inv_h_norm, H0)
     H = _matmul3(Htemp, h_norm2)
+    if H[2][2] == 0.0:
+        return None
     return H * (1.0 / H[2][2])
 
 

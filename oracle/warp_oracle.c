@@ -78,30 +78,31 @@ void mfo_jacobi_banded(const double* b, double* x_out, const double* taps, const
 /* cv2.findHomography for 4 points (method 0): normalised DLT, see find_homography_4pt in           */
 /* meshflow_oracle.py for the derivation.  Points are first rounded to float32.                     */
 /* ---------------------------------------------------------------------------------------------- */
-static int solve8(double A[8][8], double r[8], double h[8])
+/* Unit square (0,0), (1,0), (1,1), (0,1) -> p0, p1, p2, p3 (Heckbert 1989): row-major {a, b, c, d, e, f, g, h, 1}; 0 when p1, p2, p3
+ * are collinear.  The operation order of _square_to_quad in meshflow_oracle.py. */
+static int square_to_quad(const double p0[2], const double p1[2], const double p2[2], const double p3[2], double S[9])
 {
-    for (int k = 0; k < 8; ++k) {
-        int p = k;
-        double best = fabs(A[k][k]);
-        for (int i = k + 1; i < 8; ++i)
-            if (fabs(A[i][k]) > best) { best = fabs(A[i][k]); p = i; }
-        if (best == 0.0) return 0;
-        if (p != k) {
-            for (int j = 0; j < 8; ++j) { double t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
-            double t = r[k]; r[k] = r[p]; r[p] = t;
-        }
-        for (int i = k + 1; i < 8; ++i) {
-            double f = A[i][k] / A[k][k];
-            for (int j = k + 1; j < 8; ++j) A[i][j] = A[i][j] - f * A[k][j];
-            r[i] = r[i] - f * r[k];
-        }
-    }
-    for (int i = 7; i >= 0; --i) {
-        double s = r[i];
-        for (int j = i + 1; j < 8; ++j) s = s - A[i][j] * h[j];
-        h[i] = s / A[i][i];
-    }
+    const double sx = ((p0[0] - p1[0]) + p2[0]) - p3[0];
+    const double sy = ((p0[1] - p1[1]) + p2[1]) - p3[1];
+    const double dx1 = p1[0] - p2[0], dx2 = p3[0] - p2[0];
+    const double dy1 = p1[1] - p2[1], dy2 = p3[1] - p2[1];
+    const double den = dx1 * dy2 - dx2 * dy1;
+    if (den == 0.0) return 0;
+    const double g = (sx * dy2 - dx2 * sy) / den;
+    const double h = (dx1 * sy - sx * dy1) / den;
+    S[0] = (p1[0] - p0[0]) + g * p1[0]; S[1] = (p3[0] - p0[0]) + h * p3[0]; S[2] = p0[0];
+    S[3] = (p1[1] - p0[1]) + g * p1[1]; S[4] = (p3[1] - p0[1]) + h * p3[1]; S[5] = p0[1];
+    S[6] = g; S[7] = h; S[8] = 1.0;
     return 1;
+}
+
+/* adjugate of a row-major 3x3 whose last entry is 1 (_adjugate3) */
+static void adjugate3(const double S[9], double A[9])
+{
+    const double a = S[0], b = S[1], c = S[2], d = S[3], e = S[4], f = S[5], g = S[6], h = S[7];
+    A[0] = e - f * h; A[1] = c * h - b; A[2] = b * f - c * e;
+    A[3] = f * g - d; A[4] = a - c * g; A[5] = c * d - a * f;
+    A[6] = d * h - e * g; A[7] = b * g - a * h; A[8] = a * e - b * d;
 }
 
 static void matmul3(const double a[9], const double b[9], double c[9])
@@ -135,20 +136,21 @@ int mfo_find_homography_4pt(const double src[8], const double dst[8], double H[9
     smx = 4 / smx; smy = 4 / smy; sMx = 4 / sMx; sMy = 4 / sMy;
     double invHnorm[9] = { 1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1 };
     double Hnorm2[9] = { sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1 };
-    double A[8][8], r[8], h[8];
+    /* the 4-point problem in normalised coordinates, in closed form (find_homography_4pt, solver 'closed'): corners arrive as TL, TR,
+     * BL, BR; the unit square's cyclic order is points 0, 1, 3, 2 */
+    double nm[4][2], nM[4][2];
     for (int i = 0; i < 4; ++i) {
-        double x = (mx[i] - cmx) * smx, y = (my[i] - cmy) * smy;
-        double X = (Mx[i] - cMx) * sMx, Y = (My[i] - cMy) * sMy;
-        double Lx[9] = { X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x };
-        double Ly[9] = { 0, 0, 0, X, Y, 1, -y * X, -y * Y, -y };
-        for (int j = 0; j < 8; ++j) { A[2 * i][j] = Lx[j]; A[2 * i + 1][j] = Ly[j]; }
-        r[2 * i] = -Lx[8]; r[2 * i + 1] = -Ly[8];
+        nm[i][0] = (mx[i] - cmx) * smx; nm[i][1] = (my[i] - cmy) * smy;
+        nM[i][0] = (Mx[i] - cMx) * sMx; nM[i][1] = (My[i] - cMy) * sMy;
     }
-    if (!solve8(A, r, h)) return 0;
-    double H0[9] = { h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], 1.0 };
+    double Sd[9], Ss[9], As[9], H0[9];
+    if (!square_to_quad(nm[0], nm[1], nm[3], nm[2], Sd) || !square_to_quad(nM[0], nM[1], nM[3], nM[2], Ss)) return 0;
+    adjugate3(Ss, As);
+    matmul3(Sd, As, H0);
     double Ht[9], Hd[9];
     matmul3(invHnorm, H0, Ht);
     matmul3(Ht, Hnorm2, Hd);
+    if (Hd[8] == 0.0) return 0;
     double sc = 1.0 / Hd[8];
     for (int i = 0; i < 9; ++i) H[i] = Hd[i] * sc;
     return 1;
