@@ -423,29 +423,30 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
     // NOFLAG (for the scan-only pass): every pixel's source coordinates stay between the corner values of the listed cells (below),
     // known to 0.01: with u > 1 + 1/16 - 0.01 and u < W - 2 - 1/16 + 0.01 neither |u| < 1 nor |u - (W-1)| < 1 can hold (same for v;
     // mfs.py:1075-1098); a pixel no cell covers sits at (W+1, H+1) and passes none of the tests either.
-    bool noflag = false;
-    if (sane && cnt > 0 && !overflow && umin > -1e6f && vmin > -1e6f && umax < 1e6f && vmax < 1e6f) {
+    // Taps of a pixel at (u, v): columns ix, ix + 1 with ix = rint(32 u) >> 5 in [floor(u - 1/64), floor(u + 1/64)], same for
+    // rows.  u and v over the footprint stay between their corner values (ratios of affine functions, w > 0), and the corner
+    // values here are float32 evaluations: error below 0.01 at coordinates up to 8192 (a few operations at 2^-24 relative,
+    // the reciprocal to 1 ulp).  So a slack of 1/16 pixel covers both (1/64 + 0.01 < 1/16); a whole pixel on larger frames.
+    const bool ranged = sane && cnt > 0 && !overflow && umin > -1e6f && vmin > -1e6f && umax < 1e6f && vmax < 1e6f;
+    int ix_lo = 0, ix_hi = 0, iy_lo = 0, iy_hi = 0;
+    bool inside = false;                          // every tap inside the frame AND no crop flag possible (see `interior` below)
+    if (ranged) {
         const float slack = (W <= 8192 && H <= 8192) ? 0.0625f : 1.0f;
-        noflag = (int)floorf(umin - slack) >= 1 && (int)floorf(umax + slack) + 1 <= W - 2 &&
-                 (int)floorf(vmin - slack) >= 1 && (int)floorf(vmax + slack) + 1 <= H - 2;
-        if (noflag) region.flags_origin = MF_REGION_NOFLAG;
+        ix_lo = (int)floorf(umin - slack); ix_hi = (int)floorf(umax + slack) + 1;
+        iy_lo = (int)floorf(vmin - slack); iy_hi = (int)floorf(vmax + slack) + 1;
+        inside = ix_lo >= 1 && ix_hi <= W - 2 && iy_lo >= 1 && iy_hi <= H - 2;
     }
-    if (sane && cnt > 0 && !overflow && (W & 3) == 0 && 3 * W >= MF_STAGE_PITCH && H > MF_STAGE_ROWS &&
-        umin > -1e6f && vmin > -1e6f && umax < 1e6f && vmax < 1e6f) {
-        // Taps of a pixel at (u, v): columns ix, ix + 1 with ix = rint(32 u) >> 5 in [floor(u - 1/64), floor(u + 1/64)], same for
-        // rows.  u and v over the footprint stay between their corner values (ratios of affine functions, w > 0), and the corner
-        // values here are float32 evaluations: error below 0.01 at coordinates up to 8192 (a few operations at 2^-24 relative,
-        // the reciprocal to 1 ulp).  So a slack of 1/16 pixel covers both (1/64 + 0.01 < 1/16); a whole pixel on larger frames.
-        const float slack = (W <= 8192 && H <= 8192) ? 0.0625f : 1.0f;
-        const int ix_lo = (int)floorf(umin - slack), ix_hi = (int)floorf(umax + slack) + 1;
-        const int iy_lo = (int)floorf(vmin - slack), iy_hi = (int)floorf(vmax + slack) + 1;
+    const bool noflag = inside;
+    if (noflag) region.flags_origin = MF_REGION_NOFLAG;
+    if (ranged && (W & 3) == 0 && 3 * W >= MF_STAGE_PITCH && H > MF_STAGE_ROWS) {
         const bool whole = xb - xa == MF_FOOT_W - 1 && yb - ya == MF_FOOT_H - 1;
         // ONE listed cell: a pixel it COVERS passes the cell's mask test, i.e. maps (by M = inverse of the forward homography, which
         // agrees with Hi to ~1e-9) more than 1/64 pixel inside the cell's grid rect widened by one pixel -- so its taps lie in columns
         // L-1 .. Rt+1 and rows T-1 .. B+1 whatever the corner values say (the corners of a MIXED cell's footprint may lie far outside
         // what the cell covers).  Pixels the cell does not cover get the border colour and no tap of theirs matters.
+        // (not needed for an IN cell whose corner values already lie inside the frame: the hot footprints)
         int tx_lo = ix_lo, tx_hi = ix_hi, ty_lo = iy_lo, ty_hi = iy_hi;
-        if (cnt == 1) {
+        if (cnt == 1 && !(closed && inside)) {
             int rl, rt, rr, rb;
             rect_of((int)(p.e[0] & 0xFFFu), rl, rt, rr, rb);
             tx_lo = max(tx_lo, rl - 1); tx_hi = min(tx_hi, rr + 1); ty_lo = max(ty_lo, rt - 1); ty_hi = min(ty_hi, rb + 1);
@@ -466,7 +467,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
         // into the window by the kernel, which needs the bytes in front of / behind the window rows to be free.
         const uint32_t code0b = (uint32_t)codes & 0xFFFFu;
         const bool one_coded = cnt == 1 && !overflow && (closed || (code0b & 0x3Fu) != 4u);
-        if (one_coded && unit1 && whole && tx_lo <= tx_hi && ty_lo <= ty_hi && !(covered && ix_lo >= 1 && ix_hi <= W - 2 && iy_lo >= 1 && iy_hi <= H - 2)) {
+        if (one_coded && unit1 && whole && tx_lo <= tx_hi && ty_lo <= ty_hi && !(covered && inside)) {
             const bool pl = tx_lo < 0, pr = tx_hi > W - 1, pt = ty_lo < 0, pb = ty_hi > H - 1;
             const int sy0b = pb ? H - MF_STAGE_ROWS : min(cy_lo, H - MF_STAGE_ROWS);
             const bool fit = cx_hi <= last_col && cy_lo >= sy0b && cy_hi <= sy0b + MF_STAGE_ROWS - 1 &&
@@ -488,7 +489,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             // DEEP also asks for a whole footprint (all 256 pixels inside the frame): its lanes are then all active.
             // Interior: every tap inside the frame (ix_lo >= 0, ix_hi <= W - 1) and no crop flag possible -- |u| < 1 needs
             // u < 1 but u >= ix_lo + 1/16 - 1/100; |u - (W-1)| < 1 needs u > W - 2 but u < ix_hi - 1/16 + 1/100 (mfs.py:1075-1098).
-            const bool interior = whole && ix_lo >= 1 && ix_hi <= W - 2 && iy_lo >= 1 && iy_hi <= H - 2;
+            const bool interior = whole && inside;
             const bool deep = covered && interior;
             region.flags_origin = MF_REGION_STAGED | (deep ? MF_REGION_DEEP : 0u) | (noflag ? MF_REGION_NOFLAG : 0u) | ((uint32_t)sy0 * MF_STAGE_PITCH + bs);
             region.src_dwords = ((uint32_t)sy0 * (3u * (uint32_t)W) + bs) >> 2;
