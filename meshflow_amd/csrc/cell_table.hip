@@ -152,6 +152,10 @@ __device__ static void cell_bbox(const double Hf[9], const double M[9], double L
     bbox[0] = x0; bbox[1] = y0; bbox[2] = x1; bbox[3] = y1;
 }
 
+// (16-byte stores to addresses that are only element-aligned: the edge sets start behind an odd number of 8-byte boxes for odd n R C)
+typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
+
 __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict__ unstab,
                                                         const double* __restrict__ stab, int n, int W, int H, int R,
                                                         int C, double* __restrict__ records,
@@ -191,7 +195,11 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
     }
     double Hf[9], Hi[9];
     const bool ok = homography4(ub, sb, Hf) && homography4(sb, ub, Hi);
-    double* rec = records + (size_t)cid * MF_CELL_DOUBLES;
+    // The wavefront's 64 records (16 KB), then its edge sets (4 KB + 3 KB), are put together in LDS -- one slot per lane, odd strides:
+    // no bank conflicts -- and written out as whole 1 KB runs (a lane storing its own 256-byte record touches 64 different cache lines
+    // per store instruction: the table kernel was bound by exactly that, 105 -> 50 us at config 3).
+    __shared__ double s_rec[64 * (MF_CELL_DOUBLES + 1)];
+    double* rec = &s_rec[threadIdx.x * (MF_CELL_DOUBLES + 1)];
     for (int i = 0; i < MF_CELL_DOUBLES; ++i) rec[i] = 0.0;
     const double L = floor(fmin(fmin(ub[0], ub[2]), fmin(ub[4], ub[6])));
     const double Rt = ceil(fmax(fmax(ub[0], ub[2]), fmax(ub[4], ub[6])));
@@ -202,8 +210,9 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
     CellBox box;
     int rxlo = 0, rylo = 0, rxhi = 0, ryhi = 0;      // how far this cell's box reaches beyond its grid rect
     bool has_reach = false;
-    float* ed = edges + (size_t)cid * MF_EDGE_FLOATS;
-    float* ued = uedges + (size_t)cid * MF_UEDGE_FLOATS;
+    float edv[MF_EDGE_FLOATS], uedv[MF_UEDGE_FLOATS];           // (registers: LDS is busy with the records until they are out)
+    float* const ed = edv;
+    float* const ued = uedv;
     if (!ok) {
         for (int e = 0; e < 4; ++e) {                                     // never a candidate
             ed[3 * e] = ued[3 * e] = 0.0f; ed[3 * e + 1] = ued[3 * e + 1] = 0.0f; ed[3 * e + 2] = ued[3 * e + 2] = -1e30f; ed[12 + e] = 1.0f;
@@ -255,6 +264,40 @@ __global__ __launch_bounds__(64) void cell_table_kernel(const double* __restrict
         has_reach = live && box.x0 <= box.x1;
     }
     boxes[cid] = box;
+    {
+        const int cells = min(64, ncell - part * 64);          // (lanes past the frame's last cell hold copies: not written)
+        const size_t wbase = (size_t)f * ncell + (size_t)part * 64;
+        __syncthreads();
+        double* __restrict__ grec = records + wbase * MF_CELL_DOUBLES;
+#pragma unroll
+        for (int pass = 0; pass < MF_CELL_DOUBLES / 2; ++pass) {
+            const int flat = pass * 128 + 2 * (int)threadIdx.x, cell = flat / MF_CELL_DOUBLES, i = flat % MF_CELL_DOUBLES;
+            if (cell < cells)
+                *reinterpret_cast<double2_u*>(grec + flat) = (double2_u){s_rec[cell * (MF_CELL_DOUBLES + 1) + i], s_rec[cell * (MF_CELL_DOUBLES + 1) + i + 1] };
+        }
+        __syncthreads();
+        float* s_ed = reinterpret_cast<float*>(s_rec);
+        float* s_ued = s_ed + 64 * (MF_EDGE_FLOATS + 1);
+#pragma unroll
+        for (int i = 0; i < MF_EDGE_FLOATS; ++i) s_ed[threadIdx.x * (MF_EDGE_FLOATS + 1) + i] = edv[i];
+#pragma unroll
+        for (int i = 0; i < MF_UEDGE_FLOATS; ++i) s_ued[threadIdx.x * (MF_UEDGE_FLOATS + 1) + i] = uedv[i];
+        __syncthreads();
+        float* __restrict__ ged = edges + wbase * MF_EDGE_FLOATS;
+        float* __restrict__ gued = uedges + wbase * MF_UEDGE_FLOATS;
+#pragma unroll
+        for (int pass = 0; pass < MF_EDGE_FLOATS / 4; ++pass) {
+            const int flat = pass * 256 + 4 * (int)threadIdx.x, cell = flat / MF_EDGE_FLOATS, i = flat % MF_EDGE_FLOATS;
+            const float* q = &s_ed[cell * (MF_EDGE_FLOATS + 1) + i];
+            if (cell < cells) *reinterpret_cast<float4_u*>(ged + flat) = (float4_u){ q[0], q[1], q[2], q[3] };
+        }
+#pragma unroll
+        for (int pass = 0; pass < MF_UEDGE_FLOATS / 4; ++pass) {
+            const int flat = pass * 256 + 4 * (int)threadIdx.x, cell = flat / MF_UEDGE_FLOATS, i = flat % MF_UEDGE_FLOATS;
+            const float* q = &s_ued[cell * (MF_UEDGE_FLOATS + 1) + i];
+            if (cell < cells) *reinterpret_cast<float4_u*>(gued + flat) = (float4_u){ q[0], q[1], q[2], q[3] };
+        }
+    }
     // Per-frame maxima of the reach bound the plan kernel's candidate search: this wavefront's share, reduced over its lanes and
     // written to the frame's slot `part` (the plan kernel takes the maximum over the frame's slots).
     int a = has_reach ? rxlo : 0, b = has_reach ? rylo : 0, c2 = has_reach ? rxhi : 0, d = has_reach ? ryhi : 0;
