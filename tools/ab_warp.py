@@ -97,8 +97,8 @@ def main():
             same = torch.equal(v['out'], ref['out']) and torch.equal(v['crop'], ref['crop'])
             print(f'{wl}: {v["name"]} output identical to {ref["name"]}: {same}' +
                   ('' if same else f'  ({int((v["out"] != ref["out"]).sum())} bytes differ)'), flush=True)
-        for _ in range(args.rounds):
-            for v in state:
+        for rnd in range(args.rounds):
+            for v in (state if rnd % 2 == 0 else state[::-1]):      # (A B ... then ... B A: position in the round must not matter)
                 v['t_tab'].append(timed(run_table, v, max(2, args.launches // 2)))
                 run_table(v)
                 v['t_warp'].append(timed(run_warp, v, args.launches))

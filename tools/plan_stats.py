@@ -56,3 +56,23 @@ print(f'hot with the fast64 certificate {fast64.mean():.4f}')
 pf = (ne == 2) & ((plan[:, 2] & 0x6001) == 0x2001)
 pv_ = (ne == 2) & ((plan[:, 2] & 0x6003) == 0x2003)
 print(f'pair path with the fast certificate {pf.mean():.4f} (of which transposed lanes {pv_.mean():.4f})')
+# the warp kernel's own dispatch (warp.hip footprint_body, in its order)
+k_hot = (plan[:, 1] & 0x2000) != 0
+k_border = ~k_hot & ((regions & 0x08000000) != 0)          # one candidate, several, or none at all (MF_REGION_BORDER)
+k_pair = ~k_hot & ~k_border & ((plan[:, 2] & 0x2000) != 0) & ~overflow
+k_multi = ~k_hot & ~k_border & ~k_pair & ((plan[:, 4] & 0x2000) != 0) & ~overflow
+k_gen = ~(k_hot | k_border | k_pair | k_multi)
+print(f'border shapes: one candidate {(k_border & (ne == 1)).mean():.4f}  several {(k_border & (ne >= 2)).mean():.4f}  empty {(k_border & (ne == 0)).mean():.4f}')
+print(f'kernel paths: hot {k_hot.mean():.4f}  border {k_border.mean():.4f}  pair {k_pair.mean():.4f}  multi {k_multi.mean():.4f}  general {k_gen.mean():.4f}')
+staged = ((regions >> 31) & 1) != 0
+deep = ((regions >> 30) & 1) != 0
+hist = {int(k): round(float((k_gen & (ne == k)).mean()), 4) for k in np.unique(ne[k_gen])}
+print(f'general: by candidates {hist}; staged {(k_gen & staged).mean():.4f}  deep {(k_gen & deep).mean():.4f}  '
+      f'one IN cell {(k_gen & single).mean():.4f}  ragged (frame edge) {(k_gen & ~staged).mean():.4f}')
+fy = (np.arange(npl) % (nfx * nfy)) // nfx
+fxx = np.arange(npl) % nfx
+ring = (fy == 0) | (fy == nfy - 1) | (fxx == 0) | (fxx == nfx - 1)
+print(f'general on the outermost footprint ring {(k_gen & ring).mean():.4f} (ring = {ring.mean():.4f} of all), second ring '
+      f'{(k_gen & ~ring & ((fy == 1) | (fy == nfy - 2) | (fxx == 1) | (fxx == nfx - 2))).mean():.4f}, inside {(k_gen & ~ring & ~((fy == 1) | (fy == nfy - 2) | (fxx == 1) | (fxx == nfx - 2))).mean():.4f}')
+gi = k_gen & ~ring & ~((fy == 1) | (fy == nfy - 2) | (fxx == 1) | (fxx == nfx - 2))
+print('  inside-general by candidates', {int(k): round(float((gi & (ne == k)).mean()), 4) for k in np.unique(ne[gi])} if gi.any() else {})
