@@ -1,6 +1,8 @@
 // The specialised Jacobi kernel (compile-time radius) shared by jacobi.hip and the ahead-of-time instantiation table
 // jacobi_spec.hip.  See jacobi.hip for the mapping.
 #pragma once
+#include <type_traits>
+
 #include "mf_common.h"
 
 namespace mf {
@@ -35,8 +37,81 @@ __device__ __forceinline__ void jacobi_sweeps(double (&xs)[2][64 * WAVES * K + 2
     }
 }
 
+// PIPELINED form of the sweeps (K even): the K + 2 OMEGA window entries come from LDS as 16-byte pairs, a few pairs ahead of the FMAs that
+// consume them, ONE read after every pair's 2 K FMAs -- instead of the whole window, a wait, then all K (2 OMEGA + 1) FMAs: with every
+// wavefront of a CU in the same phase, the LDS pipe (8 wavefronts x 35 KB per sweep at OMEGA = 30) and the vector ALUs took turns.
+// Entry j feeds output k through tap d = j - k, entries in ascending order: per output the taps still come in ascending d -- same bits.
+// The loads are inline asm (the compiler would gather them in front of one wait again); what orders them against the FMAs is data
+// flow: a wait "produces" the pair it makes valid, and a load is tied to an accumulator the FMAs in front of it have just written.
+typedef double jd2_t __attribute__((ext_vector_type(2)));
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void jacobi_static_for(Fn&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        jacobi_static_for<I + 1, N>(f);
+    }
+}
+template <int OFF>
+__device__ __forceinline__ void jacobi_lds_pair(jd2_t& dst, uint32_t addr, double& tie)
+{
+    asm volatile("ds_read_b128 %0, %2 offset:%3" : "=v"(dst), "+v"(tie) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void jacobi_lds_wait(jd2_t& v)
+{
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
+#ifndef MF_JACOBI_AHEAD
+#define MF_JACOBI_AHEAD 4
+#endif
+template <int OMEGA, int K, int WAVES, bool SYM>
+__device__ __forceinline__ void jacobi_sweeps_piped(double (&xs)[2][64 * WAVES * K + 2 * OMEGA], const double (&w)[SYM ? OMEGA + 1 : 2 * OMEGA + 1],
+                                                    const double (&bt)[K], const double (&two_lam)[K], const double (&inv)[K], double (&xn)[K],
+                                                    int lane, int iters)
+{
+    static_assert(K % 2 == 0, "pairs of window entries");
+    constexpr int NT = 2 * OMEGA + 1, NP = (K + 2 * OMEGA) / 2, A = MF_JACOBI_AHEAD < NP ? MF_JACOBI_AHEAD : NP;
+    const uint32_t base[2] = { (uint32_t)(uintptr_t)&xs[0][lane * K], (uint32_t)(uintptr_t)&xs[1][lane * K] };
+    // (the taps are in their scalar registers BEFORE the loop: otherwise the compiler, which cannot see the asm loads, waits for "its"
+    // scalar loads with lgkmcnt(0) inside the loop, behind the first window loads of every sweep)
+#pragma unroll
+    for (int d = 0; d < (SYM ? OMEGA + 1 : 2 * OMEGA + 1); ++d) asm volatile("" :: "s"(w[d]));
+    int cur = 0;
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t addr = base[cur];
+        jd2_t wv[NP];
+        double acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = 0.0;
+        jacobi_static_for<0, A>([&](auto pc) { constexpr int P = decltype(pc)::value; jacobi_lds_pair<16 * P>(wv[P], addr, acc[0]); });
+        jacobi_static_for<0, NP>([&](auto pc) {
+            constexpr int P = decltype(pc)::value;
+            jacobi_lds_wait<(A - 1 < NP - 1 - P ? A - 1 : NP - 1 - P)>(wv[P]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int d = 2 * P + e - k;
+                    if (d >= 0 && d < NT) acc[k] = __builtin_fma(w[SYM ? (d < OMEGA ? OMEGA - d : d - OMEGA) : d], wv[P][e], acc[k]);
+                }
+            if constexpr (P + A < NP) jacobi_lds_pair<16 * (P + A)>(wv[P + A], addr, acc[2 * P + 1 < K - 1 ? 2 * P + 1 : K - 1]);
+        });
+#pragma unroll
+        for (int k = 0; k < K; ++k) xn[k] = inv[k] * __builtin_fma(two_lam[k], acc[k], bt[k]);
+        double* dst = &xs[cur ^ 1][OMEGA + lane * K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) dst[k] = xn[k];
+        cur ^= 1;
+        __syncthreads();
+    }
+}
+
+// (Series spread over several wavefronts at a wide radius keep two wavefronts per SIMD as their register budget -- what they had
+// while the full tap table shared the kernel: scheduled for four, the barrier-coupled wavefronts measured 14 % slower.)
 template <int OMEGA, int K, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* __restrict__ b, double* __restrict__ x_out,
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, (2 * OMEGA + 1 > 45 && WAVES > 1 && K >= 8) ? 2 : 8)))
+void jacobi_wave_kernel(const double* __restrict__ b, double* __restrict__ x_out,
                                                          const double* __restrict__ taps,
                                                          const double* __restrict__ lam,
                                                          const double* __restrict__ inv_on, int F, int S, int iters, int s0)
@@ -83,12 +158,38 @@ __global__ __launch_bounds__(64 * WAVES) void jacobi_wave_kernel(const double* _
         double w[OMEGA + 1];
 #pragma unroll
         for (int d = 0; d <= OMEGA; ++d) w[d] = taps[OMEGA + d];
-        jacobi_sweeps<OMEGA, K, WAVES, true>(xs, w, bt, two_lam, inv, xn, lane, iters);
+        if constexpr (K % 2 == 0 && K >= 8 && WAVES == 1) jacobi_sweeps_piped<OMEGA, K, WAVES, true>(xs, w, bt, two_lam, inv, xn, lane, iters);
+        else jacobi_sweeps<OMEGA, K, WAVES, true>(xs, w, bt, two_lam, inv, xn, lane, iters);
+    } else if (TRY_SYM) {
+        // Asymmetric taps at a wide radius (never from the reference; the C ABI accepts any): the full table does not fit the scalar
+        // registers, and carrying it would cost the symmetric path its occupancy -- so a compact loop with the taps in LDS (wave-uniform
+        // reads), same order of operations, a few times slower.
+        __shared__ double s_taps[NT];
+        for (int d = lane; d < NT; d += NTHR) s_taps[d] = taps[d];
+        __syncthreads();
+        int cur = 0;
+#pragma unroll 1
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+                const double* src = &xs[cur][lane * K + k];
+                double acc = 0.0;
+#pragma unroll 1
+                for (int d = 0; d < NT; ++d) acc = __builtin_fma(s_taps[d], src[d], acc);
+                xn[k] = inv[k] * __builtin_fma(two_lam[k], acc, bt[k]);
+            }
+            double* dst = &xs[cur ^ 1][OMEGA + lane * K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) dst[k] = xn[k];
+            cur ^= 1;
+            __syncthreads();
+        }
     } else {
         double w[NT];
 #pragma unroll
         for (int d = 0; d < NT; ++d) w[d] = taps[d];
-        jacobi_sweeps<OMEGA, K, WAVES, false>(xs, w, bt, two_lam, inv, xn, lane, iters);
+        if constexpr (K % 2 == 0 && K >= 8 && WAVES == 1) jacobi_sweeps_piped<OMEGA, K, WAVES, false>(xs, w, bt, two_lam, inv, xn, lane, iters);
+        else jacobi_sweeps<OMEGA, K, WAVES, false>(xs, w, bt, two_lam, inv, xn, lane, iters);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from meshflow_amd import synthetic, host
 wl = sys.argv[1]
-F, R, C, om, it = {'cfg2': (300, 16, 16, 10, 100), 'cfg3': (600, 32, 32, 30, 200)}[wl]
+F, R, C, om, it = {'cfg2': (300, 16, 16, 10, 100), 'cfg3': (600, 32, 32, 30, 200)}[wl] if wl in ('cfg2', 'cfg3') else tuple(int(v) for v in wl.split(','))   # or F,R,C,omega,iters
 dev = torch.device('cuda:0')
 disp, hom = synthetic.motion(F, R, C, seed=0)
 taps, lam, inv_on = host.jacobi_band_coefficients(F, 1920, 1080, 0, hom, om)
