@@ -11,6 +11,8 @@
 // back; one barrier per sweep.  Everything stays on chip for all sweeps: HBM traffic is one read of b and
 // one write of x.  This kernel is FP64-VALU / LDS bound, not HBM bound.  K is kept minimal (5 frames per thread at
 // OMEGA = 10, 10 at OMEGA = 30); clips longer than 64 K frames spread each series over 2-8 wavefronts.
+// One wavefront per series with K >= 8 (radii 13..32) does not hold the whole window: its entries arrive as 16-byte pairs a few pairs
+// ahead of the FMAs that consume them (jacobi_kernels.h, jacobi_sweeps_piped), so the LDS pipe and the vector ALUs work side by side.
 #include <stdlib.h>
 
 #include <mutex>
