@@ -123,7 +123,7 @@ void jacobi_wave_kernel(const double* __restrict__ b, double* __restrict__ x_out
     // 110 spilled to vector-register lanes and restored every sweep); symmetric taps -- what the reference always has -- need
     // OMEGA + 1 values.  Decided per launch by a wave-uniform bit comparison; anything else takes the full table.
     constexpr bool TRY_SYM = NT > 45;
-    __shared__ double xs[2][LEN];
+    __shared__ __attribute__((aligned(16))) double xs[2][LEN];      // (16 bytes: the pipelined sweeps read it in ds_read_b128 pairs)
     const int s = s0 + (int)blockIdx.x;          // (series s0 .. s0 + gridDim.x - 1 of the S: a launch may cover a slice)
     const int lane = threadIdx.x;
 
