@@ -1,6 +1,6 @@
 // Ahead-of-time table of the specialised Jacobi kernels (jacobi_kernels.h): compiled once per group of eight radii
 // (-DMF_JACOBI_GROUP=g: radii 8 g + 1 .. 8 g + 8), so that the groups build in parallel.  Per radius: the fewest frames per thread K
-// that keeps the window in registers (5 up to omega = 12, 8 up to 20, 10 beyond) x 1 / 2 / 4 / 8 wavefronts per series, i.e. clips of up
+// (5 up to omega = 12, 8 up to 20, 10 beyond) x 1 / 2 / 4 / 8 wavefronts per series, i.e. clips of up
 // to 512 K frames; omega = 10 and 30 (BASELINE configs 2-4) also have the long-clip variants (K = 10, 19).  Longer clips and larger
 // radii take jacobi.hip's run-time-radius kernel.
 #include <stdlib.h>
@@ -30,12 +30,13 @@ int launch_radius(const double* b, double* x, const double* taps, const double* 
         if (F <= 256 * 2 && want >= 4) MF_JACOBI(10, 2, 4);
         if (F <= 128 * 3) MF_JACOBI(10, 3, 2);
     }
-    // One wavefront per series, two resident per SIMD (the K = 10 kernels need ~236 vector registers), and one wavefront alone already
-    // fills a SIMD's float64 pipe: the sweep takes (series on the busiest SIMD) x (time of one series).  With S = q SIMDs + r series the
-    // last r run as a round of their own on r SIMDs while the others idle (config 3: 2178 series on 1024 SIMDs: 2048 take 652 us, the
-    // other 130 another 181 us).  A small remainder is therefore cut into four wavefronts per series (3 frames per lane, a workgroup
-    // barrier per sweep) and launched BESIDE the main launch on a second stream: 4 r short pieces spread over 4 r SIMDs instead of r
-    // long ones.  Same arithmetic per frame in the same order: same bits.
+    // One wavefront per series; a SIMD sustains one float64 FMA per ~5 cycles however many wavefronts share it (F = 600, omega = 30: 1024
+    // series 320 us, 2048 543, 3072 789), so the sweep takes (series on the busiest SIMD) x (time of one series).  With S = q SIMDs + r
+    // series, r SIMDs would carry one series more than the others (config 3: 2178 series on 1024 SIMDs).  A small remainder is therefore
+    // cut into four wavefronts per series (3 frames per lane, a workgroup barrier per sweep) and launched BESIDE the main launch on a
+    // second stream: 4 r short pieces spread over 4 r SIMDs instead of r long ones (the pipelined K = 10 kernel's 125 registers leave them
+    // room beside two main wavefronts; at the 236 of the first version they had to wait for main wavefronts to retire).  Same arithmetic
+    // per frame in the same order: same bits.
     if (OMEGA > 20 && want == 1 && F <= 64 * K && F <= 256 * 3) {
         static const bool no_tail = [] { const char* v = getenv("MF_JACOBI_NO_TAIL"); return v && *v == '1'; }();       // tuning aid
         const int simds = jacobi_simd_count(), r = simds > 0 ? S % simds : 0;
