@@ -30,8 +30,8 @@ int launch_radius(const double* b, double* x, const double* taps, const double* 
         if (F <= 256 * 2 && want >= 4) MF_JACOBI(10, 2, 4);
         if (F <= 128 * 3) MF_JACOBI(10, 3, 2);
     }
-    // One wavefront per series; a SIMD sustains one float64 FMA per ~5 cycles however many wavefronts share it (F = 600, omega = 30: 1024
-    // series 320 us, 2048 543, 3072 789), so the sweep takes (series on the busiest SIMD) x (time of one series).  With S = q SIMDs + r
+    // One wavefront per series; a SIMD's float64 pipe is full from two wavefronts on (F = 600, omega = 30: 1024 series 320 us, 2048 543,
+    // 3072 789), so the sweep takes (series on the busiest SIMD) x (time of one series).  With S = q SIMDs + r
     // series, r SIMDs would carry one series more than the others (config 3: 2178 series on 1024 SIMDs).  A small remainder is therefore
     // cut into four wavefronts per series (3 frames per lane, a workgroup barrier per sweep) and launched BESIDE the main launch on a
     // second stream: 4 r short pieces spread over 4 r SIMDs instead of r long ones (the pipelined K = 10 kernel's 125 registers leave them
