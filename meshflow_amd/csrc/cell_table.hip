@@ -589,11 +589,21 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
     }
 }
 
-constexpr int kPlanStageCells = 256;          // cells (whole mesh rows) a workgroup keeps in LDS: 21 KB
+#ifndef MF_PLAN_PER_THREAD
+#define MF_PLAN_PER_THREAD 4
+#endif
+constexpr int kPlanTile = 256 * MF_PLAN_PER_THREAD;      // footprints per workgroup: each thread plans MF_PLAN_PER_THREAD of them, one staging for all
+#ifndef MF_PLAN_STAGE_CELLS
+#define MF_PLAN_STAGE_CELLS 256
+#endif
+constexpr int kPlanStageCells = MF_PLAN_STAGE_CELLS;          // cells (whole mesh rows) a workgroup keeps in LDS: 21 KB
 
-// grid = n * ceil(footprints per frame / 256): a workgroup handles 256 consecutive footprints of ONE frame -- a few rows of
-// footprints, which only meet a few mesh rows.  Those rows' edge functions and inverse homographies are staged in LDS once
-// (the per-footprint loops then run on LDS latency instead of dependent L2 round trips); when they do not fit, from global.
+// grid = n * ceil(footprints per frame / kPlanTile): a workgroup of 256 threads handles kPlanTile = 1024 consecutive footprints of ONE
+// frame, four per thread one after the other -- a dozen rows of footprints, which only meet a few mesh rows.  Those rows' edge functions
+// and inverse homographies are staged in LDS once (the per-footprint loops then run on LDS latency instead of dependent L2 round trips);
+// when they do not fit, from global.  (The staging -- three dependent global round trips and three barriers per workgroup -- was a
+// quarter of a workgroup's life at one footprint per thread: 1 / 2 / 4 / 6 / 8 per thread: cell table + plan 104.8 / 94.5 / 91.3 / 103 /
+// 104 us at config 2, 266 / 248 / 231 / 250 / 397 at config 3; twice the staged cells: slower, 115 / 296.)
 __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __restrict__ uedges, const float* __restrict__ edges,
                                                              const double* __restrict__ records, const CellBox* __restrict__ boxes,
                                                              const int32_t* __restrict__ reach,
@@ -608,10 +618,10 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     if ((int)threadIdx.x <= R) s_gy[threadIdx.x] = grid[C + 1 + threadIdx.x];
     __syncthreads();
     const int nfx = (W + MF_FOOT_W - 1) / MF_FOOT_W, nfy = (H + MF_FOOT_H - 1) / MF_FOOT_H, per_frame = nfx * nfy;
-    const int blocks_per_frame = (per_frame + 255) / 256;
+    const int blocks_per_frame = (per_frame + kPlanTile - 1) / kPlanTile;
     const int f = (int)(blockIdx.x / (unsigned)blocks_per_frame);
     if (f >= n) return;
-    const int rem0 = ((int)blockIdx.x - f * blocks_per_frame) * 256, rem = rem0 + (int)threadIdx.x;
+    const int rem0 = ((int)blockIdx.x - f * blocks_per_frame) * kPlanTile;
     // the frame's reach = maximum over the slots its cell-table wavefronts wrote (at most 64 of them)
     __shared__ int s_reach[4];
     {
@@ -632,7 +642,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     const CellBox* __restrict__ fbox = boxes + (size_t)f * R * C;
 
     // mesh rows the workgroup's footprints can meet (same widening by the frame's reach as per footprint)
-    const int ya0 = (rem0 / nfx) * MF_FOOT_H, yb1 = min((min(rem0 + 255, per_frame - 1) / nfx) * MF_FOOT_H + MF_FOOT_H - 1, H - 1);
+    const int ya0 = (rem0 / nfx) * MF_FOOT_H, yb1 = min((min(rem0 + kPlanTile - 1, per_frame - 1) / nfx) * MF_FOOT_H + MF_FOOT_H - 1, H - 1);
     int rb_lo = 0, rb_hi = R - 1;
     while (rb_lo < R - 1 && s_gy[rb_lo + 1] < ya0 - ryhi) ++rb_lo;
     while (rb_hi > 0 && s_gy[rb_hi] > yb1 + rylo) --rb_hi;
@@ -651,7 +661,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     // depend only on its column and on its row) instead of eight data-dependent loops per thread: table + plan -4 % at cfg2
     __shared__ uint32_t s_crange[256], s_rrange[258];
     const int fy_first = rem0 / nfx;
-    const int rows_here = min(rem0 + 255, per_frame - 1) / nfx - fy_first + 1;
+    const int rows_here = min(rem0 + kPlanTile - 1, per_frame - 1) / nfx - fy_first + 1;
     const bool col_table = nfx <= 256;
     if (col_table)
         for (int i = threadIdx.x; i < nfx; i += 256) {
@@ -659,6 +669,8 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
             cell_range_1d(s_gx, C, W, i * MF_FOOT_W, min(i * MF_FOOT_W + MF_FOOT_W - 1, W - 1), rxlo, rxhi, lo, hi);
             s_crange[i] = (uint32_t)lo | (uint32_t)hi << 16;
         }
+    const bool row_table = rows_here <= 258;                   // (a tile of a very narrow frame has more rows: ranges per thread then)
+    if (row_table)
     for (int i = threadIdx.x; i < rows_here; i += 256) {
         int lo, hi;
         const int yy0 = (fy_first + i) * MF_FOOT_H;
@@ -666,6 +678,9 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
         s_rrange[i] = (uint32_t)lo | (uint32_t)hi << 16;
     }
     __syncthreads();
+#pragma unroll 1
+    for (int part = 0; part < MF_PLAN_PER_THREAD; ++part) {
+    const int rem = rem0 + part * 256 + (int)threadIdx.x;
     if (rem >= per_frame) return;
     const int fy = rem / nfx, fx = rem - fy * nfx;
     const int xa = fx * MF_FOOT_W, xb = min(xa + MF_FOOT_W - 1, W - 1);
@@ -673,7 +688,9 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     int c_lo, c_hi;
     if (col_table) { c_lo = (int)(s_crange[fx] & 0xFFFFu); c_hi = (int)(s_crange[fx] >> 16); }
     else cell_range_1d(s_gx, C, W, xa, xb, rxlo, rxhi, c_lo, c_hi);
-    const int r_lo = (int)(s_rrange[fy - fy_first] & 0xFFFFu), r_hi = (int)(s_rrange[fy - fy_first] >> 16);
+    int r_lo, r_hi;
+    if (row_table) { r_lo = (int)(s_rrange[fy - fy_first] & 0xFFFFu); r_hi = (int)(s_rrange[fy - fy_first] >> 16); }
+    else cell_range_1d(s_gy, R, H, ya, yb, rylo, ryhi, r_lo, r_hi);
     FootPlan p;
     FootRegion region;
     if (staged) {
@@ -698,6 +715,7 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
     const size_t gid = (size_t)f * per_frame + rem;
     plan[gid] = p;
     regions[gid] = region;
+    }
 }
 
 int launch_cell_table(const double* unstab, const double* stab, int n, int W, int H, int R, int C,
@@ -717,7 +735,7 @@ int launch_cell_table(const double* unstab, const double* stab, int n, int W, in
     int rc = hip_fail(hipGetLastError(), "cell_table_kernel launch");
     if (rc != MF_OK) return rc;
     const size_t per_frame = plan_count(1, W, H);
-    hipLaunchKernelGGL(footprint_plan_kernel, dim3((unsigned)(((per_frame + 255) / 256) * (size_t)n)), dim3(256), 0, st, tv.uedges, tv.edges, tv.records, tv.boxes,
+    hipLaunchKernelGGL(footprint_plan_kernel, dim3((unsigned)(((per_frame + kPlanTile - 1) / kPlanTile) * (size_t)n)), dim3(256), 0, st, tv.uedges, tv.edges, tv.records, tv.boxes,
                        tv.reach, tv.grid, n, W, H, R, C, tv.plan, tv.regions);
     return hip_fail(hipGetLastError(), "footprint_plan_kernel launch");
 }
