@@ -63,6 +63,8 @@ def _clip(F, H, W, R, C, seed, kind='noise', omega=3, iters=10, **kw):
     (272, 480, 3, 4, dict(jitter_sigma=0.5)),
     (272, 480, 2, 2, dict(translation_sigma=3.0, jitter_sigma=1.5)),
     (17, 23, 2, 3, dict(jitter_sigma=0.5)),                         # frame smaller than a footprint
+    (2400, 64, 12, 2, dict(jitter_sigma=0.5)),                      # two footprints per row, 300 rows: more footprint rows in a plan tile than its row table holds
+    (1200, 128, 6, 3, dict(translation_sigma=2.0, jitter_sigma=0.8)),   # 150 rows of four: a plan tile (1024 footprints) ends in the middle of the frame
 ])
 def test_scan_equals_fused_scan_and_oracle(dev, H, W, R, C, kw):
     from oracle import clib
