@@ -83,10 +83,11 @@ int jacobi_side_join(hipStream_t st)
 // free of bank conflicts.  ~40 VGPRs whatever the radius.
 typedef const __attribute__((address_space(4))) double* ctap_t;
 
-template <int K, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void jacobi_runtime_kernel(const double* __restrict__ b, double* __restrict__ x_out,
-                                                                    const double* __restrict__ taps_g, const double* __restrict__ lam,
-                                                                    const double* __restrict__ inv_on, int F, int S, int omega, int iters)
+// TILED (clips beyond 64 WAVES K frames): blockIdx.y = time tile, `iters` sweeps from tile.x_in -- jacobi_kernels.h, JacobiTile.
+template <int K, int WAVES, bool TILED>
+__device__ __forceinline__ void jacobi_runtime_body(const double* __restrict__ b, double* __restrict__ x_out,
+                                                    const double* __restrict__ taps_g, const double* __restrict__ lam,
+                                                    const double* __restrict__ inv_on, int F, int S, int omega, int iters, const JacobiTile& tile)
 {
     extern __shared__ double dyn[];
     constexpr int NTHR = 64 * WAVES;
@@ -98,26 +99,34 @@ __global__ __launch_bounds__(64 * WAVES) void jacobi_runtime_kernel(const double
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
 
-    double bt[K], two_lam[K], inv[K];
+    // frames this thread owns: t0 .. t0 + K - 1; frames [w_lo, w_hi) are written
+    int t0 = lane * K, w_lo = 0, w_hi = F, r_hi = F;
+    if constexpr (TILED) {
+        w_lo = (int)blockIdx.y * tile.T;
+        w_hi = w_lo + tile.T < F ? w_lo + tile.T : F;
+        r_hi = w_hi + tile.halo < F ? w_hi + tile.halo : F;          // (rows beyond the halo are never needed: left at zero)
+        t0 += w_lo - tile.halo;
+    }
+    double bt[K], two_lam[K], inv[K], xn[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int t = lane * K + k;
-        const bool in = t < F;
+        const int t = t0 + k;
+        const bool in = TILED ? (t >= 0 && t < r_hi) : t < F;
         bt[k] = in ? b[(size_t)t * S + s] : 0.0;
         two_lam[k] = in ? 2.0 * lam[t] : 0.0;
         inv[k] = in ? inv_on[t] : 0.0;            // frames past the end stay exactly 0 = the zero halo
+        xn[k] = bt[k];                            // x_start = b (mfs.py:871) ...
+        if constexpr (TILED)
+            if (tile.x_in != b) xn[k] = in ? tile.x_in[(size_t)t * S + s] : 0.0;     // ... or the state the sweeps before this launch left
     }
     for (int i = lane; i < LEN; i += NTHR) { xs0[i] = 0.0; xs1[i] = 0.0; }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; ++k) xs0[omega + lane * K + k] = bt[k];   // x_start = b
+    for (int k = 0; k < K; ++k) xs0[omega + lane * K + k] = xn[k];
     __syncthreads();
 
     double* cur = xs0;
     double* nxt = xs1;
-    double xn[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) xn[k] = bt[k];
     for (int it = 0; it < iters; ++it) {
         const double* src = cur + lane * K;        // src[j] = x[frame lane K + j - omega]
         double r[K], acc[K];
@@ -156,9 +165,27 @@ __global__ __launch_bounds__(64 * WAVES) void jacobi_runtime_kernel(const double
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int t = lane * K + k;
-        if (t < F) x_out[(size_t)t * S + s] = xn[k];
+        const int t = t0 + k;
+        if (TILED ? (t >= w_lo && t < w_hi) : t < F) x_out[(size_t)t * S + s] = xn[k];
     }
+}
+
+template <int K, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void jacobi_runtime_kernel(const double* __restrict__ b, double* __restrict__ x_out,
+                                                                    const double* __restrict__ taps_g, const double* __restrict__ lam,
+                                                                    const double* __restrict__ inv_on, int F, int S, int omega, int iters)
+{
+    jacobi_runtime_body<K, WAVES, false>(b, x_out, taps_g, lam, inv_on, F, S, omega, iters, JacobiTile{});
+}
+
+// grid = (S, time tiles)
+template <int K, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void jacobi_runtime_tiled_kernel(const double* __restrict__ b, double* __restrict__ x_out,
+                                                                          const double* __restrict__ taps_g, const double* __restrict__ lam,
+                                                                          const double* __restrict__ inv_on, int F, int S, int omega, int iters,
+                                                                          JacobiTile tile)
+{
+    jacobi_runtime_body<K, WAVES, true>(b, x_out, taps_g, lam, inv_on, F, S, omega, iters, tile);
 }
 
 template <int K, int WAVES>
@@ -208,6 +235,105 @@ __global__ __launch_bounds__(256) void jacobi_generic_kernel(const double* __res
     for (int t = threadIdx.x; t < F; t += blockDim.x) x_out[(size_t)t * S + s] = cur[omega + t];
 }
 
+// ---- clips of ANY length (mfs.py:193-213 reads every frame of the file; mfs.py:632-710, 871-878 work for any num_frames) ----------
+//
+// The kernels above keep a series' whole time axis in LDS: 64 x 8 x 19 = 9,728 frames at most.  Beyond that the clip is swept in TIME
+// TILES: a workgroup takes MF_JACOBI_TILE_LEN consecutive frames of one series -- T frames it will write plus a halo of ks * omega frames
+// either side -- and runs ks sweeps on them in LDS exactly as the untiled kernels do; a frame's value after ks sweeps depends on the
+// frames within ks * omega of it only, so the T inner frames come out as the whole-clip sweep computes them, bit for bit.  All `iters`
+// sweeps take ceil(iters / ks_max) launches that ping-pong between x and one scratch array of F x S doubles (stream-ordered
+// allocation); b is only ever read.  ks_max keeps the halo at a quarter of the tile or less (at omega = 10 all 100 sweeps of the
+// default configuration are ONE launch: halo 1,000, T = 7,728 -- 26 % redundant rows).  HBM/L2 traffic: (x_in + b in, x out) per LAUNCH,
+// not per sweep.
+struct ScratchAsync {
+    void* p = nullptr;
+    hipStream_t st = nullptr;
+    hipError_t alloc(size_t bytes, hipStream_t s) { st = s; return hipMallocAsync(&p, bytes, s); }
+    ~ScratchAsync() { if (p) (void)hipFreeAsync(p, st); }
+};
+
+template <typename Launch>
+static int sweep_launches(const double* b, double* x, int F, int S, int iters, int ks_max, hipStream_t st, Launch&& launch)
+{
+    if (iters == 0) {                                   // x = x_start = b (mfs.py:871)
+        MF_HIP_TRY(hipMemcpyAsync(x, b, (size_t)F * S * sizeof(double), hipMemcpyDeviceToDevice, st));
+        return MF_OK;
+    }
+    const int launches = (iters + ks_max - 1) / ks_max;
+    ScratchAsync tmp;
+    if (launches > 1) MF_HIP_TRY(tmp.alloc((size_t)F * S * sizeof(double), st));
+    const double* src = b;
+    int done = 0;
+    for (int i = 0; i < launches; ++i) {
+        const int ks = (iters - done + (launches - i) - 1) / (launches - i);          // the sweeps spread evenly over the launches
+        double* dst = ((launches - 1 - i) % 2 == 0) ? x : (double*)tmp.p;             // the last launch writes x
+        if (const int rc = launch(src, dst, ks)) return rc;
+        src = dst;
+        done += ks;
+    }
+    return MF_OK;
+}
+
+static int launch_jacobi_tiled(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
+                               int F, int S, int omega, int iters, hipStream_t st)
+{
+    constexpr int K = MF_JACOBI_TILE_K, WAVES = MF_JACOBI_TILE_WAVES, LEN = MF_JACOBI_TILE_LEN;
+    const int ks_max = (LEN / 4) / omega > 1 ? (LEN / 4) / omega : 1;
+    const char* fr = getenv("MF_JACOBI_RUNTIME");                     // testing aid, read at every call: the run-time-radius form
+    const bool force_runtime = fr && *fr == '1';
+    return sweep_launches(b, x, F, S, iters, ks_max, st, [&](const double* src, double* dst, int ks) {
+        JacobiTile tile;
+        tile.x_in = src;
+        tile.halo = ks * omega;
+        int t_max = LEN - 2 * tile.halo;                              // >= LEN / 2
+        if (const char* v = getenv("MF_JACOBI_TILE_T")) { const int cap = atoi(v); if (cap > 0 && cap < t_max) t_max = cap; }   // testing aid
+        const int ntiles = (F + t_max - 1) / t_max;
+        tile.T = (F + ntiles - 1) / ntiles;                           // (evened out: every tile costs the same whatever it writes)
+        if (ntiles > 65535) { set_error("mf_jacobi_f64: F=%d needs %d time tiles (> 65535)", F, ntiles); return (int)MF_ERR_INVALID_ARG; }
+        if (!force_runtime) {
+            const int rc = launch_jacobi_tiled_spec(b, dst, taps, lam, inv_on, F, S, omega, ks, tile, ntiles, st);
+            if (rc != MF_JACOBI_NOT_HERE) return rc;
+        }
+        const size_t lds = (size_t)2 * (LEN + 2 * omega + K) * sizeof(double);
+        hipError_t e = hipFuncSetAttribute((const void*)jacobi_runtime_tiled_kernel<K, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(jacobi_runtime_tiled_kernel)");
+        hipLaunchKernelGGL((jacobi_runtime_tiled_kernel<K, WAVES>), dim3(S, ntiles), dim3(64 * WAVES), lds, st, b, dst, taps, lam, inv_on, F, S, omega, ks, tile);
+        return hip_fail(hipGetLastError(), "jacobi_runtime_tiled_kernel launch");
+    });
+}
+static bool jacobi_tiled_fits(int omega) { return (size_t)2 * (MF_JACOBI_TILE_LEN + 2 * omega + MF_JACOBI_TILE_K) * sizeof(double) <= 160 * 1024; }   // omega <= 246
+
+// Whatever is left -- a radius of hundreds of frames on a clip too long for LDS: one launch per sweep on the arrays in global memory
+// (ping-pong between x and a scratch array), lanes along the series so that every tap reads one contiguous run of the [F][S] layout;
+// taps in ascending order from zero, one fma each, like every other form: same bits.  No shape is refused.
+__global__ __launch_bounds__(256) void jacobi_global_sweep_kernel(const double* __restrict__ b, const double* __restrict__ x_in, double* __restrict__ x_out,
+                                                                  const double* __restrict__ taps, const double* __restrict__ lam,
+                                                                  const double* __restrict__ inv_on, int F, int S, int omega, unsigned s_blocks)
+{
+    const unsigned tb = blockIdx.x / s_blocks, sb = blockIdx.x - tb * s_blocks;
+    const int s = (int)(sb * 64u + (threadIdx.x & 63u));
+    const long long t = (long long)tb * 4 + (threadIdx.x >> 6);
+    if (s >= S || t >= F) return;
+    double acc = 0.0;
+    for (int d = 0; d <= 2 * omega; ++d) {
+        const long long r = t + d - omega;
+        if (r >= 0 && r < F) acc = __builtin_fma(taps[d], x_in[(size_t)r * S + s], acc);
+    }
+    x_out[(size_t)t * S + s] = inv_on[t] * __builtin_fma(2.0 * lam[t], acc, b[(size_t)t * S + s]);
+}
+
+static int launch_jacobi_global(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
+                                int F, int S, int omega, int iters, hipStream_t st)
+{
+    const unsigned s_blocks = (unsigned)((S + 63) / 64);
+    const unsigned long long blocks = (unsigned long long)s_blocks * (unsigned long long)((F + 3) / 4);
+    if (blocks > 0x7FFFFFFFull) { set_error("mf_jacobi_f64: F=%d S=%d is beyond one launch grid", F, S); return MF_ERR_INVALID_ARG; }
+    return sweep_launches(b, x, F, S, iters, 1, st, [&](const double* src, double* dst, int) {
+        hipLaunchKernelGGL(jacobi_global_sweep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b, src, dst, taps, lam, inv_on, F, S, omega, s_blocks);
+        return hip_fail(hipGetLastError(), "jacobi_global_sweep_kernel launch");
+    });
+}
+
 int launch_jacobi(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
                   int F, int S, int omega, int iters, hipStream_t st)
 {
@@ -221,6 +347,12 @@ int launch_jacobi(const double* b, double* x, const double* taps, const double* 
     // wavefronts with fewer frames per lane.  Measured (F = 300, 100 sweeps): 162 series (8 x 8 mesh) 40.7 us with one wavefront
     // per series, 31.8 with two, 30.4 with four; 578 series (16 x 16) 48.1 / 49.1 / 50.4 -- there the workgroup barrier of
     // a split series costs what the shorter per-lane loop saves, so the split starts below 512 series.
+    // testing aid, read at every call: MF_JACOBI_LONG=1 sends any clip through the time tiles (MF_JACOBI_TILE_T caps the frames a tile
+    // writes, so that short clips have seams too), =2 through the sweep-by-sweep form in global memory
+    if (const char* v = getenv("MF_JACOBI_LONG")) {
+        if (*v == '1' && jacobi_tiled_fits(omega)) return launch_jacobi_tiled(b, x, taps, lam, inv_on, F, S, omega, iters, st);
+        if (*v == '2') return launch_jacobi_global(b, x, taps, lam, inv_on, F, S, omega, iters, st);
+    }
     static const int split = [] { const char* v = getenv("MF_JACOBI_SPLIT"); return v && *v ? atoi(v) : -1; }();   // tuning aid
     const int want = split > 0 ? split : (S < 256 ? 4 : S < 512 ? 2 : 1);
     static const bool force_runtime = [] { const char* v = getenv("MF_JACOBI_RUNTIME"); return v && *v == '1'; }();   // tuning aid
@@ -255,11 +387,10 @@ int launch_jacobi(const double* b, double* x, const double* taps, const double* 
 #undef MF_JACOBI_RT_K
 #undef MF_JACOBI_RT
     }
+    // a clip beyond every LDS kernel: time tiles (any radius up to 246), else sweep by sweep in global memory
+    if (F > MF_JACOBI_TILE_LEN && jacobi_tiled_fits(omega)) return launch_jacobi_tiled(b, x, taps, lam, inv_on, F, S, omega, iters, st);
     const size_t lds = ((size_t)2 * (F + 2 * omega) + 2 * omega + 1) * sizeof(double);
-    if (lds > 160 * 1024) {
-        set_error("mf_jacobi_f64: F=%d omega=%d needs %zu bytes of LDS (> 160 KiB)", F, omega, lds);
-        return MF_ERR_INVALID_ARG;
-    }
+    if (lds > 160 * 1024) return launch_jacobi_global(b, x, taps, lam, inv_on, F, S, omega, iters, st);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)jacobi_generic_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

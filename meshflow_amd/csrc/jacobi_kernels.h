@@ -107,14 +107,19 @@ __device__ __forceinline__ void jacobi_sweeps_piped(double (&xs)[2][64 * WAVES *
     }
 }
 
-// (Series spread over several wavefronts at a wide radius keep two wavefronts per SIMD as their register budget -- what they had
-// while the full tap table shared the kernel: scheduled for four, the barrier-coupled wavefronts measured 14 % slower.)
-template <int OMEGA, int K, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, (2 * OMEGA + 1 > 45 && WAVES > 1 && K >= 8) ? 2 : 8)))
-void jacobi_wave_kernel(const double* __restrict__ b, double* __restrict__ x_out,
-                                                         const double* __restrict__ taps,
-                                                         const double* __restrict__ lam,
-                                                         const double* __restrict__ inv_on, int F, int S, int iters, int s0)
+// A clip too long for LDS (F > 64 WAVES K) is swept in TIME TILES (jacobi.hip, launch_jacobi_tiled): a workgroup holds frames
+// [j T - halo, j T + T + halo) of one series, runs `iters` <= halo / OMEGA sweeps on them from x_in and writes frames [j T, j T + T) --
+// after k sweeps a frame's value depends on the frames within k OMEGA of it only (x_new[t] reads x[t - OMEGA .. t + OMEGA]), so what
+// the halo rows lack of their own neighbourhood never reaches the rows that are written; frames outside the clip are the zero halo
+// of the untiled kernels.  Same operations per frame in the same order: same bits.
+struct JacobiTile { const double* x_in; int T, halo; };
+
+// The body of the specialised kernel.  TILED: blockIdx.y = time tile (above); otherwise the whole clip from x = b.
+template <int OMEGA, int K, int WAVES, bool TILED>
+__device__ __forceinline__ void jacobi_wave_body(const double* __restrict__ b, double* __restrict__ x_out,
+                                                 const double* __restrict__ taps,
+                                                 const double* __restrict__ lam,
+                                                 const double* __restrict__ inv_on, int F, int S, int iters, int s0, const JacobiTile& tile)
 {
     constexpr int NT = 2 * OMEGA + 1;
     constexpr int NTHR = 64 * WAVES;
@@ -127,24 +132,32 @@ void jacobi_wave_kernel(const double* __restrict__ b, double* __restrict__ x_out
     const int s = s0 + (int)blockIdx.x;          // (series s0 .. s0 + gridDim.x - 1 of the S: a launch may cover a slice)
     const int lane = threadIdx.x;
 
-    double bt[K], two_lam[K], inv[K];
+    // frames this thread owns: t0 .. t0 + K - 1; frames [w_lo, w_hi) are written
+    int t0 = lane * K, w_lo = 0, w_hi = F, r_hi = F;
+    if constexpr (TILED) {
+        w_lo = (int)blockIdx.y * tile.T;
+        w_hi = w_lo + tile.T < F ? w_lo + tile.T : F;
+        r_hi = w_hi + tile.halo < F ? w_hi + tile.halo : F;          // (rows beyond the halo are never needed: left at zero)
+        t0 += w_lo - tile.halo;
+    }
+    double bt[K], two_lam[K], inv[K], xn[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int t = lane * K + k;
-        const bool in = t < F;
+        const int t = t0 + k;
+        const bool in = TILED ? (t >= 0 && t < r_hi) : t < F;
         bt[k] = in ? b[(size_t)t * S + s] : 0.0;
         two_lam[k] = in ? 2.0 * lam[t] : 0.0;
         inv[k] = in ? inv_on[t] : 0.0;            // frames past the end stay exactly 0 = the zero halo
+        xn[k] = bt[k];                            // x_start = b (mfs.py:871) ...
+        if constexpr (TILED)
+            if (tile.x_in != b) xn[k] = in ? tile.x_in[(size_t)t * S + s] : 0.0;     // ... or the state the sweeps before this launch left
     }
     for (int i = lane; i < LEN; i += NTHR) { xs[0][i] = 0.0; xs[1][i] = 0.0; }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; ++k) xs[0][OMEGA + lane * K + k] = bt[k];   // x_start = b
+    for (int k = 0; k < K; ++k) xs[0][OMEGA + lane * K + k] = xn[k];
     __syncthreads();
 
-    double xn[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) xn[k] = bt[k];
     bool symmetric = false;
     if (TRY_SYM) {
         typedef const __attribute__((address_space(4))) unsigned long long* cbits_t;      // (scalar loads)
@@ -193,9 +206,40 @@ void jacobi_wave_kernel(const double* __restrict__ b, double* __restrict__ x_out
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int t = lane * K + k;
-        if (t < F) x_out[(size_t)t * S + s] = xn[k];
+        const int t = t0 + k;
+        if (TILED ? (t >= w_lo && t < w_hi) : t < F) x_out[(size_t)t * S + s] = xn[k];
     }
+}
+
+// (Series spread over several wavefronts at a wide radius keep two wavefronts per SIMD as their register budget -- what they had
+// while the full tap table shared the kernel: scheduled for four, the barrier-coupled wavefronts measured 14 % slower.)
+template <int OMEGA, int K, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, (2 * OMEGA + 1 > 45 && WAVES > 1 && K >= 8) ? 2 : 8)))
+void jacobi_wave_kernel(const double* __restrict__ b, double* __restrict__ x_out,
+                                                         const double* __restrict__ taps,
+                                                         const double* __restrict__ lam,
+                                                         const double* __restrict__ inv_on, int F, int S, int iters, int s0)
+{
+    jacobi_wave_body<OMEGA, K, WAVES, false>(b, x_out, taps, lam, inv_on, F, S, iters, s0, JacobiTile{});
+}
+
+// grid = (S, time tiles)
+template <int OMEGA, int K, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(1, (2 * OMEGA + 1 > 45 && WAVES > 1 && K >= 8) ? 2 : 8)))
+void jacobi_wave_tiled_kernel(const double* __restrict__ b, double* __restrict__ x_out,
+                                                         const double* __restrict__ taps,
+                                                         const double* __restrict__ lam,
+                                                         const double* __restrict__ inv_on, int F, int S, int iters, JacobiTile tile)
+{
+    jacobi_wave_body<OMEGA, K, WAVES, true>(b, x_out, taps, lam, inv_on, F, S, iters, 0, tile);
+}
+
+template <int OMEGA, int K, int WAVES>
+static inline int launch_wave_tiled(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
+                                    int F, int S, int iters, const JacobiTile& tile, int ntiles, hipStream_t st)
+{
+    hipLaunchKernelGGL((jacobi_wave_tiled_kernel<OMEGA, K, WAVES>), dim3(S, ntiles), dim3(64 * WAVES), 0, st, b, x, taps, lam, inv_on, F, S, iters, tile);
+    return hip_fail(hipGetLastError(), "jacobi_wave_tiled_kernel launch");
 }
 
 template <int OMEGA, int K, int WAVES>
@@ -214,6 +258,14 @@ int jacobi_side_fork(hipStream_t st, hipStream_t* side);
 int jacobi_side_join(hipStream_t st);
 int jacobi_simd_count();
 
+
+// jacobi_spec.hip: `iters` sweeps of one tiled launch (frames per workgroup: MF_JACOBI_TILE_LEN) by the kernel specialised for
+// `omega`, or MF_JACOBI_NOT_HERE when that radius has no tiled specialisation (jacobi.hip then takes the run-time-radius form).
+#define MF_JACOBI_TILE_K 19
+#define MF_JACOBI_TILE_WAVES 8
+#define MF_JACOBI_TILE_LEN (64 * MF_JACOBI_TILE_WAVES * MF_JACOBI_TILE_K)
+int launch_jacobi_tiled_spec(const double* b, double* x, const double* taps, const double* lam, const double* inv_on, int F, int S, int omega,
+                             int iters, const JacobiTile& tile, int ntiles, hipStream_t st);
 
 // jacobi_spec.hip, compiled once per group of radii (MF_JACOBI_GROUP = 0..3, radii 8 g + 1 .. 8 g + 8): launches the
 // kernel specialised for `omega` and the clip length, or returns MF_JACOBI_NOT_HERE when omega / F is not in its table.

@@ -77,4 +77,16 @@ int MF_CAT(launch_jacobi_spec_g, MF_JACOBI_GROUP)(const double* b, double* x, co
     }
 }
 
+// The tiled form (clips beyond 64 x 8 x 19 frames, jacobi_kernels.h) of the radii the BASELINE configs use; every other radius takes
+// jacobi.hip's run-time-radius tiled kernel.  Defined once: in the group that owns radius 10.
+#if MF_JACOBI_GROUP == 1
+int launch_jacobi_tiled_spec(const double* b, double* x, const double* taps, const double* lam, const double* inv_on, int F, int S, int omega,
+                             int iters, const JacobiTile& tile, int ntiles, hipStream_t st)
+{
+    if (omega == 10) return launch_wave_tiled<10, MF_JACOBI_TILE_K, MF_JACOBI_TILE_WAVES>(b, x, taps, lam, inv_on, F, S, iters, tile, ntiles, st);
+    if (omega == 30) return launch_wave_tiled<30, MF_JACOBI_TILE_K, MF_JACOBI_TILE_WAVES>(b, x, taps, lam, inv_on, F, S, iters, tile, ntiles, st);
+    return MF_JACOBI_NOT_HERE;
+}
+#endif
+
 }  // namespace mf

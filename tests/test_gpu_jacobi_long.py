@@ -1,0 +1,157 @@
+"""Clips of ANY length through mf_jacobi_f64 (mfs.py:193-213 reads every frame of the file; mfs.py:632-710, 871-878 work for any
+num_frames): beyond the 9,728 frames the LDS kernels hold, the sweep runs in time tiles with a halo of (sweeps per launch) x omega
+frames (csrc/jacobi.hip, launch_jacobi_tiled), and beyond a radius of 246 sweep by sweep in global memory.  Everything bit-identical
+to the C oracle (taps ascending from zero, one fma each, then inv_on * fma(2 lam, acc, b)).  Needs a real MI355X (-m gpu)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: the -m gpu tests must run on an MI355X')
+    return torch.device('cuda:0')
+
+
+def _problem(F, S, omega, seed=0, symmetric=True):
+    from meshflow_amd import synthetic
+    b = np.cumsum(2.0 * synthetic.normal(np.arange(F * S).reshape(F, S), seed=F + omega + seed), axis=0)
+    taps = np.exp(-np.square((3 / omega) * np.arange(-omega, omega + 1)))
+    if not symmetric:
+        taps = taps * (1.0 + 0.01 * synthetic.uniform01(np.arange(2 * omega + 1), seed=11))
+    lam = 0.95 * synthetic.uniform01(np.arange(F), seed=3)
+    inv_on = 1.0 / (1 + 2 * lam * taps.sum())
+    return b, taps, lam, inv_on
+
+
+def _hip(dev, b, taps, lam, inv_on, omega, iters, reps=1):
+    from meshflow_amd import ops
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    args = (t(b), t(taps), t(lam), t(inv_on), omega, iters)
+    x = ops.jacobi(*args)
+    torch.cuda.synchronize()
+    ms = None
+    if reps > 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.jacobi(*args, out=x)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+    return x.cpu().numpy(), ms
+
+
+class _Env:
+    """The library's testing aids are read at every call (getenv): set for the duration of a `with` block."""
+
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize('F,S,omega,iters,tile', [
+    (700, 5, 10, 100, 97),          # config 2's radius and sweeps: ONE launch, halo 1,000 > the whole clip, 8 seams
+    (3000, 3, 10, 100, 1000),       # halo 1,000, tiles of 1,000
+    (1500, 4, 30, 20, 333),         # config 3's radius (specialised tiled kernel), 20 sweeps
+    (1500, 2, 30, 200, 500),        # 200 sweeps at omega = 30: three launches (67 + 67 + 66), scratch ping-pong
+    (900, 3, 1, 7, 64), (900, 3, 7, 50, 200), (1200, 2, 13, 40, 301), (1200, 2, 25, 33, 400),      # run-time-radius tiled kernel
+    (2000, 2, 40, 130, 700),        # ks_max = 60: three launches of the run-time-radius kernel
+    (1000, 2, 100, 9, 400), (1500, 1, 246, 10, 800),                                                # the widest radius the tiles hold
+    (5, 3, 10, 4, 2), (1, 2, 3, 5, 1), (64, 2, 10, 0, 16),                                          # tiny clips; no sweep at all
+])
+def test_tiled_sweep_bit_exact_on_forced_seams(dev, F, S, omega, iters, tile):
+    """MF_JACOBI_LONG=1 sends a clip of any length through the time tiles, MF_JACOBI_TILE_T caps the frames a tile writes: seams every
+    `tile` frames, halos that reach beyond both clip ends, several launches."""
+    from oracle import clib
+    b, taps, lam, inv_on = _problem(F, S, omega)
+    want = clib.jacobi_banded(b, taps, lam, inv_on, omega, iters, openmp=True)
+    with _Env(MF_JACOBI_LONG=1, MF_JACOBI_TILE_T=tile):
+        got, _ = _hip(dev, b, taps, lam, inv_on, omega, iters)
+    assert np.array_equal(got, want)
+    with _Env(MF_JACOBI_LONG=1, MF_JACOBI_TILE_T=tile, MF_JACOBI_RUNTIME=1):            # the run-time-radius form of the same tiles
+        got, _ = _hip(dev, b, taps, lam, inv_on, omega, iters)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('F,S,omega,iters', [(300, 70, 10, 9), (1000, 3, 30, 4), (257, 130, 300, 3), (40, 5, 3, 0), (1, 1, 1, 2)])
+def test_global_memory_sweep_bit_exact(dev, F, S, omega, iters):
+    """MF_JACOBI_LONG=2: one launch per sweep on the arrays in global memory (the form that takes radii beyond 246 on long clips)."""
+    from oracle import clib
+    b, taps, lam, inv_on = _problem(F, S, omega, symmetric=False)
+    want = clib.jacobi_banded(b, taps, lam, inv_on, omega, iters, openmp=True)
+    with _Env(MF_JACOBI_LONG=2):
+        got, _ = _hip(dev, b, taps, lam, inv_on, omega, iters)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('F,omega,iters', [(12000, 10, 100), (20000, 10, 100), (12000, 30, 20), (20000, 30, 20)])
+def test_long_clips_bit_exact_with_time(dev, F, omega, iters):
+    """mf_jacobi_f64 == clib.jacobi_banded at F = 12,000 / 20,000 for (omega = 10, 100 sweeps) and
+    (omega = 30, 20 sweeps), 16 x 16 mesh (578 series), with the time reported (gpurun_out/jacobi_long.jsonl)."""
+    from oracle import clib
+    S = 578
+    b, taps, lam, inv_on = _problem(F, S, omega)
+    t0 = time.perf_counter()
+    want = clib.jacobi_banded(b, taps, lam, inv_on, omega, iters, openmp=True)
+    cpu_s = time.perf_counter() - t0
+    got, ms = _hip(dev, b, taps, lam, inv_on, omega, iters, reps=5)
+    assert np.array_equal(got, want)
+    flops = float(iters) * F * S * (2 * (2 * omega + 1) + 3)
+    rec = {'F': F, 'S': S, 'omega': omega, 'iters': iters, 'ms': ms, 'tflops': flops / (ms * 1e-3) / 1e12, 'cpu_oracle_s': cpu_s}
+    print('jacobi long clip:', json.dumps(rec))
+    out = os.path.join(REPO, 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'jacobi_long.jsonl'), 'a') as fh:
+            fh.write(json.dumps(rec) + '\n')
+
+
+@pytest.mark.parametrize('F,S,omega,iters', [(9729, 3, 10, 12), (10100, 2, 246, 3), (10100, 2, 247, 3), (12000, 4, 300, 2), (40000, 2, 5, 30)])
+def test_long_clips_other_radii(dev, F, S, omega, iters):
+    """The first frame count beyond the LDS kernels; the widest radius the tiles hold and the first one that goes sweep by sweep through
+    global memory; a radius of hundreds of frames; a very long clip at a small radius (run-time-radius tiles)."""
+    from oracle import clib
+    b, taps, lam, inv_on = _problem(F, S, omega)
+    want = clib.jacobi_banded(b, taps, lam, inv_on, omega, iters, openmp=True)
+    got, _ = _hip(dev, b, taps, lam, inv_on, omega, iters)
+    assert np.array_equal(got, want)
+
+
+def test_stabilizer_accepts_a_long_clip(dev):
+    """The drop-in method itself (mfs.py:632-710) on a clip beyond the old ceiling: 11,000 frames, 4 x 4 mesh."""
+    import meshflow_amd as amd
+    from meshflow_amd import synthetic
+    from oracle import meshflow_oracle as mo
+    F, R, C, W, H = 11000, 4, 4, 640, 360
+    disp, hom = synthetic.motion(F, R, C, seed=5)
+    s = amd.MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=10, optimization_num_iterations=30, device='cuda:0')
+    frames0 = [np.zeros((H, W, 3), np.uint8)]
+    got = s._get_stabilized_vertex_displacements(F, frames0, 0, disp, hom)
+    from meshflow_amd import host
+    from oracle import clib
+    taps, lam, inv_on = host.jacobi_band_coefficients(F, W, H, 0, hom, 10)          # the product's O(F) coefficients: the sweep itself, bit for bit
+    want = clib.jacobi_banded(disp.reshape(F, -1), taps, lam, inv_on, 10, 30, openmp=True).reshape(disp.shape)
+    assert np.array_equal(got, want)
+    taps, lam, on = mo.jacobi_band_coefficients(F, W, H, 0, hom, 10)                # the oracle's coefficients (row sums in another order)
+    want = clib.jacobi_banded(disp.reshape(F, -1), taps, lam, np.reciprocal(on), 10, 30, openmp=True).reshape(disp.shape)
+    assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
