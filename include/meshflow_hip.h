@@ -197,10 +197,12 @@ int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab,
                       int32_t* crop /* [n][4] */, float* kernel_ms);
 /* The same for frames that are separate allocations (the reference's Python lists of per-frame arrays, mfs.py:997, 1100):
  * frames[i] / out[i] point to frame i, H*W*3 bytes each.  mf_warp_u8c3_host is this with frames[i] = frames + i*H*W*3.
- * Both move the clip in chunks of 16 frames on four upload and four download threads with their own HIP streams (plus
- * eight threads that fault the output pages in ahead of the downloads); a chunk is warped as soon as it has landed and
- * travels back while later chunks are still going up (pageable memory is fine; memory from mf_malloc_host makes the
- * copies truly asynchronous).  MF_PIPE_CHUNK / MF_PIPE_UP / MF_PIPE_DOWN / MF_PIPE_POPULATE in the environment retune it
+ * Both move the clip in chunks of ~50 MB (8 frames at 1080p, 2 at 4K) on four upload and four download threads with their own
+ * HIP streams (plus eight threads that fault the output pages in ahead of the downloads) through a RING of 18 chunk buffers per
+ * direction -- device memory is O(chunk) whatever the length of the clip (1.8 GB of ring for any 1080p or 4K clip); a chunk is warped
+ * as soon as it has landed (its cell table + plan are built right in front of its warp) and travels back while later chunks are still
+ * going up (pageable memory is fine; memory from mf_malloc_host makes the copies truly asynchronous).  MF_PIPE_CHUNK (frames per
+ * chunk) / MF_PIPE_SLOTS / MF_PIPE_UP / MF_PIPE_DOWN / MF_PIPE_POPULATE in the environment retune it
  * (read at every call; MF_PIPE_TRACE=1 prints the call's wall-clock milestones on stderr).  Input and output frames must NOT overlap in memory (MF_ERR_INVALID_ARG): output pages are touched
  * while the input is still being read.  Device buffers and streams are kept between calls, grow-only, ONE CACHE PER DEVICE
  * (the calling thread's current device, mf_set_device): calls on one device are serialised, calls on different devices
@@ -209,8 +211,9 @@ int mf_warp_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* out, 
                              int n, int W, int H, int R, int C, const uint8_t border_bgr[3],
                              int32_t* crop /* [n][4] */, float* kernel_ms);
 /* ... followed by the next step of stabilize(), _crop_frames (mfs.py:159, 1111-1157), in the same pipeline: before any frame
- * moves, the cell table of the whole clip is built and the clip-level rectangle {max left, max top, min right, min bottom}
- * (mfs.py:1103-1106) taken from it (mf_crop_scan_f64 + mf_crop_reduce: the edge scans look at the coordinate maps only) and written to
+ * moves, the cell tables of the whole clip are built (piece by piece, into one scratch table) and the clip-level rectangle
+ * {max left, max top, min right, min bottom} (mfs.py:1103-1106) taken from them (mf_crop_scan_f64 + mf_crop_reduce: the edge scans look
+ * at the coordinate maps only) and written to
  * bounds[4]; then every chunk goes up, is warped, cropped to the rectangle and resized back to W x H (mf_crop_resize_u8c3) and comes
  * down in ONE phase, both PCIe directions busy throughout: cropped[i] receives frame i of what stabilize() hands to the encoder.
  * `out` (the uncropped stabilized frames) may be NULL: they then never cross PCIe.  A degenerate mesh (MF_ERR_DEGENERATE) or an empty
@@ -219,6 +222,12 @@ int mf_warp_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* out, 
 int mf_warp_crop_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* out /* may be NULL */, uint8_t* const* cropped,
                                   const double* unstab, const double* stab, int n, int W, int H, int R, int C,
                                   const uint8_t border_bgr[3], int32_t* crop /* [n][4] */, int32_t bounds[4], float* kernel_ms);
+/* _crop_frames (mfs.py:1111-1157, called at mfs.py:159) BY ITSELF on host frames: frames[i] (H*W*3 bytes each) are cropped to the
+ * inclusive rectangle {left, top, right, bottom} and scaled back to W x H (mf_crop_resize_u8c3) into cropped[i], through the same
+ * ring of chunk buffers and copy threads as the warp wrappers (upload, resize, download of the chunks all overlap).  An empty or
+ * out-of-frame rectangle is MF_ERR_INVALID_ARG before any output byte is written. */
+int mf_crop_resize_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* cropped, int n, int W, int H, int left, int top,
+                                    int right, int bottom, float* kernel_ms);
 int mf_host_cache_release(void);
 
 /* ---- multi-GPU exchange steps, on RCCL directly: ONE process drives the GPUs 0..ndev-1 of a node ----

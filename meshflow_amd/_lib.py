@@ -52,6 +52,7 @@ SIGNATURES = {
     'mf_warp_u8c3_host': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     'mf_warp_u8c3_host_frames': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     'mf_warp_crop_u8c3_host_frames': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    'mf_crop_resize_u8c3_host_frames': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_float)]),
     'mf_host_cache_release': (_i, []),
     'mf_comm_init_all': (_i, [_i]),
     'mf_comm_size': (_i, [ctypes.POINTER(_i)]),

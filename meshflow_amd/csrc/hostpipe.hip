@@ -2,19 +2,24 @@
 // _get_stabilized_frames_and_crop_boundaries, mfs.py:909-1108, calls): frames in host memory in, stabilized frames in host
 // memory out, with the PCIe transfers chunked and overlapped with each other and with the kernels.
 //
-// The clip moves in chunks of MF_PIPE_CHUNK frames.  UP host threads each own a HIP stream and copy "their" chunks up
-// (pageable memory is fine: the runtime stages it; pinned memory -- mf_malloc_host -- makes the copies truly asynchronous);
-// the calling thread waits for chunk k's upload event, launches the cell table + warp of that chunk on the compute stream
-// and records an event; DOWN host threads wait for it on their own streams and copy the stabilized chunk back, while
-// later chunks are still going up.  PCIe carries both directions at once and the kernels disappear behind the copies
-// (the same scheme as meshflow_amd/pipeline.py, below Python).  Device buffers, streams and the per-chunk cell table are
-// kept between calls (grow-only cache, ONE PER DEVICE, each serialised by its own mutex: a process that drives several GPUs
-// from several host threads -- mf_set_device(g) per thread -- runs their clips concurrently; mf_host_cache_release frees them).
+// The clip moves in chunks of ~50 MB (8 frames at 1080p, 2 at 4K; MF_PIPE_CHUNK = frames per chunk overrides) through a RING of
+// MF_PIPE_SLOTS (18) chunk-sized device buffers per direction: device memory is O(chunk), whatever the length of the clip (2,000 frames
+// of 1080p and all 1,200 frames of config 4's 4K clip go through 1.8 GB of ring).  UP host threads each own a HIP stream and copy
+// "their" chunks into the ring slot chunk k % slots -- once the download of the chunk that used the slot before has ended (an event
+// wait on the upload stream, no host synchronisation) -- (pageable memory is fine: the runtime stages it; pinned memory --
+// mf_malloc_host -- makes the copies truly asynchronous); the calling thread waits for chunk k's upload event, launches the cell table
+// + plan + warp of that chunk on the compute stream and records an event; DOWN host threads wait for it on their own streams and copy
+// the stabilized chunk back, while later chunks are still going up.  PCIe carries both directions at once and the kernels disappear
+// behind the copies.  The ring, the per-chunk cell table, streams and small buffers are kept between calls (grow-only cache, ONE PER
+// DEVICE, each serialised by its own mutex: a process that drives several GPUs from several host threads -- mf_set_device(g) per
+// thread -- runs their clips concurrently; mf_host_cache_release frees them).
 //
-// With `cropped` the call also runs the next step of stabilize(), _crop_frames (mfs.py:159, 1111-1157): once every chunk is
-// warped, the clip-level crop rectangle is reduced on the device (mfs.py:1103-1106), read back (16 bytes), and each chunk is
-// cropped + resized into the (no longer needed) input stack and travels back; `out` may then be NULL -- the reference only
-// uses the cropped frames afterwards -- and the uncropped frames never cross PCIe.
+// With `cropped` the call also runs the next step of stabilize(), _crop_frames (mfs.py:159, 1111-1157), in the SAME single phase: the
+// clip-level crop rectangle (mfs.py:1103-1106) is taken from the cell tables alone before the first frame moves (the tables of the
+// whole clip are built piece by piece into one scratch table and scanned, mf_crop_scan_f64: ~1 ms per 1,000 frames), so every chunk is
+// uploaded, warped, cropped + resized (into the ring slot its input came in: the warp was that slot's only reader) and downloaded
+// while later chunks are still going up; `out` may then be NULL -- the reference only uses the cropped frames afterwards -- and the
+// uncropped frames never cross PCIe.  mf_crop_resize_u8c3_host_frames is _crop_frames by itself through the same ring.
 #include <stdlib.h>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -34,7 +39,13 @@
 namespace mf {
 namespace {
 
-constexpr int PIPE_CHUNK = 16;     // frames per chunk (100 MB at 1080p)
+// Chunk size and ring depth (measured on MI355X hosts, profiles/r05_e2e_ring.txt; at a fixed ring of ~1.8 GB many small chunks beat few
+// large ones -- the uploads run further ahead of the downloads while the link has nothing to bring back yet, and the ramps at both ends
+// of a clip are shorter: 1080p 16 frames x 8 slots 5,200-5,240 frames/s, 8 x 18 5,470-5,480; 4K 16 frames per chunk 1,160-1,290,
+// 4 x 8 1,290-1,490, 2 x 18 1,410-1,440)
+constexpr size_t PIPE_CHUNK_BYTES = (size_t)50 << 20;    // bytes per chunk: 8 frames at 1080p, 2 at 4K (MF_PIPE_CHUNK = frames overrides)
+constexpr int PIPE_SLOTS = 18;     // ring slots per direction (MF_PIPE_SLOTS): 2 x 18 x 50 MB = 1.8 GB of device memory for a clip of any length
+constexpr size_t PIPE_SCAN_TABLE_BYTES = (size_t)96 << 20;   // scratch table of the rectangle pre-pass: ~330 frames of 1080p at a 16 x 16 mesh per piece
 constexpr int PIPE_UP = 4;         // upload threads / streams   (2/2: 59 ms, 3/3: 64, 4/4: 58, 6/6: 57 per cfg2 clip)
 constexpr int PIPE_DOWN = 4;       // download threads / streams
 constexpr int PIPE_POPULATE = 8;   // threads that fault the output pages in ahead of the downloads (MF_PIPE_POPULATE, 0 = none)
@@ -66,11 +77,11 @@ constexpr int PIPE_MAX_DEVICES = 64;
 struct PipeCache {
     std::mutex lock;
     int device = -1;
-    Grow frames, out, table, unstab, stab, crop, status, work, bounds;
+    Grow frames, out, table, scan, unstab, stab, crop, status, work, bounds;       // frames / out: the two rings
     hipStream_t compute = nullptr, up[PIPE_MAX] = {}, down[PIPE_MAX] = {};
     void release()
     {
-        frames.release(); out.release(); table.release(); unstab.release(); stab.release(); crop.release(); status.release();
+        frames.release(); out.release(); table.release(); scan.release(); unstab.release(); stab.release(); crop.release(); status.release();
         work.release(); bounds.release();
         if (compute) (void)hipStreamDestroy(compute);
         for (auto& s : up) { if (s) (void)hipStreamDestroy(s); s = nullptr; }
@@ -84,7 +95,7 @@ PipeCache g_pipe[PIPE_MAX_DEVICES];          // one cache per device: nothing is
 struct Shared {
     std::mutex m;
     std::condition_variable cv;
-    std::vector<char> up_ready, warp_ready, populated, resize_ready, populated2;
+    std::vector<char> up_ready, warp_ready, populated, resize_ready, populated2, down_issued;
     hipError_t err = hipSuccess;
     const char* what = "";
     bool abort = false;
@@ -109,6 +120,7 @@ struct Shared {
 };
 
 // frames i0..i1-1 between host pointers and the device stack, as few copies as the host layout allows
+// (`dev` = where frame i0 lives on the device: the chunk's ring slot)
 hipError_t copy_frames(uint8_t* dev, const uint8_t* const* host, int i0, int i1, size_t fb, bool to_device, hipStream_t st)
 {
     int i = i0;
@@ -116,8 +128,8 @@ hipError_t copy_frames(uint8_t* dev, const uint8_t* const* host, int i0, int i1,
         int j = i + 1;
         while (j < i1 && host[j] == host[j - 1] + fb) ++j;            // run of frames contiguous in host memory
         const size_t bytes = (size_t)(j - i) * fb;
-        hipError_t e = to_device ? hipMemcpyAsync(dev + (size_t)i * fb, host[i], bytes, hipMemcpyHostToDevice, st)
-                                 : hipMemcpyAsync(const_cast<uint8_t*>(host[i]), dev + (size_t)i * fb, bytes, hipMemcpyDeviceToHost, st);
+        hipError_t e = to_device ? hipMemcpyAsync(dev + (size_t)(i - i0) * fb, host[i], bytes, hipMemcpyHostToDevice, st)
+                                 : hipMemcpyAsync(const_cast<uint8_t*>(host[i]), dev + (size_t)(i - i0) * fb, bytes, hipMemcpyDeviceToHost, st);
         if (e != hipSuccess) return e;
         i = j;
     }
@@ -165,18 +177,35 @@ bool ranges_overlap(const uint8_t* const* a, const uint8_t* const* b, int n, siz
 
 }  // namespace
 
-int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t* const* cropped, const double* unstab, const double* stab,
-                     int n, int W, int H, int R, int C, const uint8_t border_bgr[3], int32_t* crop, int32_t* bounds, float* kernel_ms)
+// One job of the pipeline.  warp: frames -> (out: stabilized frames) (cropped: + _crop_frames of them); !warp: _crop_frames of `frames`
+// by itself with the rectangle given (-> cropped).
+struct PipeJob {
+    const uint8_t* const* frames; uint8_t* const* out; uint8_t* const* cropped;
+    const double* unstab; const double* stab;
+    int n, W, H, R, C;
+    uint32_t border;
+    int32_t* crop; int32_t* bounds; float* kernel_ms;
+    bool warp;
+    int rect[4];
+    const char* name;
+};
+
+int run_host_pipeline(PipeJob job)
 {
+    const uint8_t* const* frames = job.frames;
+    uint8_t* const* out = job.out;
+    uint8_t* const* cropped = job.cropped;
+    const int n = job.n, W = job.W, H = job.H, R = job.R, C = job.C;
+    float* kernel_ms = job.kernel_ms;
     int dev = 0;
     MF_HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= PIPE_MAX_DEVICES) { set_error("mf_warp_u8c3_host: device %d out of range", dev); return MF_ERR_INVALID_ARG; }
+    if (dev < 0 || dev >= PIPE_MAX_DEVICES) { set_error("%s: device %d out of range", job.name, dev); return MF_ERR_INVALID_ARG; }
     PipeCache& pc = g_pipe[dev];
     std::lock_guard<std::mutex> cache_guard(pc.lock);
     const size_t fb = (size_t)W * H * 3;
     if ((out && ranges_overlap(frames, out, n, fb)) || (cropped && ranges_overlap(frames, cropped, n, fb)) ||
         (out && cropped && ranges_overlap(out, cropped, n, fb))) {
-        set_error("mf_warp_u8c3_host: input and output frames overlap in memory (in-place operation is not supported)");
+        set_error("%s: input and output frames overlap in memory (in-place operation is not supported)", job.name);
         return MF_ERR_INVALID_ARG;
     }
     if (pc.device != dev) {                              // first use of this device: its streams
@@ -188,26 +217,35 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
     }
     const size_t vb1 = (size_t)(R + 1) * (C + 1) * 2 * sizeof(double);        // vertex displacements of one frame
     // (read at every call: a host may retune between clips)
-    const int cfg_chunk = env_int("MF_PIPE_CHUNK", PIPE_CHUNK, 1, 4096), cfg_up = env_int("MF_PIPE_UP", PIPE_UP, 1, PIPE_MAX),
-              cfg_down = env_int("MF_PIPE_DOWN", PIPE_DOWN, 1, PIPE_MAX), cfg_pop = env_int("MF_PIPE_POPULATE", PIPE_POPULATE, 0, PIPE_MAX);
+    const int by_bytes = (int)std::min<size_t>(4096, std::max<size_t>(1, (PIPE_CHUNK_BYTES + fb / 2) / fb));
+    const int cfg_chunk = env_int("MF_PIPE_CHUNK", by_bytes, 1, 4096), cfg_up = env_int("MF_PIPE_UP", PIPE_UP, 1, PIPE_MAX),
+              cfg_down = env_int("MF_PIPE_DOWN", PIPE_DOWN, 1, PIPE_MAX), cfg_pop = env_int("MF_PIPE_POPULATE", PIPE_POPULATE, 0, PIPE_MAX),
+              cfg_slots = env_int("MF_PIPE_SLOTS", PIPE_SLOTS, 2, 64);
     const int chunk = n < cfg_chunk ? n : cfg_chunk;
     const int nchunks = (n + chunk - 1) / chunk;
-    MF_HIP_TRY(pc.frames.need(fb * n)); MF_HIP_TRY(pc.out.need(fb * n));
-    MF_HIP_TRY(pc.unstab.need(vb1 * n)); MF_HIP_TRY(pc.stab.need(vb1 * n));
-    MF_HIP_TRY(pc.table.need(table_bytes(n, W, H, R, C)));           // of the whole clip: built once, before the first chunk
-    MF_HIP_TRY(pc.crop.need((size_t)n * 4 * sizeof(int32_t)));
-    MF_HIP_TRY(pc.status.need(sizeof(int32_t)));
-    MF_HIP_TRY(pc.bounds.need(4 * sizeof(int32_t)));
+    const int slots = nchunks < cfg_slots ? nchunks : cfg_slots;
+    const size_t slot_bytes = fb * chunk;
+    MF_HIP_TRY(pc.frames.need(slot_bytes * slots)); MF_HIP_TRY(pc.out.need(slot_bytes * slots));
+    if (job.warp) {
+        MF_HIP_TRY(pc.unstab.need(vb1 * n)); MF_HIP_TRY(pc.stab.need(vb1 * n));
+        MF_HIP_TRY(pc.table.need(table_bytes(chunk, W, H, R, C)));       // of ONE chunk: rebuilt in front of every chunk's warp (~20 us)
+        MF_HIP_TRY(pc.crop.need((size_t)n * 4 * sizeof(int32_t)));
+        MF_HIP_TRY(pc.status.need(sizeof(int32_t)));
+        MF_HIP_TRY(pc.bounds.need(4 * sizeof(int32_t)));
+    }
     if (cropped) MF_HIP_TRY(pc.work.need(crop_resize_workspace_bytes(W, H)));
-    uint8_t* d_frames = (uint8_t*)pc.frames.p;
-    uint8_t* d_out = (uint8_t*)pc.out.p;
+    uint8_t* const ring_in = (uint8_t*)pc.frames.p;
+    uint8_t* const ring_out = (uint8_t*)pc.out.p;
     int32_t* d_crop = (int32_t*)pc.crop.p;
+    const double* d_unstab = (const double*)pc.unstab.p;
+    const double* d_stab = (const double*)pc.stab.p;
+    const size_t v2 = vb1 / sizeof(double);
 
-    std::vector<hipEvent_t> up_done(nchunks, nullptr), warp_done(nchunks, nullptr), resize_done(nchunks, nullptr), t0(nchunks, nullptr),
-        t1(nchunks, nullptr);
+    std::vector<hipEvent_t> up_done(nchunks, nullptr), warp_done(nchunks, nullptr), resize_done(nchunks, nullptr), down_done(nchunks, nullptr),
+        t0(nchunks, nullptr), t1(nchunks, nullptr);
     hipEvent_t r0 = nullptr, r1 = nullptr;
     struct EventGuard {
-        std::vector<hipEvent_t>* v[5];
+        std::vector<hipEvent_t>* v[6];
         hipEvent_t *a, *b;
         ~EventGuard()
         {
@@ -215,46 +253,57 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
             if (*a) (void)hipEventDestroy(*a);
             if (*b) (void)hipEventDestroy(*b);
         }
-    } guard{{&up_done, &warp_done, &resize_done, &t0, &t1}, &r0, &r1};
+    } guard{{&up_done, &warp_done, &resize_done, &down_done, &t0, &t1}, &r0, &r1};
     for (int k = 0; k < nchunks; ++k) {
         MF_HIP_TRY(hipEventCreateWithFlags(&up_done[k], hipEventDisableTiming));
         if (out) MF_HIP_TRY(hipEventCreateWithFlags(&warp_done[k], hipEventDisableTiming));
         if (cropped) MF_HIP_TRY(hipEventCreateWithFlags(&resize_done[k], hipEventDisableTiming));
+        if (k + slots < nchunks) MF_HIP_TRY(hipEventCreateWithFlags(&down_done[k], hipEventDisableTiming));       // (only where a later chunk takes the slot over)
         if (kernel_ms) { MF_HIP_TRY(hipEventCreate(&t0[k])); MF_HIP_TRY(hipEventCreate(&t1[k])); }
     }
     if (kernel_ms) { MF_HIP_TRY(hipEventCreate(&r0)); MF_HIP_TRY(hipEventCreate(&r1)); }
 
-    // Before any frame moves: vertex paths up, the cell table + footprint plan of the WHOLE clip (0.1-0.4 ms), and -- with `cropped` --
-    // the clip-level crop rectangle from the table alone (mf_crop_scan_f64: the edge scans of mfs.py:1075-1098 look at the coordinate
-    // maps, not at pixels), so that _crop_frames can follow every chunk's warp directly.  A degenerate mesh or an empty rectangle
-    // (cv2.resize would fail on an empty source) ends the call here: no frame has been uploaded, no output page touched.
-    const uint32_t border = (uint32_t)border_bgr[0] | ((uint32_t)border_bgr[1] << 8) | ((uint32_t)border_bgr[2] << 16);
-    const TableView tv = table_view(pc.table.p, n, W, H, R, C);
+    // Before any frame moves: vertex paths up and -- with `cropped` -- the clip-level crop rectangle from the cell tables alone
+    // (mf_crop_scan_f64: the edge scans of mfs.py:1075-1098 look at the coordinate maps, not at pixels), so that _crop_frames can follow
+    // every chunk's warp directly: the tables of the whole clip are built piece by piece into one scratch table (O(piece) memory) and
+    // scanned.  A degenerate mesh or an empty rectangle (cv2.resize would fail on an empty source) ends the call here: no frame has
+    // been uploaded, no output page touched.
+    const uint32_t border = job.border;
     int32_t status = 0;
-    int32_t rect[4] = { 0, 0, W - 1, H - 1 };
-    MF_HIP_TRY(hipMemsetAsync(pc.status.p, 0, sizeof(int32_t), pc.compute));
-    MF_HIP_TRY(hipMemcpyAsync(pc.unstab.p, unstab, vb1 * n, hipMemcpyHostToDevice, pc.compute));
-    MF_HIP_TRY(hipMemcpyAsync(pc.stab.p, stab, vb1 * n, hipMemcpyHostToDevice, pc.compute));
+    int32_t rect[4] = { job.rect[0], job.rect[1], job.rect[2], job.rect[3] };
+    if (job.warp) {
+        MF_HIP_TRY(hipMemsetAsync(pc.status.p, 0, sizeof(int32_t), pc.compute));
+        MF_HIP_TRY(hipMemcpyAsync(pc.unstab.p, job.unstab, vb1 * n, hipMemcpyHostToDevice, pc.compute));
+        MF_HIP_TRY(hipMemcpyAsync(pc.stab.p, job.stab, vb1 * n, hipMemcpyHostToDevice, pc.compute));
+    }
     if (kernel_ms) MF_HIP_TRY(hipEventRecord(r0, pc.compute));
-    if (const int rc0 = launch_cell_table((const double*)pc.unstab.p, (const double*)pc.stab.p, n, W, H, R, C, tv, d_crop, (int32_t*)pc.status.p, pc.compute)) return rc0;
-    if (cropped) {
-        if (const int rc0 = launch_crop_scan(tv, n, W, H, R, C, d_crop, pc.compute)) return rc0;
+    if (job.warp && cropped) {
+        const size_t per_frame = table_bytes(1, W, H, R, C);
+        int piece = (int)std::max<size_t>(1, PIPE_SCAN_TABLE_BYTES / per_frame);
+        if (piece > n) piece = n;
+        MF_HIP_TRY(pc.scan.need(table_bytes(piece, W, H, R, C)));
+        for (int i0 = 0; i0 < n; i0 += piece) {
+            const int m = n - i0 < piece ? n - i0 : piece;
+            const TableView tv = table_view(pc.scan.p, m, W, H, R, C);
+            if (const int rc0 = launch_cell_table(d_unstab + v2 * i0, d_stab + v2 * i0, m, W, H, R, C, tv, d_crop + 4 * (size_t)i0, (int32_t*)pc.status.p, pc.compute)) return rc0;
+            if (const int rc0 = launch_crop_scan(tv, m, W, H, R, C, d_crop + 4 * (size_t)i0, pc.compute)) return rc0;
+        }
         if (const int rc0 = launch_crop_reduce(d_crop, n, W, H, (int32_t*)pc.bounds.p, pc.compute)) return rc0;
     }
     if (kernel_ms) MF_HIP_TRY(hipEventRecord(r1, pc.compute));
-    if (cropped) {
+    if (job.warp && cropped) {
         MF_HIP_TRY(hipMemcpyAsync(rect, pc.bounds.p, sizeof rect, hipMemcpyDeviceToHost, pc.compute));
         MF_HIP_TRY(hipMemcpyAsync(&status, pc.status.p, sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute));
         MF_HIP_TRY(hipStreamSynchronize(pc.compute));
-        if (bounds) for (int i = 0; i < 4; ++i) bounds[i] = rect[i];
+        if (job.bounds) for (int i = 0; i < 4; ++i) job.bounds[i] = rect[i];
         if (status != 0) {
-            set_error("mf_warp_u8c3_host: %d degenerate mesh cell(s): no homography exists (cv2.findHomography would return None)", status);
+            set_error("%s: %d degenerate mesh cell(s): no homography exists (cv2.findHomography would return None)", job.name, status);
             return MF_ERR_DEGENERATE;
         }
         if (rect[2] < rect[0] || rect[3] < rect[1]) {
-            MF_HIP_TRY(hipMemcpy(crop, d_crop, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));       // (the per-frame values say which frame emptied it)
-            set_error("mf_warp_crop_u8c3_host_frames: empty crop rectangle (%d, %d, %d, %d): cv2.resize would fail on an empty source",
-                      rect[0], rect[1], rect[2], rect[3]);
+            MF_HIP_TRY(hipMemcpy(job.crop, d_crop, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));       // (the per-frame values say which frame emptied it)
+            set_error("%s: empty crop rectangle (%d, %d, %d, %d): cv2.resize would fail on an empty source",
+                      job.name, rect[0], rect[1], rect[2], rect[3]);
             return MF_ERR_INVALID_ARG;
         }
     }
@@ -267,12 +316,18 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
     sh.up_ready.assign(nchunks, 0);
     sh.warp_ready.assign(nchunks, 0);
     sh.resize_ready.assign(nchunks, 0);
+    sh.down_issued.assign(nchunks, 0);
     sh.populated.assign(nchunks, cfg_pop > 0 && out ? 0 : 1);
     sh.populated2.assign(nchunks, cfg_pop > 0 && cropped ? 0 : 1);
     std::vector<std::thread> workers;
     const int n_up = nchunks < cfg_up ? nchunks : cfg_up, n_down = nchunks < cfg_down ? nchunks : cfg_down;
     const int n_pop = nchunks < cfg_pop ? nchunks : cfg_pop;
     auto chunk_end = [&](int k) { return (k * chunk + chunk < n) ? k * chunk + chunk : n; };
+    auto slot_in = [&](int k) { return ring_in + slot_bytes * (size_t)(k % slots); };
+    auto slot_out = [&](int k) { return ring_out + slot_bytes * (size_t)(k % slots); };
+    // where chunk k's cropped + resized frames are: with the warp in front, in the slot its input came in (the warp was that slot's only
+    // reader); _crop_frames by itself writes the out ring
+    auto slot_cropped = [&](int k) { return job.warp ? slot_in(k) : slot_out(k); };
     for (int t = 0; t < n_pop; ++t)
         workers.emplace_back([&, t] {
             for (int k = t; k < nchunks; k += n_pop) {       // chunk by chunk, in the order the downloads will need the pages
@@ -286,7 +341,12 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
             if (hipSetDevice(dev) != hipSuccess) { sh.fail(hipErrorInvalidDevice, "hipSetDevice (upload thread)"); return; }
             for (int k = t; k < nchunks; k += n_up) {
                 const int i0 = k * chunk, i1 = chunk_end(k);
-                hipError_t e = copy_frames(d_frames, frames, i0, i1, fb, true, pc.up[t]);
+                hipError_t e = hipSuccess;
+                if (k >= slots) {                            // the ring slot is free once the chunk that used it before has gone down
+                    if (!sh.wait(sh.down_issued, k - slots)) return;
+                    e = hipStreamWaitEvent(pc.up[t], down_done[k - slots], 0);
+                }
+                if (e == hipSuccess) e = copy_frames(slot_in(k), frames, i0, i1, fb, true, pc.up[t]);
                 if (e == hipSuccess) e = hipEventRecord(up_done[k], pc.up[t]);
                 if (e != hipSuccess) { sh.fail(e, "upload of a frame chunk"); return; }
                 sh.mark(sh.up_ready, k);
@@ -294,9 +354,7 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
                 { std::lock_guard<std::mutex> g(sh.m); if (sh.abort) return; }
             }
         });
-    // Cropped + resized chunk k is written where input chunk k was (the warp of chunk k, in front of it on the compute stream, was
-    // that chunk's only reader) and travels back while later chunks are still going up and being warped: ONE phase, both PCIe
-    // directions busy throughout.
+    // Finished chunks travel back while later ones are still going up and being warped: ONE phase, both PCIe directions busy throughout.
     for (int t = 0; t < n_down; ++t)
         workers.emplace_back([&, t] {
             if (hipSetDevice(dev) != hipSuccess) { sh.fail(hipErrorInvalidDevice, "hipSetDevice (download thread)"); return; }
@@ -304,14 +362,19 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
                 if (out) {
                     if (!sh.wait(sh.warp_ready, k) || !sh.wait(sh.populated, k)) return;
                     hipError_t e = hipStreamWaitEvent(pc.down[t], warp_done[k], 0);
-                    if (e == hipSuccess) e = copy_frames(d_out, out, k * chunk, chunk_end(k), fb, false, pc.down[t]);
+                    if (e == hipSuccess) e = copy_frames(slot_out(k), out, k * chunk, chunk_end(k), fb, false, pc.down[t]);
                     if (e != hipSuccess) { sh.fail(e, "download of a frame chunk"); return; }
                 }
                 if (cropped) {
                     if (!sh.wait(sh.resize_ready, k) || !sh.wait(sh.populated2, k)) return;
                     hipError_t e = hipStreamWaitEvent(pc.down[t], resize_done[k], 0);
-                    if (e == hipSuccess) e = copy_frames(d_frames, cropped, k * chunk, chunk_end(k), fb, false, pc.down[t]);
+                    if (e == hipSuccess) e = copy_frames(slot_cropped(k), cropped, k * chunk, chunk_end(k), fb, false, pc.down[t]);
                     if (e != hipSuccess) { sh.fail(e, "download of a cropped frame chunk"); return; }
+                }
+                if (down_done[k]) {                          // both ring slots of chunk k are free behind this point of the stream
+                    hipError_t e = hipEventRecord(down_done[k], pc.down[t]);
+                    if (e != hipSuccess) { sh.fail(e, "hipEventRecord (download stream)"); return; }
+                    sh.mark(sh.down_issued, k);
                 }
             }
             hipError_t e = hipStreamSynchronize(pc.down[t]);
@@ -319,7 +382,8 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
             if (e != hipSuccess) sh.fail(e, "hipStreamSynchronize (download stream)");
         });
 
-    // the calling thread: the kernels of every chunk as soon as its frames have landed -- warp, then (with `cropped`) crop + resize
+    // the calling thread: the kernels of every chunk as soon as its frames have landed -- cell table + plan, warp, then (with `cropped`)
+    // crop + resize
     int rc = MF_OK;
     hipError_t e = hipSuccess;
     for (int k = 0; k < nchunks && e == hipSuccess && rc == MF_OK; ++k) {
@@ -328,15 +392,20 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
         e = hipStreamWaitEvent(pc.compute, up_done[k], 0);
         if (e != hipSuccess) { sh.fail(e, "hipStreamWaitEvent"); break; }
         if (kernel_ms) (void)hipEventRecord(t0[k], pc.compute);
-        rc = launch_warp(d_frames + fb * i0, d_out + fb * i0, table_slice(tv, i0, W, H, R, C), m, W, H, R, C, border, d_crop + 4 * (size_t)i0, pc.compute);
-        if (rc != MF_OK) { sh.fail(hipErrorUnknown, "kernel launch"); break; }
-        if (out) {
-            e = hipEventRecord(warp_done[k], pc.compute);
-            if (e != hipSuccess) { sh.fail(e, "hipEventRecord"); break; }
-            sh.mark(sh.warp_ready, k);
+        if (job.warp) {
+            const TableView tv = table_view(pc.table.p, m, W, H, R, C);
+            rc = launch_cell_table(d_unstab + v2 * i0, d_stab + v2 * i0, m, W, H, R, C, tv, d_crop + 4 * (size_t)i0, (int32_t*)pc.status.p, pc.compute);
+            if (rc == MF_OK) rc = launch_warp(slot_in(k), slot_out(k), tv, m, W, H, R, C, border, d_crop + 4 * (size_t)i0, pc.compute);
+            if (rc != MF_OK) { sh.fail(hipErrorUnknown, "kernel launch"); break; }
+            if (out) {
+                e = hipEventRecord(warp_done[k], pc.compute);
+                if (e != hipSuccess) { sh.fail(e, "hipEventRecord"); break; }
+                sh.mark(sh.warp_ready, k);
+            }
         }
         if (cropped) {                                     // _crop_frames (mfs.py:1111-1157) of this chunk, its source still in the caches
-            rc = launch_crop_resize(d_out + fb * i0, d_frames + fb * i0, m, W, H, rect[0], rect[1], rect[2], rect[3], pc.work.p, pc.compute);
+            rc = job.warp ? launch_crop_resize(slot_out(k), slot_in(k), m, W, H, rect[0], rect[1], rect[2], rect[3], pc.work.p, pc.compute)
+                          : launch_crop_resize(slot_in(k), slot_out(k), m, W, H, rect[0], rect[1], rect[2], rect[3], pc.work.p, pc.compute);
             if (rc != MF_OK) { sh.fail(hipErrorUnknown, "kernel launch"); break; }
             e = hipEventRecord(resize_done[k], pc.compute);
             if (e != hipSuccess) { sh.fail(e, "hipEventRecord"); break; }
@@ -344,12 +413,12 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
         }
         if (kernel_ms) (void)hipEventRecord(t1[k], pc.compute);
     }
-    if (!sh.abort) {
+    if (!sh.abort && job.warp) {
         // per-frame crop values (and, without the early scan, the clip-level rectangle and the degenerate-mesh count) in one wait
         if (!cropped) rc = launch_crop_reduce(d_crop, n, W, H, (int32_t*)pc.bounds.p, pc.compute);
         if (rc != MF_OK) sh.fail(hipErrorUnknown, "kernel launch");
         else {
-            e = hipMemcpyAsync(crop, d_crop, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute);
+            e = hipMemcpyAsync(job.crop, d_crop, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute);
             if (e == hipSuccess && !cropped) e = hipMemcpyAsync(rect, pc.bounds.p, sizeof rect, hipMemcpyDeviceToHost, pc.compute);
             if (e == hipSuccess && !cropped) e = hipMemcpyAsync(&status, pc.status.p, sizeof(int32_t), hipMemcpyDeviceToHost, pc.compute);
             if (e == hipSuccess) e = hipStreamSynchronize(pc.compute);
@@ -358,11 +427,11 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
     }
     if (trace) fprintf(stderr, "[mf pipe] %8.2f ms  every chunk's kernels issued\n", since());
     for (auto& w : workers) w.join();
-    if (trace) fprintf(stderr, "[mf pipe] %8.2f ms  done (%d frames of %d x %d, %d chunks)\n", since(), n, W, H, nchunks);
-    if (bounds) for (int i = 0; i < 4; ++i) bounds[i] = rect[i];
+    if (trace) fprintf(stderr, "[mf pipe] %8.2f ms  done (%d frames of %d x %d, %d chunks of %d, %d ring slots)\n", since(), n, W, H, nchunks, chunk, slots);
+    if (job.bounds) for (int i = 0; i < 4; ++i) job.bounds[i] = rect[i];
     if (status != 0) {
         (void)hipDeviceSynchronize();
-        set_error("mf_warp_u8c3_host: %d degenerate mesh cell(s): no homography exists (cv2.findHomography would return None)", status);
+        set_error("%s: %d degenerate mesh cell(s): no homography exists (cv2.findHomography would return None)", job.name, status);
         return MF_ERR_DEGENERATE;
     }
     if (sh.abort) {
@@ -374,10 +443,24 @@ int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t*
         MF_HIP_TRY(hipStreamSynchronize(pc.compute));
         float total = 0.0f;
         for (int k = 0; k < nchunks; ++k) { float ms = 0.0f; MF_HIP_TRY(hipEventElapsedTime(&ms, t0[k], t1[k])); total += ms; }
-        { float ms = 0.0f; MF_HIP_TRY(hipEventElapsedTime(&ms, r0, r1)); total += ms; }         // cell table + plan (+ scan + reduce)
+        { float ms = 0.0f; MF_HIP_TRY(hipEventElapsedTime(&ms, r0, r1)); total += ms; }         // the rectangle pre-pass (tables + scan + reduce)
         *kernel_ms = total;
     }
     return MF_OK;
+}
+
+int warp_host_frames(const uint8_t* const* frames, uint8_t* const* out, uint8_t* const* cropped, const double* unstab, const double* stab,
+                     int n, int W, int H, int R, int C, const uint8_t border_bgr[3], int32_t* crop, int32_t* bounds, float* kernel_ms)
+{
+    PipeJob job{};
+    job.frames = frames; job.out = out; job.cropped = cropped; job.unstab = unstab; job.stab = stab;
+    job.n = n; job.W = W; job.H = H; job.R = R; job.C = C;
+    job.border = (uint32_t)border_bgr[0] | ((uint32_t)border_bgr[1] << 8) | ((uint32_t)border_bgr[2] << 16);
+    job.crop = crop; job.bounds = bounds; job.kernel_ms = kernel_ms;
+    job.warp = true;
+    job.rect[0] = 0; job.rect[1] = 0; job.rect[2] = W - 1; job.rect[3] = H - 1;
+    job.name = cropped ? "mf_warp_crop_u8c3_host_frames" : "mf_warp_u8c3_host";
+    return run_host_pipeline(job);
 }
 
 }  // namespace mf
@@ -424,6 +507,28 @@ int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab,
     std::vector<uint8_t*> outp(n);
     for (int i = 0; i < n; ++i) { in[i] = frames + fb * i; outp[i] = out + fb * i; }
     return warp_host_frames(in.data(), outp.data(), nullptr, unstab, stab, n, W, H, R, C, border_bgr, crop, nullptr, kernel_ms);
+}
+
+int mf_crop_resize_u8c3_host_frames(const uint8_t* const* frames, uint8_t* const* cropped, int n, int W, int H, int left, int top,
+                                    int right, int bottom, float* kernel_ms)
+{
+    if (!frames || !cropped) { set_error("mf_crop_resize_u8c3_host_frames: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (n <= 0 || W < 1 || H < 1 || W > 32767 || H > 32767) { set_error("mf_crop_resize_u8c3_host_frames: unsupported shape n=%d W=%d H=%d", n, W, H); return MF_ERR_INVALID_ARG; }
+    if (left < 0 || top < 0 || right >= W || bottom >= H || right < left || bottom < top) {        // before any output page is touched
+        set_error("mf_crop_resize_u8c3_host_frames: empty or out-of-frame crop rectangle (%d, %d, %d, %d) for %dx%d (cv2.resize would "
+                  "fail on an empty source)", left, top, right, bottom, W, H);
+        return MF_ERR_INVALID_ARG;
+    }
+    for (int i = 0; i < n; ++i)
+        if (!frames[i] || !cropped[i]) { set_error("mf_crop_resize_u8c3_host_frames: null frame pointer %d", i); return MF_ERR_INVALID_ARG; }
+    PipeJob job{};
+    job.frames = frames; job.cropped = cropped;
+    job.n = n; job.W = W; job.H = H; job.R = 1; job.C = 1;
+    job.kernel_ms = kernel_ms;
+    job.warp = false;
+    job.rect[0] = left; job.rect[1] = top; job.rect[2] = right; job.rect[3] = bottom;
+    job.name = "mf_crop_resize_u8c3_host_frames";
+    return run_host_pipeline(job);
 }
 
 int mf_host_cache_release(void)

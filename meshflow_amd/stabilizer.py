@@ -23,6 +23,18 @@ except Exception:  # pragma: no cover
     _tqdm = None
 
 
+def _torch_device_of(self):
+    """The torch device of a stabilizer(-like) object: its `device` attribute, None / absent / 'cuda' = the CURRENT HIP device."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError('no MI355X visible: the meshflow_amd hot path has no CPU fallback')
+    name = getattr(self, 'device', None)
+    dev = torch.device(name if name is not None else 'cuda')
+    if dev.index is None:                 # 'cuda' without an index means the caller's CURRENT device, not device 0
+        dev = torch.device(dev.type, torch.cuda.current_device())
+    return dev
+
+
 def _warp_host_c(self, clip, unstab, stab, crop=False, keep_uncropped=True):
     """Host frames in -> host frames out through the C ABI's own chunked pipeline (csrc/hostpipe.hip:
     `mf_warp_u8c3_host_frames`, upload / kernel / download threads below Python, GIL released for the whole call).
@@ -238,29 +250,12 @@ class MeshFlowStabilizer:
         out_host, bounds, cropped_host = _warp_host_c(self, clip, unstab, stab, crop=True, keep_uncropped=keep_uncropped)
         return (list(out_host) if out_host is not None else None), bounds, stab, score, list(cropped_host)
 
-    def _start_upload(self, io, clip, chunk_frames):
-        """Allocates the device clip and starts the chunked upload; returns (d_frames, ranges, upload futures, clip)."""
-        import torch
-        from . import pipeline
-        dev = io.device
-        ranges = pipeline.chunk_ranges(clip.num_frames, chunk_frames)
-        d_frames = torch.empty((clip.num_frames, clip.height, clip.width, 3), dtype=torch.uint8, device=dev)
-        allocated = torch.cuda.Event()
-        allocated.record(torch.cuda.current_stream(dev))
-        return d_frames, ranges, io.upload_all(clip, d_frames, ranges, allocated), clip
-
     # ------------------------------------------------------------------------------------------
     # drop-in boundary, host buffers (same signatures as the reference)
     # ------------------------------------------------------------------------------------------
 
     def _torch_device(self):
-        import torch
-        if not torch.cuda.is_available():
-            raise RuntimeError('no MI355X visible: the meshflow_amd hot path has no CPU fallback')
-        dev = torch.device(self.device if self.device is not None else 'cuda')
-        if dev.index is None:                 # 'cuda' without an index means the caller's CURRENT device, not device 0
-            dev = torch.device(dev.type, torch.cuda.current_device())
-        return dev
+        return _torch_device_of(self)
 
     def _get_stabilized_vertex_displacements(self, num_frames, unstabilized_frames, adaptive_weights_definition,
                                              vertex_unstabilized_displacements_by_frame_index, homographies):
@@ -325,27 +320,26 @@ class MeshFlowStabilizer:
 
     def _crop_frames(self, uncropped_frames, crop_boundaries, chunk_frames=16, io_threads=3):
         """mfs.py:1111-1157: crop to the inclusive bounds and resize back to (W, H) (cv2.resize, INTER_LINEAR).
-        The bounds are known up front, so upload, resize and download of the chunks all overlap."""
+        Host frames in, host frames out through the C ABI's ring of chunk buffers (`mf_crop_resize_u8c3_host_frames`,
+        csrc/hostpipe.hip): upload, resize and download of the chunks all overlap, below Python.
+        (`chunk_frames` / `io_threads` are kept for callers of earlier versions; the C pipeline has its own, MF_PIPE_*.)"""
+        import ctypes
         import torch
-        from . import ops, pipeline
-        dev = self._torch_device()
-        clip = pipeline.HostClip(uncropped_frames, len(uncropped_frames))
-        io = pipeline.ChunkedTransfer(dev, io_threads, io_threads)
-        try:
-            d_frames, ranges, uploads, _ = self._start_upload(io, clip, chunk_frames)
-            d_out = torch.empty_like(d_frames)
-            out_host = np.empty((clip.num_frames, clip.height, clip.width, 3), dtype=np.uint8)
-            compute = torch.cuda.current_stream(dev)
-            for k, (i0, i1) in enumerate(ranges):
-                compute.wait_event(uploads[k].result())
-                ops.crop_resize(d_frames[i0:i1], crop_boundaries, out=d_out[i0:i1])
-                done = torch.cuda.Event()
-                done.record(compute)
-                io.download(d_out[i0:i1], out_host[i0:i1], done, k)
-            io.finish()
-        finally:
-            io.close()
-        return list(out_host)
+        from . import _lib, pipeline
+        dev = _torch_device_of(self)
+        n = len(uncropped_frames)
+        clip = pipeline.HostClip(uncropped_frames, n)
+        H, W = clip.height, clip.width
+        frames = [clip.array[i] for i in range(n)] if clip.array is not None else \
+            [pipeline._as_frame(f, H, W) for f in clip.frames]
+        left, top, right, bottom = (int(v) for v in crop_boundaries)
+        out = np.empty((n, H, W, 3), dtype=np.uint8)
+        fb = H * W * 3
+        pin = (ctypes.c_void_p * n)(*[f.ctypes.data for f in frames])
+        pout = (ctypes.c_void_p * n)(*[out.ctypes.data + i * fb for i in range(n)])
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.mf_crop_resize_u8c3_host_frames(pin, pout, n, W, H, left, top, right, bottom, None))
+        return list(out)
 
     def compute_scores(self, frame_width, frame_height, vertex_unstabilized_displacements_by_frame_index,
                        vertex_stabilized_displacements_by_frame_index, crop_boundaries):

@@ -23,6 +23,71 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 
+# Decoder-paced staging: frames arrive ONE AT A TIME from cv2.VideoCapture and leave one chunk at a time towards cv2.VideoWriter, so
+# this module feeds the device as chunks complete (the C ring of csrc/hostpipe.hip serves calls that hold the whole clip).
+
+def chunk_ranges(num_frames, chunk_frames):
+    chunk_frames = max(1, int(chunk_frames))
+    return [(i, min(i + chunk_frames, num_frames)) for i in range(0, num_frames, chunk_frames)]
+
+
+class ChunkedTransfer:
+    """Thread pools + streams for the two copy directions.  `upload_all` starts every upload and returns one
+    (future -> event) per chunk, in order; `download` queues the copy of a device chunk into a host array once
+    `after` (an event on the compute stream) has fired."""
+
+    def __init__(self, device, in_threads=3, out_threads=3):
+        import torch
+        self.device = device
+        self.in_streams = [torch.cuda.Stream(device=device) for _ in range(max(1, in_threads))]
+        self.out_streams = [torch.cuda.Stream(device=device) for _ in range(max(1, out_threads))]
+        self.in_pool = ThreadPoolExecutor(max_workers=len(self.in_streams), thread_name_prefix='mf-h2d')
+        self.out_pool = ThreadPoolExecutor(max_workers=len(self.out_streams), thread_name_prefix='mf-d2h')
+        self.pending = []
+
+    def upload(self, clip, d_frames, i0, i1, after, k):
+        """Queues the copy of clip frames i0..i1-1 into d_frames[i0:i1] on copy stream k (mod the pool); returns a
+        future whose result is the event that marks its end.  `after`: event on the stream that allocated d_frames
+        (the copy streams must not run ahead of it)."""
+        import torch
+
+        def task():
+            stream = self.in_streams[k % len(self.in_streams)]
+            with torch.cuda.device(self.device), torch.cuda.stream(stream):
+                stream.wait_event(after)
+                clip.upload(d_frames, i0, i1)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            return ev
+
+        return self.in_pool.submit(task)
+
+    def upload_all(self, clip, d_frames, ranges, after):
+        return [self.upload(clip, d_frames, i0, i1, after, k) for k, (i0, i1) in enumerate(ranges)]
+
+    def download(self, d_src, host_dst, after, k):
+        import torch
+
+        def task():
+            stream = self.out_streams[k % len(self.out_streams)]
+            with torch.cuda.device(self.device), torch.cuda.stream(stream):
+                stream.wait_event(after)
+                torch.from_numpy(host_dst).copy_(d_src)          # blocking on this thread, this stream
+
+        self.pending.append(self.out_pool.submit(task))
+
+    def finish(self):
+        """Wait for every queued download; re-raises the first failure."""
+        pending, self.pending = self.pending, []
+        for f in pending:
+            f.result()
+
+    def close(self):
+        self.in_pool.shutdown(wait=True)
+        self.out_pool.shutdown(wait=True)
+
+
+
 def stabilize_streamed(stab, cv2, input_path, output_path, adaptive_weights_definition, chunk_frames=16, workers=8,
                        io_threads=3):
     """Returns (cropping_ratio, distortion_score, stability_score) and writes the stabilized video -- mfs.py:102-169."""
@@ -30,7 +95,7 @@ def stabilize_streamed(stab, cv2, input_path, output_path, adaptive_weights_defi
     from . import frontend_cv2, host, ops, pipeline
     dev = stab._torch_device()
     tracker = stab._tracker()
-    io = pipeline.ChunkedTransfer(dev, io_threads, io_threads)
+    io = ChunkedTransfer(dev, io_threads, io_threads)
     pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix='mf-track')
     video = cv2.VideoCapture(input_path)
     try:
@@ -38,7 +103,7 @@ def stabilize_streamed(stab, cv2, input_path, output_path, adaptive_weights_defi
         num_frames = int(video.get(cv2.CAP_PROP_FRAME_COUNT))
         frames_per_second = video.get(cv2.CAP_PROP_FPS)
         codec = int(video.get(cv2.CAP_PROP_FOURCC))
-        ranges = pipeline.chunk_ranges(num_frames, chunk_frames)
+        ranges = chunk_ranges(num_frames, chunk_frames)
         frames, pair_futures, uploads = [], [], []
         d_frames = allocated = None
         next_chunk = 0

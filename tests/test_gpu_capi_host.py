@@ -320,3 +320,174 @@ def test_host_pipeline_leaves_the_current_device_alone(dev):
         assert torch.cuda.current_device() == before
         assert s._torch_device().index == (before if name == 'cuda' else last)
         assert len(out) == F and len(cropped) == F
+
+
+# ---- the ring of chunk buffers: device memory O(chunk), clips of any length ----
+
+def _hbm_used():
+    import torch
+    free_b, total_b = torch.cuda.mem_get_info(0)
+    return total_b - free_b
+
+
+def _device_warp_crop(d_frames, disp, stab, R, C, rect=None):
+    """The device operators on resident frames (what the host pipeline must reproduce chunk by chunk): stabilized frames, per-frame
+    crop rows, the clip rectangle and the cropped + resized frames."""
+    import torch
+    from meshflow_amd import ops
+    n, H, W, _ = d_frames.shape
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d_frames.device)
+    table = ops.cell_table(t(disp), t(stab), W, H, R, C)
+    out = ops.warp(d_frames, table)
+    crop = table.crop.cpu().numpy()
+    if rect is None:
+        rect = (int(crop[:, 0].max()), int(crop[:, 1].max()), int(crop[:, 2].min()), int(crop[:, 3].min()))
+    return out, crop, rect, ops.crop_resize(out, rect)
+
+
+def test_crop_resize_host_frames_raw_ctypes_and_errors(dev):
+    """mf_crop_resize_u8c3_host_frames: _crop_frames (mfs.py:1111-1157) by itself through the ring -- several chunks, a ring of two slots,
+    separate per-frame allocations; bad rectangles are refused before any output byte is written."""
+    import os
+    from meshflow_amd import _lib, synthetic
+    from oracle import meshflow_oracle as mo
+    F, H, W = 23, 72, 100
+    frames = synthetic.frames_numpy(F, H, W, seed=4, kind='noise')
+    ins = [f.copy() for f in frames]
+    rect = (3, 5, 90, 66)
+    want = np.stack(mo.crop_frames(list(frames), rect))
+    pin = (ctypes.c_void_p * F)(*[f.ctypes.data for f in ins])
+    old = {k: os.environ.get(k) for k in ('MF_PIPE_CHUNK', 'MF_PIPE_SLOTS')}
+    try:
+        for chunk, slots in ((None, None), (4, 2), (1, 3), (64, 8)):
+            for k, v in (('MF_PIPE_CHUNK', chunk), ('MF_PIPE_SLOTS', slots)):
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = str(v)
+            outs = [np.full((H, W, 3), 7, np.uint8) for _ in range(F)]
+            pout = (ctypes.c_void_p * F)(*[f.ctypes.data for f in outs])
+            ms = ctypes.c_float(-1)
+            _lib.check(_lib.lib.mf_crop_resize_u8c3_host_frames(pin, pout, F, W, H, *rect, ctypes.byref(ms)))
+            np.testing.assert_array_equal(np.stack(outs), want)
+            assert ms.value > 0
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    outs = [np.full((H, W, 3), 7, np.uint8) for _ in range(F)]
+    pout = (ctypes.c_void_p * F)(*[f.ctypes.data for f in outs])
+    for bad in ((50, 10, 40, 60), (0, 0, W, H - 1), (-1, 0, 10, 10), (0, 30, 10, 20)):
+        assert _lib.lib.mf_crop_resize_u8c3_host_frames(pin, pout, F, W, H, *bad, None) == _lib.MF_ERR_INVALID_ARG
+    assert all(int(o.min()) == 7 and int(o.max()) == 7 for o in outs)                   # untouched
+    assert _lib.lib.mf_crop_resize_u8c3_host_frames(pin, pin, F, W, H, *rect, None) == _lib.MF_ERR_INVALID_ARG       # in place
+    assert _lib.lib.mf_crop_resize_u8c3_host_frames(None, pout, F, W, H, *rect, None) == _lib.MF_ERR_INVALID_ARG
+
+
+def test_2000_frame_1080p_clip_in_two_gigabytes_of_device_memory(dev):
+    """A 2,000-frame 1080p clip (12.4 GB each way) host-to-host through `stabilize_clip(crop=True)`: the device-memory high-water mark
+    stays below 2 GB (the ring: 8 slots x 2 directions x 16 frames; round 4 held 2 x 12.4 GB), the rectangle equals the resident
+    pipeline's, sampled chunks equal the device operators on the same frames byte for byte, and an integer global shift gives the
+    analytic answer on every frame."""
+    import torch
+    from meshflow_amd import _lib, synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    F, H, W, R, C = 2000, 1080, 1920, 16, 16
+    base = synthetic.frames_torch(40, H, W, dev, seed=2, kind='pattern').cpu().numpy()
+    frames = [base[i % 40] for i in range(F)]                     # 40 distinct frames, cycled (input frames may repeat; outputs may not)
+    disp, hom = synthetic.motion(F, R, C, seed=2)
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, device='cuda:0')
+    _lib.lib.mf_host_cache_release()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    before = _hbm_used()
+    peak = [before]
+    stop = [False]
+
+    def watch():
+        import time
+        while not stop[0]:
+            peak[0] = max(peak[0], _hbm_used())
+            time.sleep(0.005)
+    import threading
+    th = threading.Thread(target=watch)
+    th.start()
+    try:
+        out, bounds, stab, score, cropped = s.stabilize_clip(frames, disp, hom, crop=True, keep_uncropped=True)
+    finally:
+        stop[0] = True
+        th.join()
+    grown = peak[0] - before
+    print(f'2000-frame clip: device memory high-water mark +{grown / 2**30:.2f} GiB')
+    assert grown <= 2 * 2**30, grown
+    assert len(out) == F and len(cropped) == F
+    # sampled chunks against the device operators on the same frames
+    rect = tuple(int(v) for v in bounds)
+    for i0 in (0, 16 * 61 + 3, F - 16):
+        d_in = torch.from_numpy(np.stack(frames[i0:i0 + 16])).to(dev)
+        d_out, crop_rows, _, d_cropped = _device_warp_crop(d_in, disp[i0:i0 + 16], stab[i0:i0 + 16], R, C, rect)
+        assert np.array_equal(np.stack(out[i0:i0 + 16]), d_out.cpu().numpy())
+        assert np.array_equal(np.stack(cropped[i0:i0 + 16]), d_cropped.cpu().numpy())
+    # the rectangle: every frame's rows through the crop scan of the whole clip's table, in pieces
+    from meshflow_amd import ops
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lo = [0, 0, W - 1, H - 1]
+    for i0 in range(0, F, 250):
+        table = ops.cell_table(t(disp[i0:i0 + 250]), t(stab[i0:i0 + 250]), W, H, R, C)
+        rows = ops.crop_scan(table).cpu().numpy()
+        lo = [max(lo[0], rows[:, 0].max()), max(lo[1], rows[:, 1].max()), min(lo[2], rows[:, 2].min()), min(lo[3], rows[:, 3].min())]
+    assert rect == tuple(int(v) for v in lo)
+    del out, cropped
+
+
+def test_full_config4_clip_through_one_gpu(dev):
+    """BASELINE config 4 WHOLE -- 1,200 frames of 3840 x 2160 (29.9 GB each way) -- host to host through ONE GPU's ring (4-frame chunks,
+    1.6 GB of device memory).  Motion = an integer global shift per frame, so every frame has the analytic answer: interior pixels
+    moved by exactly that shift, the uncovered band in the border colour, crop rows (dx, 0, W-1, H-1+dy)-like values; sampled frames
+    are also held against the device operators."""
+    import time
+    import psutil
+    import torch
+    from meshflow_amd import _lib, synthetic
+    F, H, W, R, C = 1200, 2160, 3840, 16, 16
+    if psutil.virtual_memory().available < 80 * 2**30:
+        pytest.skip('needs ~65 GB of host memory for the 1,200 output frames and the input')
+    base = synthetic.frames_torch(24, H, W, dev, seed=7, kind='pattern').cpu().numpy()          # 24 distinct input frames, cycled
+    frames = [base[i % 24] for i in range(F)]
+    disp, hom = synthetic.motion(F, R, C, seed=4)
+    unstab = np.ascontiguousarray(disp)
+    shift = np.zeros((F, 2))
+    shift[:, 0] = (np.arange(F) % 7) - 3                                        # dx in -3..3
+    shift[:, 1] = (np.arange(F) % 5) - 2                                        # dy in -2..2
+    stab = np.ascontiguousarray(unstab + shift[:, None, None, :])               # content moves by (dx, dy)
+    out = np.empty((F, H, W, 3), np.uint8)
+    fb = H * W * 3
+    pin = (ctypes.c_void_p * F)(*[f.ctypes.data for f in frames])
+    pout = (ctypes.c_void_p * F)(*[out.ctypes.data + i * fb for i in range(F)])
+    crop = np.zeros((F, 4), np.int32)
+    border = (ctypes.c_uint8 * 3)(0, 0, 255)
+    _lib.lib.mf_host_cache_release()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    before = _hbm_used()
+    t0 = time.perf_counter()
+    _lib.check(_lib.lib.mf_warp_u8c3_host_frames(pin, pout, _p(unstab), _p(stab), F, W, H, R, C, border, _p(crop), None))
+    dt = time.perf_counter() - t0
+    grown = _hbm_used() - before
+    print(f'full config 4 through one GPU: {dt:.2f} s = {F / dt:.0f} frames/s, {2 * F * fb / dt / 1e9:.1f} GB/s both ways, ring {grown / 2**30:.2f} GiB')
+    assert grown <= 2 * 2**30
+    for f in list(range(0, F, 97)) + [F - 1]:
+        dx, dy = int(shift[f, 0]), int(shift[f, 1])
+        src = frames[f]
+        got = out[f]
+        ys, xs = slice(max(dy, 0) + 2, H + min(dy, 0) - 2), slice(max(dx, 0) + 2, W + min(dx, 0) - 2)
+        assert np.array_equal(got[ys, xs], src[ys.start - dy:ys.stop - dy, xs.start - dx:xs.stop - dx]), f
+        if dx > 1:
+            assert (got[:, :dx - 1] == np.array([0, 0, 255], np.uint8)).all(), f                 # the uncovered band, in the border colour
+    for f in (0, 601, F - 1):                                                   # and byte for byte against the device operators
+        d_out, crop_rows, _, _ = _device_warp_crop(torch.from_numpy(frames[f][None]).to(dev), unstab[f:f + 1], stab[f:f + 1], R, C, (0, 0, W - 1, H - 1))
+        assert np.array_equal(out[f], d_out[0].cpu().numpy())
+        assert np.array_equal(crop[f], crop_rows[0])
+    del out

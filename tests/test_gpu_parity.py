@@ -449,11 +449,16 @@ def test_stabilizer_class_end_to_end(dev):
     np.testing.assert_array_equal(np.stack(res[4]), np.stack(mo.crop_frames(list(want), bounds)))
 
 
-@pytest.mark.parametrize('chunk_frames,io_threads', [(1, 1), (7, 2), (5, 4), (64, 3)])
-def test_chunked_staging_gives_the_same_clip(dev, chunk_frames, io_threads):
-    """pipeline.py: any chunking / thread count, list or array input, every output identical (ragged last chunk,
-    more threads than chunks, one frame per chunk)."""
+@pytest.mark.parametrize('chunk_frames,io_threads,slots', [(1, 1, 2), (1, 4, 3), (7, 2, 2), (5, 4, 8), (2, 3, 4), (64, 3, 8)])
+def test_chunked_staging_gives_the_same_clip(dev, monkeypatch, chunk_frames, io_threads, slots):
+    """The host pipeline (csrc/hostpipe.hip): any chunking, thread count and ring depth (MF_PIPE_CHUNK / _UP / _DOWN / _SLOTS, read at
+    every call), list or array input, every output identical -- ragged last chunk, more threads than chunks, one frame per chunk, a
+    ring of two slots that every chunk after the second has to wait for."""
     from meshflow_amd import synthetic
+    monkeypatch.setenv('MF_PIPE_CHUNK', str(chunk_frames))
+    monkeypatch.setenv('MF_PIPE_UP', str(io_threads))
+    monkeypatch.setenv('MF_PIPE_DOWN', str(io_threads))
+    monkeypatch.setenv('MF_PIPE_SLOTS', str(slots))
     from meshflow_amd.stabilizer import MeshFlowStabilizer
     from oracle import clib, meshflow_oracle as mo
     F, H, W, R, C = 23, 72, 100, 3, 5
@@ -461,13 +466,18 @@ def test_chunked_staging_gives_the_same_clip(dev, chunk_frames, io_threads):
     s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=4, optimization_num_iterations=15)
     separate = [f.copy() for f in frames]
     for inp in (separate, frames):
-        got = s.stabilize_clip(inp, disp, hom, crop=True, chunk_frames=chunk_frames, io_threads=io_threads)
+        got = s.stabilize_clip(inp, disp, hom, crop=True)
         out, bounds, stab, score, cropped = got
         want, want_crop, _ = clib.warp_clip(frames, R, C, disp, stab)
         np.testing.assert_array_equal(np.stack(out), want)
         assert tuple(int(v) for v in bounds) == (want_crop[:, 0].max(), want_crop[:, 1].max(),
                                                  want_crop[:, 2].min(), want_crop[:, 3].min())
         np.testing.assert_array_equal(np.stack(cropped), np.stack(mo.crop_frames(list(want), bounds)))
+        # the two methods of the reference's call sequence by themselves (mfs.py:154, 159), through the same ring
+        out2, bounds2 = s._get_stabilized_frames_and_crop_boundaries(F, inp, disp, stab)
+        np.testing.assert_array_equal(np.stack(out2), want)
+        assert tuple(int(v) for v in bounds2) == tuple(int(v) for v in bounds)
+        np.testing.assert_array_equal(np.stack(s._crop_frames(out2, bounds2)), np.stack(cropped))
 
 
 def test_chunked_staging_reports_a_bad_frame(dev):
@@ -479,8 +489,8 @@ def test_chunked_staging_reports_a_bad_frame(dev):
     bad[6] = np.zeros((H, W + 1, 3), np.uint8)
     s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=2, optimization_num_iterations=5)
     with pytest.raises(ValueError, match='shape'):
-        s.stabilize_clip(bad, disp, hom, chunk_frames=2, io_threads=2)
-    out, *_ = s.stabilize_clip([f.copy() for f in frames], disp, hom, chunk_frames=2, io_threads=2)    # still usable
+        s.stabilize_clip(bad, disp, hom)
+    out, *_ = s.stabilize_clip([f.copy() for f in frames], disp, hom)    # still usable
     assert len(out) == F
 
 
@@ -577,7 +587,6 @@ def test_methods_borrowed_by_a_foreign_class(dev):
         _torch_device = amd.MeshFlowStabilizer._torch_device
         _jacobi_coefficients_device = amd.MeshFlowStabilizer._jacobi_coefficients_device
         _stabilized_vertex_displacements_device = amd.MeshFlowStabilizer._stabilized_vertex_displacements_device
-        _start_upload = amd.MeshFlowStabilizer._start_upload
         _crop_frames = amd.MeshFlowStabilizer._crop_frames
         device = None
 

@@ -133,7 +133,7 @@ def test_streamed_stabilize_overlaps_io_with_the_stages_around_it(cv2_stub, monk
     have started before the last frame is decoded; with downloads that finish 250 ms apart, the encoder must have been handed
     frames before the last chunk is back; and the frames reach the encoder in order."""
     import time
-    from meshflow_amd import pipeline
+    from meshflow_amd import streaming as pipeline
     from meshflow_amd.stabilizer import MeshFlowStabilizer
     F = 40
     frames = _make_video(cv2_stub, 'in.m4v', F=F)
