@@ -205,6 +205,7 @@ def end_to_end(stab, d_frames, disp, hom, F, runs=5):
         t = host_clip(stab, frames, disp, hom, runs, **kw)
         mean, best = float(np.mean(t)), float(np.min(t))
         r = {'value': F / mean, 'unit': 'frames/s', 'ms_per_clip': mean * 1e3, 'min_ms_per_clip': best * 1e3, 'best_value': F / best, 'runs': runs,
+             'steps': runs, 'warmup': 1, 'ms_per_step': mean * 1e3, 'elapsed_s': float(np.sum(t)),
              'roofline': pcie_roofline(mean)}
         if key:
             r['what'] = ('stabilize_clip(crop=True, keep_uncropped=False): the same + clip-level crop rectangle + _crop_frames (mfs.py:159) on the '
@@ -373,7 +374,178 @@ def launch_children(args):
     return rc
 
 
-def main():
+class KernelPath:
+    """The timed step: K passes of the PRODUCT's device-resident pipeline through its PUBLIC method, `MeshFlowStabilizer.stabilize_resident`
+    (no private stages, default degenerate-mesh check: deferred, `finish()` once inside the timed region) -- host coefficient set-up, Jacobi
+    sweep on the stabilizer's prep stream, cell table + plan, the warp alone, the clip rectangle folded together by the kernel (-> 16-byte
+    all-reduce at N > 1), inputs resident in HBM, clips issued back to back.  HIP events bracket the warp kernel on the caller's stream and
+    the sweep stage on the prep stream (the streams they are launched on).  `serial`: the same kernels in order on ONE stream (private
+    stages handed to dist.stabilize_sharded: the figure comparable with rounds 1-2)."""
+
+    def __init__(self, stab, d_frames, d_disp, hom, F, frame_range, W, H, R, C, device, collective=False, no_events=False):
+        import torch
+        self.stab, self.d_frames, self.d_disp, self.hom, self.F, self.range = stab, d_frames, d_disp, hom, F, frame_range
+        self.W, self.H, self.R, self.C, self.device, self.collective, self.no_events = W, H, R, C, device, collective, no_events
+        self.d_out = torch.empty_like(d_frames)
+        self.inputs_ready = torch.cuda.Event()
+        self.inputs_ready.record(torch.cuda.current_stream(device))
+        self.serial_table = {}
+
+    def step(self, events=None):
+        """One clip through the public method."""
+        we, je = events if events else (None, None)
+        _, bounds, d_stab = self.stab.stabilize_resident(self.d_frames, self.d_disp, self.hom, out=self.d_out, frame_range=self.range,
+                                                         inputs_ready=self.inputs_ready, collective=self.collective,
+                                                         warp_events=we, jacobi_events=je)
+        return d_stab, bounds
+
+    def serial_step(self, events=None):
+        from meshflow_amd import dist as mfdist, ops
+        stab, W, H, R, C = self.stab, self.W, self.H, self.R, self.C
+        we, je = events if events else (None, None)
+
+        def jacobi_fn():
+            if je:
+                je[0].record()
+            d_stab = stab._stabilized_vertex_displacements_device(self.d_disp, W, H, 0, self.hom)
+            if je:
+                je[1].record()
+            return d_stab
+
+        def warp_fn(lo_, hi_, d_stab):
+            if 't' not in self.serial_table:
+                self.serial_table['t'] = ops.CellTable(hi_ - lo_, W, H, R, C, self.device)
+            table = self.serial_table['t']
+            ops.cell_table(self.d_disp[lo_:hi_], d_stab[lo_:hi_], W, H, R, C, table=table, reset_status=False)
+            if we:
+                we[0].record()
+            ops.warp(self.d_frames, table, stab.color_outside_image_area_bgr, out=self.d_out)
+            if we:
+                we[1].record()
+            return self.d_out, table
+
+        _, bounds, d_stab, _ = mfdist.stabilize_sharded(self.F, jacobi_fn, warp_fn, lambda table: ops.crop_reduce(table.crop, W, H),
+                                                        frame_range=self.range, collective=self.collective)
+        return d_stab, bounds
+
+    def finish(self, serial):
+        if serial:
+            if 't' in self.serial_table:
+                self.serial_table['t'].check()
+        else:
+            self.stab.finish()                # the deferred degenerate-mesh verdicts of the last clips: inside the timed region
+
+    def measure(self, steps, warmup, serial, barrier, max_over_ranks):
+        import torch
+        step = self.serial_step if serial else self.step
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        jev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        # Clock spin-up, then the W warm-up steps, then the K timed ones back to back.  After an idle period (set-up: milliseconds) this
+        # GPU runs the launches of the following ~2-15 ms 5-25 % slower than in steady state (tools/resize_probe.py shows it launch by
+        # launch; MF_BENCH_PER_STEP=1 shows it here) -- a power-management transient, not a property of the kernels.  ~25 ms of the same
+        # step in front of the warm-up take it out of the timed region; the timed region is still exactly K steps.
+        n = self.range[1] - self.range[0]
+        spinup_steps = min(50, int(np.ceil(25e-3 / max(2.0 * n * self.H * self.W * 3 / 3.2e12, 1e-4))))
+        for _ in range(spinup_steps + warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            d_stab, bounds = step(None if self.no_events else (ev[i], jev[i]))
+        self.finish(serial)                    # degenerate-mesh check of all K steps, inside the timing
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        return {'elapsed': elapsed, 'spinup_steps': spinup_steps, 'bounds': bounds.clone(), 'd_stab': d_stab, 'ev': ev, 'jev': jev}
+
+    def latency(self):
+        import torch
+        lat = []
+        for _ in range(7):
+            self.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            self.step()
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        self.stab.finish()
+        return {'median': float(np.median(lat)), 'min': float(np.min(lat)),
+                'note': 'one clip through the product pipeline between two synchronisations, right after another clip '
+                        '(clocks up): host issue + Jacobi sweep + first table + warp chunks; median / min of 7'}
+
+    def serial(self, steps, warmup):
+        import torch
+        for _ in range(warmup):
+            self.serial_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            self.serial_step()
+        self.finish(True)
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t1) / steps * 1e3
+        return {'ms_per_step': serial_ms, 'value': self.F / (serial_ms * 1e-3), 'unit': 'frames/s',
+                'note': 'the same K steps with every kernel of a clip in order on ONE stream (Jacobi -> cell table + plan -> warp + scan '
+                        '-> reduce), no overlap inside or across clips: the figure comparable with rounds 1-2'}
+
+    def jacobi_kernel_ms(self, omega, iters, reps=5):
+        """The sweep kernel alone (the per-step figure includes the host-side coefficient set-up), outside any timed region."""
+        import torch
+        from meshflow_amd import ops
+        taps_d, lam_d, inv_on_d = self.stab._jacobi_coefficients_device(self.F, self.W, self.H, 0, self.hom, self.device)
+        b2d = self.d_disp.reshape(self.F, -1)
+        x2d = torch.empty_like(b2d)
+        ops.jacobi(b2d, taps_d, lam_d, inv_on_d, omega, iters, out=x2d)
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record()
+        for _ in range(reps):
+            ops.jacobi(b2d, taps_d, lam_d, inv_on_d, omega, iters, out=x2d)
+        k1.record()
+        torch.cuda.synchronize()
+        ms = k0.elapsed_time(k1) / reps
+        flops = float(iters) * self.F * b2d.shape[1] * (2 * (2 * omega + 1) + 3)
+        return ms, flops, int(b2d.shape[1])
+
+
+def other_workload(name, device, steps, pcie_peak):
+    """A second configuration in the SAME run (N = 1): its kernel path through the public method -- warp launch time and roofline
+    fraction, step time, Jacobi kernel -- and its host-to-host clip with _crop_frames against the PCIe rate measured in this run.
+    Bounded to a few seconds; `--no-workloads` skips it."""
+    import torch
+    from meshflow_amd import synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    H, W, F, R, C, omega, iters = WORKLOADS[name]
+    stab = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=omega, optimization_num_iterations=iters, device=str(device))
+    disp, hom = synthetic.motion(F, R, C, seed=0)
+    d_disp = torch.from_numpy(disp).to(device)
+    d_frames = synthetic.frames_torch(F, H, W, device, seed=0, kind='pattern')
+    kp = KernelPath(stab, d_frames, d_disp, hom, F, (0, F), W, H, R, C, device)
+    sync = torch.cuda.synchronize
+    m = kp.measure(steps, 3, False, sync, lambda t: t)
+    warp_ms = float(np.mean([a.elapsed_time(b) for a, b in m['ev']]))
+    jac_ms, jac_flops, series = kp.jacobi_kernel_ms(omega, iters)
+    algo = 2.0 * H * W * 3 * F
+    res = {'config': f'{W}x{H}, {F} frames, {R}x{C} mesh, omega={omega}, {iters} Jacobi sweeps', 'steps': steps,
+           'ms_per_step': m['elapsed'] / steps * 1e3, 'value': F * steps / m['elapsed'], 'unit': 'frames/s',
+           'warp': {'avg_launch_ms': warp_ms, 'algorithmic_bytes_per_launch': algo, 'achieved': algo / (warp_ms * 1e-3) / 1e9, 'unit': 'GB/s',
+                    'frac': algo / (warp_ms * 1e-3) / HBM_PEAK_BYTES_PER_S},
+           'jacobi': {'kernel_ms': jac_ms, 'achieved': jac_flops / (jac_ms * 1e-3) / 1e12, 'unit': 'TFLOP/s', 'frac': jac_flops / (jac_ms * 1e-3) / 78.6e12,
+                      'series': series},
+           'crop_bounds': [int(v) for v in m['bounds'].tolist()]}
+    frames = [f.copy() for f in d_frames.cpu().numpy()]
+    del kp, d_frames
+    kw = {'crop': True, 'keep_uncropped': False}
+    host_clip(stab, frames, disp, hom, 1, **kw)
+    t = host_clip(stab, frames, disp, hom, 3, **kw)
+    mean = float(np.mean(t))
+    ach = F * H * W * 3 / mean / 1e9
+    res['end_to_end'] = {'value': F / mean, 'unit': 'frames/s', 'ms_per_clip': mean * 1e3, 'min_ms_per_clip': float(np.min(t)) * 1e3, 'runs': 3,
+                         'what': 'stabilize_clip(crop=True, keep_uncropped=False), pageable NumPy frame list in, list out',
+                         'roofline': {'bound': 'pcie', 'achieved': ach, 'peak_measured': pcie_peak, 'unit': 'GB/s per direction, both directions busy',
+                                      'frac': (ach / pcie_peak) if pcie_peak else None}}
+    return res
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -392,6 +564,9 @@ def main():
                          '"clips" = N independent clips, one per GPU, no collective (BASELINE config 5); '
                          '"e2e" = host frames in -> host frames out, PCIe both ways (N independent clips when N > 1)')
     ap.add_argument('--no-e2e', action='store_true', help='skip the host-buffers-in / host-buffers-out side measurement (N = 1 only)')
+    ap.add_argument('--no-workloads', action='store_true', help='skip the other configurations measured in the same run (N = 1, default workload only: '
+                    'cfg3 and cfg4shard, ~4 s each, ~4 GB of HBM and of host memory)')
+    ap.add_argument('--workload-steps', type=int, default=10, help='timed steps of each of those other configurations')
     ap.add_argument('--pipeline', default='product', choices=['product', 'serial'],
                     help='"product" = MeshFlowStabilizer.stabilize_resident\'s own overlap (sweep, tables, crop scan and rectangle on its prep '
                          'stream beside the warp chunks); "serial" = every kernel of a clip in order on one stream')
@@ -403,7 +578,11 @@ def main():
     ap.add_argument('--as-rank-of', type=int, default=0, metavar='N',
                     help='single process only: do the work rank 0 of an N-GPU "shard" run does (clip of N x frames, own '
                          'frame range, replicated Jacobi) without the collective -- predicts weak scaling on one GPU')
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = build_parser().parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(launch_children(args))
@@ -486,10 +665,6 @@ def main():
             dist.destroy_process_group()
         return
 
-    d_out = torch.empty_like(d_frames)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    jev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    now = {'i': None}                      # index of the timed step being issued (None during warm-up)
     no_events = bool(os.environ.get('MF_BENCH_NO_EVENTS'))     # tuning aid: what the HIP events around the kernels cost the step
     main_stream = torch.cuda.current_stream(device)
     if os.environ.get('MF_MAIN_PRIORITY'):                      # tuning aid: the warp's stream at another priority than the prep stream
@@ -501,150 +676,26 @@ def main():
     if args.rectangle:
         stab.resident_rectangle = args.rectangle   # 'early': the rectangle from the table on the prep stream (the all-reduce of a sharded clip
                                                    # then runs beside the warp); the default takes it from the warp's own scan, behind the warp
-    exchange_on_prep = stab.resident_chunks > 0 or stab.resident_rectangle == 'early'
-
-    # The timed step is the PRODUCT's device-resident pipeline (MeshFlowStabilizer.stabilize_resident, here as its two stages handed to
-    # dist.stabilize_sharded).  Default arrangement (resident_chunks = 0): cell table + plan, then the warp ALONE, then the rectangle, in
-    # order on the main stream; the Jacobi sweep on the stabilizer's prep stream, gated so that the NEXT clip's sweep runs beside THIS
-    # clip's cell table + plan -- nothing runs beside the warp kernel (measured: whatever does costs the warp more than it takes alone).
-    # --chunks k >= 1: the clip in k frame ranges, tables + crop scan + rectangle on the prep stream beside the warp.  HIP events
-    # bracket the sweep on the prep stream and the clip's warp kernel(s) on the main stream (the stream each is launched on).
-    # --pipeline serial: the same kernels in order on ONE stream, no overlap of any kind (the figure comparable with rounds 1-2);
-    # reported beside the timed figure as `serial` in every default run.
-    inputs_ready = torch.cuda.Event()
-    inputs_ready.record(main_stream)
-    serial_table = {}
-
-    def make_fns(serial):
-        def jacobi_fn():
-            i = now['i']
-            timed = i is not None and not no_events
-            if serial:
-                if timed:
-                    jev[i][0].record()
-                d_stab = stab._stabilized_vertex_displacements_device(d_disp, W, H, 0, hom)
-                if timed:
-                    jev[i][1].record()
-                return d_stab
-            prep = stab._resident_state(device)['prep']
-            if timed:
-                jev[i][0].record(prep)
-            d_stab = stab._resident_jacobi(d_disp, W, H, 0, hom, inputs_ready=inputs_ready)
-            if timed:
-                jev[i][1].record(prep)
-            return d_stab
-
-        def warp_fn(lo_, hi_, d_stab):
-            i = now['i']
-            timed = i is not None and not no_events
-            if serial:
-                if 't' not in serial_table:
-                    serial_table['t'] = ops.CellTable(hi_ - lo_, W, H, R, C, device)
-                table = serial_table['t']
-                ops.cell_table(d_disp[lo_:hi_], d_stab[lo_:hi_], W, H, R, C, table=table, reset_status=False)
-                if timed:
-                    ev[i][0].record()
-                ops.warp(d_frames, table, stab.color_outside_image_area_bgr, out=d_out)
-                if timed:
-                    ev[i][1].record()
-                return d_out, table
-            _, table = stab._resident_warp(d_frames, d_disp[lo_:hi_], d_stab[lo_:hi_], out=d_out, warp_events=ev[i] if timed else None)
-            return d_out, table
-
-        def crop_reduce_fn(table):
-            if serial:
-                return ops.crop_reduce(table.crop, W, H)
-            return table.bounds                # already reduced on the prep stream (mf_warp_clip_u8c3), final before the warp ends
-        return jacobi_fn, warp_fn, crop_reduce_fn
-
-    def exchange_ctx():
-        # the 16-byte all-reduce of a sharded clip goes to the prep stream too: beside the warp, off the critical path
-        return torch.cuda.stream(stab._resident_state(device)['prep'])
-
-    def make_step(serial):
-        fns = make_fns(serial)
-
-        def step(i=None):
-            now['i'] = i
-            _, bounds, d_stab, _ = mfdist.stabilize_sharded(F, *fns, gather=False, shard=shard, collective=not clips_mode,
-                                                            exchange_ctx=exchange_ctx if (exchange_on_prep and not serial) else None)
-            return d_stab, bounds
-        return step
-
-    def check_tables():
-        for pair in stab._resident_state(device)['tables'].values():
-            for slot in pair:
-                slot['table'].check()
-        if 't' in serial_table:
-            serial_table['t'].check()
-
     serial_mode = args.pipeline == 'serial'
-    step = make_step(serial_mode)
-    # Clock spin-up, then the W warm-up steps, then the K timed ones back to back.  After an idle period (set-up: milliseconds) this
-    # GPU runs the launches of the following ~2-15 ms 5-25 % slower than in steady state (tools/resize_probe.py shows it launch by
-    # launch; MF_BENCH_PER_STEP=1 shows it here) -- a power-management transient, not a property of the kernels.  ~25 ms of the same
-    # step in front of the warm-up take it out of the timed region; the timed region is still exactly K steps.
-    spinup_steps = min(50, int(np.ceil(25e-3 / max(2.0 * (hi - lo) * H * W * 3 / 3.2e12, 1e-4))))
-    for _ in range(spinup_steps):
-        step()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        d_stab, bounds = step(i)
-    check_tables()                         # degenerate-mesh check of all K steps: 4-byte D2H per table, inside the timing
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    bounds = bounds.clone()
+    kp = KernelPath(stab, d_frames, d_disp, hom, F, (lo, hi), W, H, R, C, device, collective=(world > 1 and not clips_mode), no_events=no_events)
+    m = kp.measure(args.steps, args.warmup, serial_mode, barrier, max_over_ranks)
+    elapsed, spinup_steps, bounds, d_out = m['elapsed'], m['spinup_steps'], m['bounds'], kp.d_out
+    ev, jev = m['ev'], m['jev']
 
     # Beside the timed figure, outside the timed region (N = 1): the latency of ONE clip through the same pipeline from an idle GPU
     # (synchronise, issue one clip, synchronise: the sweep and the first frame range's table cannot hide behind anything), and the
     # K steps again with everything on one stream.
     extra = {}
     if world == 1 and not serial_mode and not os.environ.get('MF_BENCH_NO_EXTRAS'):
-        lat = []
-        for _ in range(7):
-            step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            step()
-            torch.cuda.synchronize()
-            lat.append((time.perf_counter() - t1) * 1e3)
-        extra['latency_ms_single_clip'] = {'median': float(np.median(lat)), 'min': float(np.min(lat)),
-                                           'note': 'one clip through the product pipeline between two synchronisations, right after another clip '
-                                                   '(clocks up): host issue + Jacobi sweep + first table + warp chunks; median / min of 7'}
-        sstep = make_step(True)
-        for _ in range(max(args.warmup, 3)):
-            sstep()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            sstep()
-        check_tables()
-        torch.cuda.synchronize()
-        serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        extra['serial'] = {'ms_per_step': serial_ms, 'value': F / (serial_ms * 1e-3), 'unit': 'frames/s',
-                           'note': 'the same K steps with every kernel of a clip in order on ONE stream (Jacobi -> cell table + plan -> warp + scan '
-                                   '-> reduce), no overlap inside or across clips: the figure comparable with rounds 1-2'}
+        extra['latency_ms_single_clip'] = kp.latency()
+        extra['serial'] = kp.serial(args.steps, max(args.warmup, 3))
 
     warp_ms = float('nan') if no_events else float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if os.environ.get('MF_BENCH_PER_STEP') and rank == 0 and not no_events:          # tuning aid: the launches one by one (clock transients)
         print('warp ms per step:', [round(a.elapsed_time(b), 3) for a, b in ev], file=sys.stderr)
     jac_ms = float('nan') if no_events else float(np.mean([a.elapsed_time(b) for a, b in jev]))
     # Jacobi kernel alone (the per-step figure above includes the host-side coefficient set-up), outside the timed region
-    taps_d, lam_d, inv_on_d = stab._jacobi_coefficients_device(F, W, H, 0, hom, device)
-    b2d = d_disp.reshape(F, -1)
-    x2d = torch.empty_like(b2d)
-    ops.jacobi(b2d, taps_d, lam_d, inv_on_d, omega, iters, out=x2d)
-    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    k0.record()
-    for _ in range(5):
-        ops.jacobi(b2d, taps_d, lam_d, inv_on_d, omega, iters, out=x2d)
-    k1.record()
-    torch.cuda.synchronize()
-    jac_kernel_ms = k0.elapsed_time(k1) / 5
-    jac_flops = float(iters) * F * b2d.shape[1] * (2 * (2 * omega + 1) + 3)
+    jac_kernel_ms, jac_flops, jac_series = kp.jacobi_kernel_ms(omega, iters)
     # Next row on the path, measured outside the timed region: crop to the clip-level bounds and
     # resize back, device-resident (mfs.py:1111-1157).
     resize_ms = None
@@ -775,7 +826,7 @@ def main():
                          'note': 'bound by vector and scalar instruction issue (float64 coordinates, integer blend, one wavefront per 32x8 footprint), not by HBM: DESIGN.md 4.3'},
             'jacobi': {'avg_ms_in_pipeline': jac_ms, 'on_prep_stream': not serial_mode, 'kernel_ms': jac_kernel_ms,
                        'note': 'avg_ms_in_pipeline: HIP events around the stage (coefficient upload + sweep) on the stream it is issued on -- on the prep '
-                               'stream it shares the chip with the previous clip\'s warp, so this is NOT the kernel\'s own time; kernel_ms: the kernel alone, measured after the timed region', 'series': int(d_disp[0].numel()), 'frames': F,
+                               'stream it shares the chip with the previous clip\'s warp, so this is NOT the kernel\'s own time; kernel_ms: the kernel alone, measured after the timed region', 'series': jac_series, 'frames': F,
                        'bound': 'fp64 vector ALU + LDS (the state never leaves the chip)', 'achieved': jac_flops / (jac_kernel_ms * 1e-3) / 1e12,
                        'peak': 78.6, 'unit': 'TFLOP/s', 'frac': jac_flops / (jac_kernel_ms * 1e-3) / 78.6e12},
             'crop_bounds': [int(v) for v in bounds.tolist()],
@@ -783,6 +834,13 @@ def main():
             'cfg1': cfg1_status(),
         }
         result.update(extra)
+        # the same figures under one key (the bench contract of this tier keeps the HBM-resident rate in `value`: "inputs already resident in
+        # HBM when the timed region starts ... the PCIe-inclusive rate is never `value`"; BASELINE.json's host-to-host figure is `end_to_end`,
+        # a timed region of its own with its own `steps` / `ms_per_step` / `elapsed_s`)
+        result['kernel_path'] = {'value': result['value'], 'unit': 'frames/s', 'ms_per_step': result['ms_per_step'], 'steps': args.steps,
+                                 'through': 'MeshFlowStabilizer.stabilize_resident (public method, deferred degenerate-mesh check, finish() inside the timed region)'
+                                 if not serial_mode else 'private stages in order on one stream',
+                                 'serial': extra.get('serial'), 'latency_ms_single_clip': extra.get('latency_ms_single_clip')}
         if resize_ms is not None:
             result['next_rows'] = {'crop_resize': {'kernel': 'resize_kernel', 'avg_launch_ms': resize_ms, 'bound': 'hbm',
                                                    'achieved': algo_bytes / (resize_ms * 1e-3) / 1e9, 'unit': 'GB/s',
@@ -810,6 +868,18 @@ def main():
                 result['end_to_end'] = end_to_end(stab, d_frames, disp, hom, F)
             except Exception as e:                      # (host memory): never let the side measurement take the line down
                 result['end_to_end'] = {'error': f'{type(e).__name__}: {e}'}
+        if world == 1 and args.workload == 'cfg2' and not sliced and not args.no_workloads and args.as_rank_of <= 1 and not serial_mode:
+            # the other single-GPU configurations in the same run, so that whoever runs this line observes them too
+            del kp, d_out, d_frames
+            torch.cuda.empty_cache()
+            pcie_peak = (result.get('end_to_end') or {}).get('pcie_probe', {}).get('both_GBps_per_direction')
+            result['workloads'] = {}
+            for name in ('cfg3', 'cfg4shard'):
+                try:
+                    result['workloads'][name] = other_workload(name, device, args.workload_steps, pcie_peak)
+                except Exception as e:
+                    result['workloads'][name] = {'error': f'{type(e).__name__}: {e}'}
+                torch.cuda.empty_cache()
         if world == 1 and args.cpu_frames > 0:
             try:
                 result['cpu_baseline'], stab_cpu = cpu_baseline(H, W, F, R, C, omega, iters, disp, hom, args.cpu_frames)

@@ -112,6 +112,17 @@ int mf_warp_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, i
  * chunk by chunk.  Running mf_warp_u8c3 on the same d_crop afterwards changes nothing (max/min of equal values). */
 int mf_crop_scan_f64(const void* d_table, int n, int W, int H, int R, int C, int32_t* d_crop, void* stream);
 
+/* ---- the same three calls with the clip-level rectangle in the CALLER's memory ----
+ * mf_cell_table_f64 / mf_warp_u8c3 / mf_crop_scan_f64 with d_bounds[4] int32 {max left, max top, min right, min bottom}
+ * (mfs.py:1103-1106) in place of the four words inside the table blob (mf_cell_table_bounds_offset): the cell table sets the defaults
+ * {0, 0, W-1, H-1} there, the warp / the scan fold their frames' values into it.  A pipeline that reuses one table for clip after clip
+ * gives every clip its own 16 bytes: a rectangle handed to a consumer is never rewritten by a later clip. */
+int mf_cell_table_bounds_f64(const double* d_unstab, const double* d_stab, int n, int W, int H, int R, int C,
+                             void* d_table, int32_t* d_crop, int32_t* d_status, int32_t* d_bounds, void* stream);
+int mf_warp_bounds_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, int n, int W, int H,
+                        int R, int C, const uint8_t border_bgr[3], int32_t* d_crop, int32_t* d_bounds, void* stream);
+int mf_crop_scan_bounds_f64(const void* d_table, int n, int W, int H, int R, int C, int32_t* d_crop, int32_t* d_bounds, void* stream);
+
 /* ---- kernels 2a + 2b + the rectangle for a clip RESIDENT in HBM, overlapped inside the clip (csrc/clippipe.hip) ----
  * _get_stabilized_frames_and_crop_boundaries (mfs.py:909-1108) as ONE call: mf_cell_table_f64 + mf_crop_scan_f64 + mf_crop_reduce on a
  * PREP stream, mf_warp_u8c3 on `stream`, the clip cut into `chunks` frame ranges (1..32; 4 is a good value) so that warp(k) waits for

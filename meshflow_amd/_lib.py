@@ -38,6 +38,9 @@ SIGNATURES = {
     'mf_cell_table_f64': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'mf_warp_u8c3': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mf_crop_scan_f64': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'mf_cell_table_bounds_f64': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'mf_warp_bounds_u8c3': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'mf_crop_scan_bounds_f64': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mf_warp_clip_u8c3': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'mf_crop_reduce': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'mf_crop_resize_workspace_bytes': (_sz, [_i, _i]),

@@ -124,6 +124,38 @@ int mf_crop_scan_f64(const void* d_table, int n, int W, int H, int R, int C, int
     return launch_crop_scan(tv, n, W, H, R, C, d_crop, (hipStream_t)stream);
 }
 
+// ---- the same three calls with the clip-level rectangle in the CALLER's d_bounds[4] instead of inside the table blob ----
+
+int mf_cell_table_bounds_f64(const double* d_unstab, const double* d_stab, int n, int W, int H, int R, int C,
+                             void* d_table, int32_t* d_crop, int32_t* d_status, int32_t* d_bounds, void* stream)
+{
+    if (!d_unstab || !d_stab || !d_table || !d_crop || !d_status || !d_bounds) { set_error("mf_cell_table_bounds_f64: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (n <= 0 || R <= 0 || C <= 0) { set_error("mf_cell_table_bounds_f64: bad sizes"); return MF_ERR_INVALID_ARG; }
+    TableView tv = table_view(d_table, n, W, H, R, C);
+    tv.bounds = d_bounds;
+    return launch_cell_table(d_unstab, d_stab, n, W, H, R, C, tv, d_crop, d_status, (hipStream_t)stream);
+}
+
+int mf_warp_bounds_u8c3(const uint8_t* d_frames, uint8_t* d_out, const void* d_table, int n, int W, int H,
+                        int R, int C, const uint8_t border_bgr[3], int32_t* d_crop, int32_t* d_bounds, void* stream)
+{
+    if (!d_frames || !d_out || !d_table || !border_bgr || !d_crop || !d_bounds) { set_error("mf_warp_bounds_u8c3: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (d_frames == d_out) { set_error("mf_warp_bounds_u8c3: d_frames and d_out alias"); return MF_ERR_INVALID_ARG; }
+    if (n <= 0 || R <= 0 || C <= 0) { set_error("mf_warp_bounds_u8c3: bad sizes"); return MF_ERR_INVALID_ARG; }
+    TableView tv = table_view(const_cast<void*>(d_table), n, W, H, R, C);
+    tv.bounds = d_bounds;
+    return launch_warp(d_frames, d_out, tv, n, W, H, R, C, pack_border(border_bgr), d_crop, (hipStream_t)stream);
+}
+
+int mf_crop_scan_bounds_f64(const void* d_table, int n, int W, int H, int R, int C, int32_t* d_crop, int32_t* d_bounds, void* stream)
+{
+    if (!d_table || !d_crop || !d_bounds) { set_error("mf_crop_scan_bounds_f64: null pointer"); return MF_ERR_INVALID_ARG; }
+    if (n <= 0 || R <= 0 || C <= 0) { set_error("mf_crop_scan_bounds_f64: bad sizes"); return MF_ERR_INVALID_ARG; }
+    TableView tv = table_view(const_cast<void*>(d_table), n, W, H, R, C);
+    tv.bounds = d_bounds;
+    return launch_crop_scan(tv, n, W, H, R, C, d_crop, (hipStream_t)stream);
+}
+
 int mf_crop_reduce(const int32_t* d_crop, int n, int W, int H, int32_t* d_bounds, void* stream)
 {
     if (!d_crop || !d_bounds) { set_error("mf_crop_reduce: null pointer"); return MF_ERR_INVALID_ARG; }

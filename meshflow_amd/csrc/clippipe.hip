@@ -67,13 +67,13 @@ extern "C" int mf_warp_clip_u8c3(const uint8_t* d_frames, uint8_t* d_out, const 
     if (chunks <= 0) {
         // IN ORDER (the default of the product pipeline -- measured: kernels that run beside the warp kernel cost it more than they take
         // alone): the whole table on `stream`, then the warp by itself.  The rectangle comes from the warp's own fused
-        // scan + one reduction behind it; or, when the caller gives a prep stream of its own, EARLY from the table (crop scan +
-        // reduction there, beside the first microseconds of the warp) -- what a sharded run wants: its all-reduce then hides
-        // behind the warp as well.
+        // scan (folded into d_bounds by the kernel); or, when the caller gives a prep stream of its own, EARLY from the table (crop scan
+        // there, beside the first microseconds of the warp) -- what a sharded run wants: its all-reduce then hides behind the warp as well.
         const hipStream_t st = (hipStream_t)stream;
         const hipStream_t prep = (hipStream_t)prep_stream;
         const uint32_t border = (uint32_t)border_bgr[0] | ((uint32_t)border_bgr[1] << 8) | ((uint32_t)border_bgr[2] << 16);
-        const TableView tv = table_view(d_table, n, W, H, R, C);
+        TableView tv = table_view(d_table, n, W, H, R, C);
+        tv.bounds = d_bounds;                  // the kernels fold the clip-level rectangle into the caller's 16 bytes themselves: no reduction launch
         if (const int rc = launch_cell_table(d_unstab, d_stab, n, W, H, R, C, tv, d_crop, d_status, st)) return rc;
         const bool early = prep != nullptr && prep != st;
         std::unique_lock<std::mutex> g(side->lock, std::defer_lock);
@@ -82,12 +82,10 @@ extern "C" int mf_warp_clip_u8c3(const uint8_t* d_frames, uint8_t* d_out, const 
             MF_HIP_TRY(hipEventRecord(side->fork, st));
             MF_HIP_TRY(hipStreamWaitEvent(prep, side->fork, 0));
             if (const int rc = launch_crop_scan(tv, n, W, H, R, C, d_crop, prep)) return rc;
-            if (const int rc = launch_crop_reduce(d_crop, n, W, H, d_bounds, prep)) return rc;
             MF_HIP_TRY(hipEventRecord(side->done, prep));
         }
         if (const int rc = launch_warp(d_frames, d_out, tv, n, W, H, R, C, border, d_crop, st)) return rc;
         if (early) MF_HIP_TRY(hipStreamWaitEvent(st, side->done, 0));
-        else if (const int rc = launch_crop_reduce(d_crop, n, W, H, d_bounds, st)) return rc;
         return MF_OK;
     }
     if (chunks > CLIP_MAX_CHUNKS) chunks = CLIP_MAX_CHUNKS;
@@ -95,7 +93,8 @@ extern "C" int mf_warp_clip_u8c3(const uint8_t* d_frames, uint8_t* d_out, const 
     const hipStream_t st = (hipStream_t)stream;
     hipStream_t prep = (hipStream_t)prep_stream;
     const uint32_t border = (uint32_t)border_bgr[0] | ((uint32_t)border_bgr[1] << 8) | ((uint32_t)border_bgr[2] << 16);
-    const TableView tv = table_view(d_table, n, W, H, R, C);
+    TableView tv = table_view(d_table, n, W, H, R, C);
+    tv.bounds = d_bounds;                      // (the first chunk's cell table sets the defaults there, the scan and the warps fold into it)
     const size_t vb1 = (size_t)(R + 1) * (C + 1) * 2, fb = (size_t)W * H * 3;
     const int per = (n + chunks - 1) / chunks;
     // the event set is per device: one call at a time records and waits on it (host side only -- the GPU work overlaps freely)
@@ -114,7 +113,6 @@ extern "C" int mf_warp_clip_u8c3(const uint8_t* d_frames, uint8_t* d_out, const 
         if (!one_stream) MF_HIP_TRY(hipEventRecord(side->ready[nk], prep));
     }
     if (const int rc = launch_crop_scan(tv, n, W, H, R, C, d_crop, prep)) return rc;
-    if (const int rc = launch_crop_reduce(d_crop, n, W, H, d_bounds, prep)) return rc;
     if (!one_stream) MF_HIP_TRY(hipEventRecord(side->done, prep));
     nk = 0;
     for (int i0 = 0; i0 < n; i0 += per, ++nk) {

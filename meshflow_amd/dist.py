@@ -114,9 +114,11 @@ def gather_frames(local_frames, num_frames, dst=0):
     return None
 
 
-def stabilize_sharded(num_frames, jacobi_fn, warp_fn, crop_reduce_fn, gather=False, shard=None, collective=True, exchange_ctx=None):
-    """Frame-range sharded pass of the hot path -- the function bench.py's timed step calls (with the HIP operators) and
-    tests/test_dist_gloo.py drives under gloo (with the oracle standing in for the kernels).
+def stabilize_sharded(num_frames, jacobi_fn, warp_fn, crop_reduce_fn, gather=False, shard=None, collective=True, exchange_ctx=None,
+                      frame_range=None):
+    """Frame-range sharded pass of the hot path -- the function behind `MeshFlowStabilizer.stabilize_resident` (with the HIP
+    operators; bench.py's timed step is that method) and what tests/test_dist_gloo.py drives under gloo (with the oracle standing in
+    for the kernels).
 
     jacobi_fn() -> stabilized displacements of ALL frames (replicated on every rank)
     warp_fn(lo, hi, stab_all) -> (stabilized frames [hi-lo, H, W, 3], per-frame crop values [hi-lo, 4])
@@ -126,10 +128,13 @@ def stabilize_sharded(num_frames, jacobi_fn, warp_fn, crop_reduce_fn, gather=Fal
     (independent clips need none).  exchange_ctx: a callable returning a context manager under which the crop all-reduce is issued
     (the HIP pipeline passes its prep stream: the rectangle is final there before the warp ends, so the exchange runs beside the warp).
     Returns (local or gathered frames, clip-level crop bounds tensor, stab_all, (lo, hi))."""
-    if shard is None:
-        G = world_size()
-        shard = (G, dist.get_rank() if G > 1 else 0)
-    lo, hi = host.shard_range(num_frames, *shard)
+    if frame_range is not None:                  # the caller holds frames lo..hi-1 (whatever the partition was)
+        lo, hi = frame_range
+    else:
+        if shard is None:
+            G = world_size()
+            shard = (G, dist.get_rank() if G > 1 else 0)
+        lo, hi = host.shard_range(num_frames, *shard)
     stab_all = jacobi_fn()
     frames, crop = warp_fn(lo, hi, stab_all)
     bounds = crop_reduce_fn(crop)

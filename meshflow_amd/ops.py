@@ -47,19 +47,31 @@ def jacobi(b, taps, lam, inv_on, omega, iters, out=None):
 
 
 class CellTable:
-    """Per-cell records + compact boxes of n frames (layout: include/meshflow_hip.h)."""
+    """Per-cell records + compact boxes of n frames (layout: include/meshflow_hip.h).  One object serves clips of any length of
+    its geometry: `resize(n)` re-views the (grow-only) buffers for n frames."""
 
     def __init__(self, n, W, H, R, C, device):
-        self.n, self.W, self.H, self.R, self.C = n, W, H, R, C
-        nbytes = _lib_.mf_cell_table_bytes(n, W, H, R, C)
-        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        self.crop = torch.empty((n, 4), dtype=torch.int32, device=device)
+        self.W, self.H, self.R, self.C = W, H, R, C
+        self.device = device
+        self.capacity = 0
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
         self.bounds = None            # clip-level rectangle, filled by warp_clip
-        off = _lib_.mf_cell_table_bounds_offset(n, W, H, R, C)
-        # the same rectangle as the kernels fold it together inside the table blob (valid after the warp / crop scan of all n frames;
-        # overwritten by the next cell_table on this object)
-        self.clip_bounds = self.buf[off:off + 16].view(torch.int32)
+        self.resize(n)
+
+    def resize(self, n):
+        """View the table for n frames (allocates when n exceeds every earlier n; the contents do not survive a resize)."""
+        if n > self.capacity:
+            self.buf = torch.empty(_lib_.mf_cell_table_bytes(n, self.W, self.H, self.R, self.C), dtype=torch.uint8, device=self.device)
+            self._crop = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+            self.capacity = n
+        if n != getattr(self, 'n', None):
+            self.n = n
+            self.crop = self._crop[:n]
+            off = _lib_.mf_cell_table_bounds_offset(n, self.W, self.H, self.R, self.C)
+            # the rectangle as the kernels fold it together inside the table blob when no caller-owned tensor is given (valid after the
+            # warp / crop scan of all n frames; overwritten by the next cell_table on this object)
+            self.clip_bounds = self.buf[off:off + 16].view(torch.int32)
+        return self
 
     def records(self):
         """(n, R*C, 32) float64 view of the records (for tests)."""
@@ -74,9 +86,17 @@ class CellTable:
                              '(cv2.findHomography would return None)')
 
 
-def cell_table(unstab, stab, W, H, R, C, table=None, reset_status=True):
+def _need_bounds(bounds):
+    _need(bounds, torch.int32, 'bounds')
+    if bounds.numel() != 4:
+        raise ValueError('bounds must hold 4 int32 {left, top, right, bottom}')
+
+
+def cell_table(unstab, stab, W, H, R, C, table=None, reset_status=True, bounds=None):
     """Per-cell homographies of n frames (mfs.py:1039-1048).  unstab/stab: (n, R+1, C+1, 2) or (n, V*2)
-    float64 device tensors.  Also resets the per-frame crop values to their defaults (mfs.py:992-995)."""
+    float64 device tensors.  Also resets the per-frame crop values to their defaults (mfs.py:992-995).
+    bounds: a caller-owned int32[4] device tensor that receives the clip-level rectangle (defaults here; `warp` / `crop_scan` called
+    with the same tensor fold their frames into it) instead of the four words inside the table (`table.clip_bounds`)."""
     _need(unstab, torch.float64, 'unstab')
     _need(stab, torch.float64, 'stab')
     n = unstab.shape[0]
@@ -85,16 +105,26 @@ def cell_table(unstab, stab, W, H, R, C, table=None, reset_status=True):
         raise ValueError('displacement tensors do not match (n, R+1, C+1, 2)')
     if table is None:
         table = CellTable(n, W, H, R, C, unstab.device)
-    elif reset_status:
-        table.status.zero_()          # reset_status=False: keep accumulating; the caller checks once later
-    _lib.check(_lib_.mf_cell_table_f64(_ptr(unstab), _ptr(stab), n, W, H, R, C, _ptr(table.buf), _ptr(table.crop),
-                                       _ptr(table.status), _stream()))
+    else:
+        if (table.W, table.H, table.R, table.C) != (W, H, R, C):
+            raise ValueError('the cell table was made for another frame size / mesh')
+        table.resize(n)
+        if reset_status:
+            table.status.zero_()          # reset_status=False: keep accumulating; the caller checks once later
+    if bounds is None:
+        _lib.check(_lib_.mf_cell_table_f64(_ptr(unstab), _ptr(stab), n, W, H, R, C, _ptr(table.buf), _ptr(table.crop),
+                                           _ptr(table.status), _stream()))
+    else:
+        _need_bounds(bounds)
+        _lib.check(_lib_.mf_cell_table_bounds_f64(_ptr(unstab), _ptr(stab), n, W, H, R, C, _ptr(table.buf), _ptr(table.crop),
+                                                  _ptr(table.status), _ptr(bounds), _stream()))
     return table
 
 
-def warp(frames, table, border_bgr=(0, 0, 255), out=None):
+def warp(frames, table, border_bgr=(0, 0, 255), out=None, bounds=None):
     """Mesh warp + crop scan of n frames (mfs.py:1000-1100).  frames: (n, H, W, 3) uint8 device tensor.
-    Returns the stabilized frames; per-frame crop values accumulate in table.crop."""
+    Returns the stabilized frames; per-frame crop values accumulate in table.crop, the clip-level rectangle in `bounds` (the tensor
+    `cell_table` was given) or, without one, in table.clip_bounds."""
     _need(frames, torch.uint8, 'frames')
     n, H, W, ch = frames.shape
     if ch != 3 or (n, W, H) != (table.n, table.W, table.H):
@@ -103,18 +133,24 @@ def warp(frames, table, border_bgr=(0, 0, 255), out=None):
         out = torch.empty_like(frames)
     _need(out, torch.uint8, 'out')
     border = (ctypes.c_uint8 * 3)(*[int(np.clip(round(float(v)), 0, 255)) for v in border_bgr[:3]])
-    _lib.check(_lib_.mf_warp_u8c3(_ptr(frames), _ptr(out), _ptr(table.buf), n, W, H, table.R, table.C, border,
-                                  _ptr(table.crop), _stream()))
+    if bounds is None:
+        _lib.check(_lib_.mf_warp_u8c3(_ptr(frames), _ptr(out), _ptr(table.buf), n, W, H, table.R, table.C, border,
+                                      _ptr(table.crop), _stream()))
+    else:
+        _need_bounds(bounds)
+        _lib.check(_lib_.mf_warp_bounds_u8c3(_ptr(frames), _ptr(out), _ptr(table.buf), n, W, H, table.R, table.C, border,
+                                             _ptr(table.crop), _ptr(bounds), _stream()))
     return out
 
 
-def warp_clip(frames, unstab, stab, table, border_bgr=(0, 0, 255), out=None, chunks=4, prep_stream=None):
+def warp_clip(frames, unstab, stab, table, border_bgr=(0, 0, 255), out=None, chunks=4, prep_stream=None, bounds=None):
     """mfs.py:909-1108 for a clip resident in HBM as ONE call overlapped inside the clip (csrc/clippipe.hip): cell table + plan +
     crop scan + clip rectangle on `prep_stream` (a torch stream; None = the library's own, forked from the current stream), the warp
     of `chunks` frame ranges on torch's current stream, each waiting for its own table only.  chunks=0: in order on the current
     stream -- table, warp alone, rectangle (early on `prep_stream` when one is given).  Returns (stabilized frames,
-    table.bounds): bounds = int32 {left, top, right, bottom} of the clip, final on the prep stream right after the tables (and on
-    the current stream after the call); per-frame values in table.crop; table.status accumulates degenerate cells."""
+    bounds): bounds = int32 {left, top, right, bottom} of the clip -- the caller's tensor when one is given, else table.bounds --,
+    folded together by the kernels, final on the prep stream right after the tables' crop scan (and on the current stream after
+    the call); per-frame values in table.crop; table.status accumulates degenerate cells."""
     _need(frames, torch.uint8, 'frames')
     _need(unstab, torch.float64, 'unstab')
     _need(stab, torch.float64, 'stab')
@@ -125,19 +161,29 @@ def warp_clip(frames, unstab, stab, table, border_bgr=(0, 0, 255), out=None, chu
     if out is None:
         out = torch.empty_like(frames)
     _need(out, torch.uint8, 'out')
-    if table.bounds is None:
-        table.bounds = torch.empty(4, dtype=torch.int32, device=frames.device)
+    if bounds is None:                  # (without a caller-owned tensor: one per table, rewritten by the next call on it)
+        if table.bounds is None:
+            table.bounds = torch.empty(4, dtype=torch.int32, device=frames.device)
+        bounds = table.bounds
+    else:
+        _need_bounds(bounds)
     border = (ctypes.c_uint8 * 3)(*[int(np.clip(round(float(v)), 0, 255)) for v in border_bgr[:3]])
     prep = ctypes.c_void_p(prep_stream.cuda_stream) if prep_stream is not None else None
     _lib.check(_lib_.mf_warp_clip_u8c3(_ptr(frames), _ptr(out), _ptr(unstab), _ptr(stab), n, W, H, table.R, table.C, border,
-                                       _ptr(table.buf), _ptr(table.crop), _ptr(table.bounds), _ptr(table.status), int(chunks), prep, _stream()))
-    return out, table.bounds
+                                       _ptr(table.buf), _ptr(table.crop), _ptr(bounds), _ptr(table.status), int(chunks), prep, _stream()))
+    return out, bounds
 
 
-def crop_scan(table):
+def crop_scan(table, bounds=None):
     """The four edge scans of mfs.py:1075-1098 from the cell table alone (no frame is touched): fills table.crop exactly as
-    `warp` would.  Returns table.crop, (n, 4) int32 {left, top, right, bottom}."""
-    _lib.check(_lib_.mf_crop_scan_f64(_ptr(table.buf), table.n, table.W, table.H, table.R, table.C, _ptr(table.crop), _stream()))
+    `warp` would (and folds the clip-level rectangle into `bounds` / table.clip_bounds).  Returns table.crop, (n, 4) int32
+    {left, top, right, bottom}."""
+    if bounds is None:
+        _lib.check(_lib_.mf_crop_scan_f64(_ptr(table.buf), table.n, table.W, table.H, table.R, table.C, _ptr(table.crop), _stream()))
+    else:
+        _need_bounds(bounds)
+        _lib.check(_lib_.mf_crop_scan_bounds_f64(_ptr(table.buf), table.n, table.W, table.H, table.R, table.C, _ptr(table.crop),
+                                                 _ptr(bounds), _stream()))
     return table.crop
 
 

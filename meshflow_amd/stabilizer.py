@@ -426,16 +426,76 @@ class MeshFlowStabilizer:
     #      table(j) only): the rectangle is known earliest, the clip takes 2-8 % longer.
     resident_chunks = 0
     resident_rectangle = 'fused'     # 'early': rectangle from the table on the prep stream (a sharded run's all-reduce hides behind the warp)
+    resident_table_shapes = 4        # cell tables are kept for this many (W, H, mesh) geometries (two tables each, grow-only in the clip length)
 
     def _resident_state(self, dev):
-        """Per-device plumbing of `stabilize_resident`: the PREP stream beside the caller's, two cell tables per clip shape taking
-        turns, the event after which a table is free again, and the gate of the next sweep."""
+        """Per-device plumbing of `stabilize_resident`: the PREP stream beside the caller's, a stream for the 4-byte status read-backs,
+        two cell tables per clip geometry taking turns, the event after which a table is free again, and the gate of the next sweep."""
+        import collections
         import torch
         st = getattr(self, '_resident', None)
         if st is None or st['device'] != dev:
-            st = {'device': dev, 'prep': torch.cuda.Stream(device=dev), 'tables': {}, 'turn': 0, 'ends': []}
+            if st is not None:                               # another device: nothing of the old one's is kept
+                self.finish()
+            st = {'device': dev, 'prep': torch.cuda.Stream(device=dev), 'status': torch.cuda.Stream(device=dev),
+                  'tables': collections.OrderedDict(), 'turn': 0, 'ends': [], 'serial': 0}
             self._resident = st
         return st
+
+    @staticmethod
+    def _settle(slot):
+        """The degenerate-mesh verdict of the clip that last used this table slot: waits for its 4-byte status read-back (issued behind
+        that clip's warp on a stream of its own -- long finished when the slot comes up again two clips later) and raises if the clip had
+        cells without a homography.  The counter is cumulative per table; a slot remembers what it has seen."""
+        pending, slot['pending'] = slot['pending'], None
+        if pending is None:
+            return
+        pending['copied'].synchronize()
+        total = int(slot['host'][0])
+        bad, slot['seen'] = total - slot['seen'], total
+        if bad and not pending['ignore']:
+            raise ValueError(f'{bad} degenerate mesh cell(s) in resident clip #{pending["serial"]}: no homography exists '
+                             '(cv2.findHomography would return None); its frames are undefined')
+
+    def finish(self):
+        """Waits for the verdict of every clip `stabilize_resident` has issued and not yet checked (it checks clip i when clip i + 2 is
+        issued) and raises ValueError for the first one that had a degenerate mesh.  Later clips are unaffected either way."""
+        st = getattr(self, '_resident', None)
+        first = None
+        if st is not None:
+            for pair in st['tables'].values():
+                for slot in pair:
+                    try:
+                        self._settle(slot)
+                    except ValueError as e:
+                        first = first or e
+        if first is not None:
+            raise first
+
+    def _resident_slot(self, st, n, W, H):
+        """The table slot of the next clip (two per geometry take turns), settled and sized for n frames."""
+        import torch
+        from . import ops
+        dev = st['device']
+        key = (W, H, self.mesh_row_count, self.mesh_col_count)
+        pair = st['tables'].get(key)
+        if pair is None:
+            while len(st['tables']) >= max(1, self.resident_table_shapes):           # least recently used geometry out (its verdicts first)
+                _, old = next(iter(st['tables'].items()))
+                for slot in old:
+                    self._settle(slot)
+                torch.cuda.synchronize(dev)
+                st['tables'].popitem(last=False)
+            pair = st['tables'][key] = [{'table': ops.CellTable(n, W, H, self.mesh_row_count, self.mesh_col_count, dev), 'free': None,
+                                         'pending': None, 'seen': 0, 'host': torch.zeros(1, dtype=torch.int32).pin_memory()} for _ in range(2)]
+        st['tables'].move_to_end(key)
+        slot = pair[st['turn'] & 1]
+        self._settle(slot)                                   # (raises BEFORE anything of the new clip is issued or any state changes)
+        if n > slot['table'].capacity:
+            torch.cuda.synchronize(dev)                      # a longer clip than this slot has seen: its buffers are replaced (rare)
+        slot['table'].resize(n)
+        st['turn'] += 1
+        return slot
 
     def _resident_jacobi(self, d_disp, frame_width, frame_height, adaptive_weights_definition, homographies, inputs_ready=None):
         """Stage 1 of the resident pipeline, on the prep stream: mfs.py:632-710.  `inputs_ready`: a torch.cuda.Event after which
@@ -465,9 +525,10 @@ class MeshFlowStabilizer:
         d_stab.record_stream(torch.cuda.current_stream(dev))      # allocated on the prep stream, handed to the caller's
         return d_stab
 
-    def _resident_warp(self, d_frames, d_unstab, d_stab, out=None, chunks=None, warp_events=None):
-        """Stages 2-4, mfs.py:909-1108, for the d_stab `_resident_jacobi` just produced.  Returns (stabilized frames, table):
-        table.crop per frame, table.bounds the clip-level rectangle, table.status the degenerate-cell counter.
+    def _resident_warp(self, d_frames, d_unstab, d_stab, out=None, chunks=None, warp_events=None, check='deferred'):
+        """Stages 2-4, mfs.py:909-1108, for the d_stab `_resident_jacobi` just produced.  Returns (stabilized frames, bounds, table):
+        bounds = the clip-level rectangle in a 16-byte tensor of this clip's own (the kernels fold it together there), table.crop per
+        frame (valid until the table's next turn, two clips on).
         warp_events: two torch events recorded on the current stream in front of and behind the warp kernel(s) (bench.py's roofline)."""
         import torch
         from . import ops
@@ -476,76 +537,122 @@ class MeshFlowStabilizer:
         main = torch.cuda.current_stream(dev)
         chunks = self.resident_chunks if chunks is None else chunks
         n, H, W, _ = d_frames.shape
-        key = (n, W, H, self.mesh_row_count, self.mesh_col_count)
-        pair = st['tables'].get(key)
-        if pair is None:
-            pair = st['tables'][key] = [{'table': ops.CellTable(n, W, H, self.mesh_row_count, self.mesh_col_count, dev), 'free': None} for _ in range(2)]
-        slot = pair[st['turn'] & 1]
-        st['turn'] += 1
+        slot = self._resident_slot(st, n, W, H)
+        table = slot['table']
+        bounds = torch.empty(4, dtype=torch.int32, device=dev)           # this clip's own: never rewritten by a later one
         if chunks <= 0:
             if st.get('swept') is not None:
                 main.wait_event(st['swept'])                      # the sweep that produced d_stab
             # (every marker on a stream costs the step ~5 us -- DESIGN.md section 5 -- so ONE event per clip, recorded behind its warp,
-            # serves as the end of a timed interval, as "this table is free again" and, two clips on, as the gate of a sweep)
+            # serves as the end of a timed interval, as "this table is free again", as the start of the status read-back and, two clips
+            # on, as the gate of a sweep)
             # (the same launches as mf_warp_clip_u8c3 with chunks = 0, issued from here so that the warp kernel can be bracketed)
-            table = ops.cell_table(d_unstab, d_stab, W, H, self.mesh_row_count, self.mesh_col_count, table=slot['table'], reset_status=False)
+            ops.cell_table(d_unstab, d_stab, W, H, self.mesh_row_count, self.mesh_col_count, table=table, reset_status=False, bounds=bounds)
             early = self.resident_rectangle == 'early'
             if early:                                             # rectangle from the table, on the prep stream, beside the start of the warp
                 tabled = torch.cuda.Event()
                 tabled.record(main)
                 st['prep'].wait_event(tabled)
                 with torch.cuda.stream(st['prep']):
-                    ops.crop_scan(table)
-                    table.bounds = table.clip_bounds      # (the scan folds the clip-level rectangle together as well)
+                    ops.crop_scan(table, bounds=bounds)           # (the scan folds the clip-level rectangle together as well)
                     scanned = torch.cuda.Event()
                     scanned.record(st['prep'])
+                st['scanned'] = scanned
             if warp_events:
                 warp_events[0].record(main)
-            out = ops.warp(d_frames, table, self.color_outside_image_area_bgr, out=out)
+            out = ops.warp(d_frames, table, self.color_outside_image_area_bgr, out=out, bounds=bounds)
             end = warp_events[1] if warp_events else torch.cuda.Event()
             end.record(main)
             st['ends'].append(end)
             del st['ends'][:-2]
-            slot['free'] = end
-            if early:
-                main.wait_event(scanned)
-            else:
-                table.bounds = table.clip_bounds       # folded together by the warp kernel itself (no reduction launch); it lives in the
-                                                       # table: valid until this table's next turn, two clips on
-            return out, slot['table']
         else:
             if slot['free'] is not None:
                 st['prep'].wait_event(slot['free'])               # the warps that last read this table (two clips ago) have ended
             if warp_events:
                 warp_events[0].record(main)
-            out, _ = ops.warp_clip(d_frames, d_unstab, d_stab, slot['table'], self.color_outside_image_area_bgr, out=out,
-                                   chunks=chunks, prep_stream=st['prep'])
-            if warp_events:
-                warp_events[1].record(main)
-        slot['free'] = torch.cuda.Event()
-        slot['free'].record(main)
-        return out, slot['table']
+            out, _ = ops.warp_clip(d_frames, d_unstab, d_stab, table, self.color_outside_image_area_bgr, out=out,
+                                   chunks=chunks, prep_stream=st['prep'], bounds=bounds)
+            end = warp_events[1] if warp_events else torch.cuda.Event()
+            end.record(main)
+        slot['free'] = end
+        # the degenerate-cell counter of this clip, 4 bytes into pinned memory on a stream of their own behind the warp: no marker on
+        # the caller's stream, nobody waits -- `_settle` looks at it when this slot comes up again (or `finish()` does); check='never'
+        # only keeps the slot's running total in step
+        ss = st['status']
+        ss.wait_event(end)
+        with torch.cuda.stream(ss):
+            slot['host'].copy_(table.status, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(ss)
+        st['serial'] += 1
+        slot['pending'] = {'copied': copied, 'serial': st['serial'], 'ignore': check == 'never' or check is False}
+        if check is True or check == 'now':
+            self._settle(slot)
+        return out, bounds, table
 
     def stabilize_resident(self, d_frames, d_disp, homographies, adaptive_weights_definition=ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL,
-                           out=None, frame_range=None, inputs_ready=None, check=True):
+                           out=None, frame_range=None, inputs_ready=None, check='deferred', collective=False, warp_events=None,
+                           jacobi_events=None):
         """mfs.py:150-158 for a clip whose frames (n, H, W, 3) uint8 and vertex displacements (F, R+1, C+1, 2) float64 are RESIDENT in
-        HBM: Jacobi sweep -> cell tables -> warp + crop rectangle, nothing leaves the device, one call per clip.  The sweep runs on this
-        object's prep stream: calls issued back to back overlap the next clip's sweep with this clip's cell table + plan (see
-        `resident_chunks` for the other arrangement).
-        frame_range = (lo, hi): d_frames holds frames lo..hi-1 of the clip (a frame-range shard; the sweep still covers all F).
-        Returns (stabilized frames, clip-level crop bounds as a device int32 tensor {left, top, right, bottom}, stabilized vertex
-        displacements (F, R+1, C+1, 2)), all valid in current-stream order."""
+        HBM: Jacobi sweep -> cell tables -> warp + crop rectangle, nothing leaves the device, one call per clip, NO synchronisation:
+        calls issued back to back pipeline by themselves (the sweep runs on this object's prep stream, the next clip's beside this
+        clip's cell table + plan; see `resident_chunks` for the other arrangement).
+        frame_range = (lo, hi): d_frames holds frames lo..hi-1 of the clip (a frame-range shard; the sweep still covers all F);
+        collective=True then all-reduces the rectangle over the process group (16 bytes, `dist.allreduce_crop`).
+        Returns (stabilized frames, clip-level crop bounds as a device int32 tensor {left, top, right, bottom} -- 16 bytes of this
+        clip's own, never rewritten by a later call --, stabilized vertex displacements (F, R+1, C+1, 2)), all valid in current-stream
+        order.
+        A degenerate mesh (a cell without homography: the reference would die inside cv2) raises ValueError -- by default DEFERRED:
+        the 4-byte verdict of clip i is looked at when clip i + 2 is issued (its table slot comes up again) or by `finish()`, whichever
+        comes first, and names the clip by its serial number; check=True waits for it before returning (one blocking device-to-host
+        read per clip: the calls no longer overlap), check='never' skips it.  Clips after a degenerate one are unaffected.
+        warp_events / jacobi_events: pairs of torch events recorded around the warp kernel (caller's stream) and the sweep stage (prep
+        stream) -- bench.py's roofline brackets."""
+        import torch
+        from . import dist as mfdist
         self._check_definition(adaptive_weights_definition)
+        if check is False:
+            check = 'never'
         F = d_disp.shape[0]
         lo, hi = frame_range if frame_range is not None else (0, F)
         n, H, W, _ = d_frames.shape
         if hi - lo != n:
             raise ValueError(f'frame_range {lo, hi} does not match {n} frames')
-        d_stab = self._resident_jacobi(d_disp, W, H, adaptive_weights_definition, homographies, inputs_ready)
-        out, table = self._resident_warp(d_frames, d_disp[lo:hi], d_stab[lo:hi], out=out)
-        if check:
-            table.check()
-        return out, table.bounds, d_stab
+        dev = d_frames.device
+        st = self._resident_state(dev)
+        result = {}
+
+        def jacobi_fn():
+            if jacobi_events:
+                jacobi_events[0].record(st['prep'])
+            d_stab = self._resident_jacobi(d_disp, W, H, adaptive_weights_definition, homographies, inputs_ready)
+            if jacobi_events:
+                jacobi_events[1].record(st['prep'])
+            return d_stab
+
+        def warp_fn(lo_, hi_, d_stab):
+            frames, bounds, table = self._resident_warp(d_frames, d_disp[lo_:hi_], d_stab[lo_:hi_], out=out, warp_events=warp_events, check=check)
+            result['table'] = table
+            return frames, bounds
+
+        on_prep = self.resident_chunks > 0 or self.resident_rectangle == 'early'       # the rectangle is final on the prep stream, early
+
+        def exchange_ctx():
+            # the 16-byte all-reduce of a sharded clip goes to the prep stream too: beside the warp, off the critical path
+            return torch.cuda.stream(st['prep'])
+
+        frames, bounds, d_stab, _ = mfdist.stabilize_sharded(F, jacobi_fn, warp_fn, lambda b: b, frame_range=(lo, hi), collective=collective,
+                                                             exchange_ctx=exchange_ctx if (on_prep and collective) else None)
+        if on_prep:
+            main = torch.cuda.current_stream(dev)
+            if collective and mfdist.world_size() > 1:
+                done = torch.cuda.Event()
+                done.record(st['prep'])
+                main.wait_event(done)                        # the exchanged rectangle, back in current-stream order
+                bounds.record_stream(main)
+            elif self.resident_chunks <= 0:
+                main.wait_event(st['scanned'])               # (the chunked arrangement joins the streams inside mf_warp_clip_u8c3)
+        return frames, bounds, d_stab
 
     def _stabilized_frames_device(self, d_frames, d_unstab, d_stab, out=None, table=None):
         """d_frames: (n, H, W, 3) uint8; d_unstab/d_stab: (n, R+1, C+1, 2) float64, all in HBM.

@@ -15,3 +15,34 @@ def test_self_launch_without_gpus_exits_2():
     if torch.cuda.device_count() >= 2:
         return                                # a real multi-GPU box: covered by the -m gpu tests
     assert proc.returncode == 2 and 'GPU(s) visible' in proc.stderr and not proc.stdout.strip()
+
+
+def test_scale_all_dry_run_commands_parse():
+    """tools/scale_all.sh --dry-run prints every command of the north-star sweep; each must be accepted by bench.py's own argument
+    parser (tools/capi_shard_run.py's by its own), name a known workload, and together they must cover N = 1, 2, 4, 8 of config 2,
+    config 4 = cfg4shard x N, config 5 = --mode clips and the host-to-host mode -- so that the first multi-GPU lease cannot fail on a flag."""
+    import shlex
+    sys.path.insert(0, REPO)
+    import bench
+    proc = subprocess.run(['bash', os.path.join(REPO, 'tools', 'scale_all.sh'), '--dry-run'], cwd=REPO, capture_output=True, text=True, timeout=60)
+    assert proc.returncode == 0, proc.stderr
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) >= 14
+    parser = bench.build_parser()
+    seen = set()
+    for line in lines:
+        words = shlex.split(line)
+        assert words[0] == 'python'
+        if words[1] == 'bench.py':
+            a = parser.parse_args(words[2:])               # SystemExit(2) on an unknown flag or a bad choice
+            assert a.workload in bench.WORKLOADS and a.gpus in (1, 2, 4, 8) and a.steps > 0
+            seen.add((a.workload, a.mode, a.gpus))
+        else:
+            assert words[1] == 'tools/capi_shard_run.py' and os.path.exists(os.path.join(REPO, words[1])) and words[2:] == ['--gpus', '8']
+    for n in (1, 2, 4, 8):
+        assert ('cfg2', 'shard', n) in seen
+    for n in (2, 4, 8):
+        assert ('cfg4shard', 'shard', n) in seen and ('cfg2', 'clips', n) in seen and ('cfg2', 'e2e', n) in seen
+    # and the launcher's own default run: flags of the driver's command line
+    a = parser.parse_args(['--gpus', '8', '--steps', '20', '--warmup', '5'])
+    assert (a.gpus, a.steps, a.warmup, a.workload, a.mode) == (8, 20, 5, 'cfg2', 'shard')

@@ -45,9 +45,36 @@ def test_bench_json_line_contract():
     assert f['kind'].startswith('reference-faithful, scaled from') and 0 < f['value'] < c['value']
     e = d['end_to_end']
     assert e['value'] > 0 and e['runs'] >= 5 and e['min_ms_per_clip'] <= e['ms_per_clip']
+    # BASELINE's host-to-host figure is a timed region of its own: steps x ms_per_step = the seconds it took
+    assert e['steps'] == e['runs'] and abs(e['steps'] * e['ms_per_step'] * 1e-3 - e['elapsed_s']) < 1e-6 * e['elapsed_s'] + 1e-9
+    assert e['with_crop']['steps'] == e['with_crop']['runs'] and e['with_crop']['value'] > 0
+    k = d['kernel_path']                                          # the HBM-resident figure = `value`, through the public method
+    assert k['value'] == d['value'] and k['ms_per_step'] == d['ms_per_step'] and 'stabilize_resident' in k['through']
+    assert k['serial']['ms_per_step'] > 0 and k['latency_ms_single_clip']['median'] > 0
+    assert 'workloads' not in d                                   # only beside the default workload (below)
     assert d['next_rows']['vertex_motion']['avg_ms'] > 0
     assert d['cfg1'].startswith('skipped')                       # BASELINE configs[0]: no decoder / no video on the box
     assert d['communicator']['world_size'] == 1
+
+
+def test_bench_default_run_carries_the_other_configurations():
+    """The driver's own command line (default workload = BASELINE configs[1]): the line also measures configs 3 and 4-shard in the same
+    run -- warp launch time and roofline fraction, step time, Jacobi kernel, host-to-host clip against the PCIe rate of this run."""
+    proc = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2', '--cpu-frames', '8',
+                           '--no-faithful', '--workload-steps', '4'], cwd=REPO, capture_output=True, text=True, timeout=1500)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    _contract(d, 1, 5, 2)
+    assert d['config']['workload'].startswith('cfg2: 1920x1080, 300 frames')
+    assert 0.2 < d['roofline']['frac'] < 1.0 and d['end_to_end']['with_crop']['value'] > 500          # north_star: >= 500 frames/s end to end
+    for name, frames in (('cfg3', 600), ('cfg4shard', 150)):
+        w = d['workloads'][name]
+        assert 'error' not in w, w
+        assert w['steps'] == 4 and w['ms_per_step'] > 0 and abs(w['value'] - frames / (w['ms_per_step'] * 1e-3)) < 1e-6 * w['value']
+        assert 0.2 < w['warp']['frac'] < 1.0 and w['warp']['avg_launch_ms'] < w['ms_per_step']
+        assert w['jacobi']['kernel_ms'] > 0 and w['end_to_end']['value'] > 0 and 0.3 < w['end_to_end']['roofline']['frac'] < 1.2
 
 
 def test_bench_e2e_mode_value_is_the_host_to_host_clip():

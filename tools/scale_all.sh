@@ -1,7 +1,10 @@
 #!/bin/bash
 # The whole north-star table in ONE command, for the first box that has more than one GPU (nothing here has ever run on more than one):
 #
-#     tools/scale_all.sh [MAXGPUS] [OUTDIR]          default: every GPU of the node, gpurun_out/scale
+#     tools/scale_all.sh [--dry-run] [MAXGPUS] [OUTDIR]          default: every GPU of the node, gpurun_out/scale
+#
+# --dry-run prints every command of the sweep (one per line, nothing runs, no GPU needed): tests/test_bench_launcher.py parses them with
+# bench.py's own argument parser, so that the first 8-GPU lease fails on RCCL itself, if at all, not on a flag.
 #
 #   cfg2, frame-range shards, N = 1, 2, 4, 8     (weak scaling: 300 frames per GPU, Jacobi replicated, 16-byte crop all-reduce, final gather)
 #   cfg4 = cfg4shard x N                          (3840x2160, 150 frames per GPU: BASELINE config 4 at N = 8)
@@ -13,16 +16,21 @@
 # the command in front, stderr (RCCL version, free memory before the gather) to OUTDIR/*.err.  A failing run is recorded and the sweep goes on.
 set -u
 cd "$(dirname "$0")/.."
+DRY=0
+if [ "${1:-}" = "--dry-run" ]; then DRY=1; shift; fi
 # (kept on purpose: the host driver of this pool only supports dmabuf IPC -- without it RCCL and cross-process tensor sharing fail with
 # "hipIpcGetMemHandle: invalid argument"; see the Environment notes of the build)
 export HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}
-NGPU=$(python3 -c "import bench; print(bench.visible_gpus() or 1)")
+if [ "$DRY" = 1 ]; then NGPU=8; else NGPU=$(python3 -c "import bench; print(bench.visible_gpus() or 1)"); fi
 MAX=${1:-$NGPU}
 OUT=${2:-gpurun_out/scale}
-mkdir -p "$OUT"
-: > "$OUT/scale.jsonl"
+if [ "$DRY" = 0 ]; then
+    mkdir -p "$OUT"
+    : > "$OUT/scale.jsonl"
+fi
 run() {     # name, then the bench flags
     local name=$1; shift
+    if [ "$DRY" = 1 ]; then echo "python bench.py $*"; return; fi
     echo "== $name: python bench.py $*" | tee -a "$OUT/scale.jsonl" >&2
     if timeout 1500 python bench.py "$@" >> "$OUT/scale.jsonl" 2> "$OUT/$name.err"; then :; else
         echo "{\"failed\": \"$name\", \"rc\": $?}" >> "$OUT/scale.jsonl"
@@ -30,7 +38,7 @@ run() {     # name, then the bench flags
 }
 for n in 1 2 4 8; do
     [ "$n" -le "$MAX" ] || continue
-    run "cfg2_shard_n$n" --gpus $n --steps 20 --warmup 5 --cpu-frames 0 --no-e2e
+    run "cfg2_shard_n$n" --gpus $n --steps 20 --warmup 5 --cpu-frames 0 --no-e2e --no-workloads
 done
 for n in 2 4 8; do
     [ "$n" -le "$MAX" ] || continue
@@ -38,6 +46,7 @@ for n in 2 4 8; do
     run "cfg5_clips_n$n" --gpus $n --mode clips --steps 20 --warmup 5 --cpu-frames 0 --no-e2e
     run "e2e_n$n" --gpus $n --mode e2e --steps 5 --warmup 1
 done
+if [ "$DRY" = 1 ]; then echo "python tools/capi_shard_run.py --gpus $MAX"; exit 0; fi
 echo "== capi: python tools/capi_shard_run.py --gpus $MAX" | tee -a "$OUT/scale.jsonl" >&2
 timeout 900 python tools/capi_shard_run.py --gpus "$MAX" >> "$OUT/scale.jsonl" 2> "$OUT/capi.err" || echo "{\"failed\": \"capi\", \"rc\": $?}" >> "$OUT/scale.jsonl"
 grep -c '"value"' "$OUT/scale.jsonl" >&2
