@@ -243,12 +243,29 @@ class MeshFlowStabilizer:
         d_stab = self._stabilized_vertex_displacements_device(torch.from_numpy(unstab).to(dev), W, H,
                                                               adaptive_weights_definition, homographies)
         stab = d_stab.cpu().numpy()
-        score = self._compute_stability_score(num_frames, stab)
+        # the stability score (mfs.py:162: np.fft over every vertex path, 20 ms at config 3) on a host thread BESIDE the frames' trip over
+        # PCIe (the C call releases the GIL): same function, same bits, off the critical path
+        import threading
+        score = {}
+
+        def scoring():
+            try:
+                score['value'] = self._compute_stability_score(num_frames, stab)
+            except BaseException as e:          # re-raised on the calling thread
+                score['error'] = e
+        scorer = threading.Thread(target=scoring, name='mf-score')
+        scorer.start()
+        try:
+            res = _warp_host_c(self, clip, unstab, stab, crop=crop, keep_uncropped=keep_uncropped)
+        finally:
+            scorer.join()
+        if 'error' in score:
+            raise score['error']
         if not crop:
-            out_host, bounds = _warp_host_c(self, clip, unstab, stab)
-            return list(out_host), bounds, stab, score
-        out_host, bounds, cropped_host = _warp_host_c(self, clip, unstab, stab, crop=True, keep_uncropped=keep_uncropped)
-        return (list(out_host) if out_host is not None else None), bounds, stab, score, list(cropped_host)
+            out_host, bounds = res
+            return list(out_host), bounds, stab, score['value']
+        out_host, bounds, cropped_host = res
+        return (list(out_host) if out_host is not None else None), bounds, stab, score['value'], list(cropped_host)
 
     # ------------------------------------------------------------------------------------------
     # drop-in boundary, host buffers (same signatures as the reference)
