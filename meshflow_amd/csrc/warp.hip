@@ -537,6 +537,24 @@ __device__ __forceinline__ uint3 blend(const uint32_t (&bx)[4], const uint32_t (
 }
 
 
+// ---- EXPERIMENT builds only (tools/phase_profile.sh; nothing of this is in the product library) ------------------------------------
+// -DMF_EXP_SKIP=mask: TIMING-ONLY kernels in which the wavefronts of a path class return right after the plan test that selects
+// them (their output is garbage): 1 hot, 2 border, 4 pair, 8 multi, 16 everything else, 32 every wavefront right after the plan and
+// region words have arrived (no window copy), 64 every wavefront right after the window copy is issued.  What a class costs = the
+// product kernel's time minus the time with that class skipped.
+// -DMF_EXP_PHASES: every 64th HOT wavefront adds the s_memtime ticks between five points of its life to mf_exp_phase[] (read back by
+// mf_exp_phase_read): entry -> plan + region arrived -> coordinates done (window copy in flight) -> window landed -> blend done.
+// -DMF_EXP_TWICE: TIMING-ONLY: a hot wavefront does its per-pixel work twice (how much of a wavefront's cost is per wavefront?).
+#ifndef MF_EXP_SKIP
+#define MF_EXP_SKIP 0
+#endif
+#ifdef MF_EXP_PHASES
+__device__ unsigned long long mf_exp_phase[8];
+#define MF_EXP_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define MF_EXP_STAMP(var)
+#endif
+
 // STAGE_OK: the clip is 4-byte aligned, so the plan's STAGED windows can be copied by 16-byte global->LDS loads (always the case
 // for buffers from hipMalloc / torch; the other instantiation ignores the windows).
 // SCAN: the crop-boundary scan ALONE (crop_scan_kernel below): the same ownership and coordinate code for footprint t of frame f,
@@ -555,6 +573,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     __shared__ __attribute__((aligned(16))) uint8_t s_src_all[SCAN ? 16 : LDS_WINDOW_PAD + LDS_WINDOW_BYTES + 64];
     uint8_t* const s_src = &s_src_all[SCAN ? 0 : LDS_WINDOW_PAD];
     constexpr int wave = 0;
+    MF_EXP_STAMP(exp_t0);
     const uint32_t ty = (__umulhi(t, g.div_m) + (t & g.div_pass)) >> g.div_s, tx = t - ty * g.nfx;
     const int xa = (int)(tx * (uint32_t)FOOT_W), ya = (int)(ty * (uint32_t)FOOT_H);
     const int lane = threadIdx.x;
@@ -568,6 +587,11 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     const uint32_t rg = (uint32_t)region, src_dwords = (uint32_t)(region >> 32);
     const uint8_t* __restrict__ src = frames + (uint64_t)f * g.frame_bytes;
     const bool staged = STAGE_OK && !SCAN && (rg & MF_REGION_STAGED) != 0;
+    if (!SCAN && (MF_EXP_SKIP & 32)) { asm volatile("" :: "s"(pv.x), "s"(pv.y), "s"(pv.z), "s"(pv.w), "s"(rg), "s"(src_dwords)); return; }
+#ifdef MF_EXP_PHASES
+    asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(pv.x), "s"(pv.w), "s"(rg) : "memory");
+    MF_EXP_STAMP(exp_t1);
+#endif
     if (staged) {
         // Source region -> LDS, asynchronously (global_load_lds: no VGPRs, no ds_write).  Two layouts, chosen by the plan:
         //   COMPACT (hot footprints whose taps fit 9 rows x 112 bytes: ~3/4 of them): ONE load, lane i fetches the i-th 16-byte
@@ -608,6 +632,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o1), (__attribute__((address_space(3))) void*)(window + 1024), 16, 0, 0);
         }
     }
+    if (!SCAN && (MF_EXP_SKIP & 64)) { asm volatile("" :: "s"(pv.x), "s"(pv.y), "s"(pv.z), "s"(pv.w)); return; }
     // taps are addressed by absolute LDS byte address (= LDS_PITCH iy + 3 ix - lds_origin): the window base is folded in
     const uint32_t lds_origin = (rg & MF_REGION_ORIGIN_MASK) - (uint32_t)(uintptr_t)&s_src[0];
     const crec_t frec = (crec_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(records) + f * g.rec_frame_bytes);
@@ -619,6 +644,20 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         // The plan certifies everything (~2/3 of the footprints at config-2 geometry): ONE cell owns all 256 pixels, its
         // denominator allows the trimmed reciprocal (UNIT), the footprint lies inside the frame, its window is staged and every
         // tap is at least two pixels inside the frame (DEEP: no crop flag either).  Straight-line code, all lanes active.
+        if (MF_EXP_SKIP & 1) return;
+#ifdef MF_EXP_TWICE
+        {   // the per-pixel work a second time (rows + 8), stored over the first result
+            float u2[4], v2[4];
+            if (!cell_coords_fast(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy + 8.0, u2, v2))
+                cell_coords<false>(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy + 8.0, x0, 0xFu, u2, v2, true);
+            uint32_t bx2[4], by2[4];
+            fixed_point(u2, v2, bx2, by2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint3 d2 = (rg & MF_REGION_COMPACT) ? gather_blend_staged<MF_COMPACT_PITCH>(bx2, by2, lds_origin) : gather_blend_staged(bx2, by2, lds_origin);
+            uint8_t* __restrict__ dst2 = out + (uint64_t)f * g.frame_bytes;
+            *reinterpret_cast<uint3*>(dst2 + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d2;
+        }
+#endif
         float u[4], v[4];
 #ifndef MF_NO_FAST64
         if (!((pv.x >> 16) & MF_PLAN_FAST64) || !cell_coords_fast(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy, u, v))
@@ -626,12 +665,28 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         cell_coords<false>(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy, x0, 0xFu, u, v, true);
         uint32_t bx[4], by[4];
         fixed_point(u, v, bx, by);
+#ifdef MF_EXP_PHASES
+        asm volatile("" :: "v"(bx[0]), "v"(bx[1]), "v"(bx[2]), "v"(bx[3]), "v"(by[0]), "v"(by[1]), "v"(by[2]), "v"(by[3]));
+        MF_EXP_STAMP(exp_t2);
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the window has landed in LDS
+        MF_EXP_STAMP(exp_t3);
         uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
 #ifndef MF_NO_COMPACT
         const uint3 d = (rg & MF_REGION_COMPACT) ? gather_blend_staged<MF_COMPACT_PITCH>(bx, by, lds_origin) : gather_blend_staged(bx, by, lds_origin);
 #else
         const uint3 d = gather_blend_staged(bx, by, lds_origin);
+#endif
+#ifdef MF_EXP_PHASES
+        asm volatile("" :: "v"(d.x), "v"(d.y), "v"(d.z));
+        MF_EXP_STAMP(exp_t4);
+        if ((fp & 63u) == 0u && lane == 0) {
+            atomicAdd(&mf_exp_phase[0], 1ull);
+            atomicAdd(&mf_exp_phase[1], exp_t1 - exp_t0);
+            atomicAdd(&mf_exp_phase[2], exp_t2 - exp_t1);
+            atomicAdd(&mf_exp_phase[3], exp_t3 - exp_t2);
+            atomicAdd(&mf_exp_phase[4], exp_t4 - exp_t3);
+        }
 #endif
         *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;     // (STAGED implies W % 4 == 0)
         return;
@@ -647,6 +702,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         // clamping, no per-tap selects (cv2.remap BORDER_CONSTANT, mfs.py:1063-1069).  Pixels the cell does not cover get the border
         // colour (the map template's (W+1, H+1), mfs.py:983-984) and take no part in the crop scan; a pixel inside the float32 error
         // band of an edge sends the wavefront to the general code.
+        if (MF_EXP_SKIP & 2) return;
         const uint32_t k0 = pv.x & 0xFFFu;
         uint32_t cov = 0xFu;
         bool decided = true;
@@ -755,6 +811,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         // config 3): the later cell wins wherever ONE of its mask edges passes -- one float32 fma per pixel -- and the other cell
         // owns what is left; denominators, window and interior as on the hot path.  Both inverse homographies go to LDS by
         // global->LDS DMA (one 80-byte load per cell, scalar base address), and every pixel reads its owner's row.
+        if (MF_EXP_SKIP & 4) return;
         const uint32_t k0 = pv.x & 0xFFFu, k1 = (pv.x >> 16) & 0xFFFu;
         if (lane < 20) {
             uint32_t lo4 = (uint32_t)lane << 2;
@@ -864,6 +921,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         // Two to four cells, each MIXED one with one or two coded mask edges (the four cells around a mesh vertex, three of them, or a
         // pair the pair path did not take); window, interior and denominators certified, coverage not: a pixel that no listed cell
         // takes -- or one inside the float32 error band of an edge -- sends the wavefront to the general code.
+        if (MF_EXP_SKIP & 8) return;
         const int ne = (int)((pv.z >> MF_PLAN_COUNT_SHIFT) & 3u) + 1;
         if (lane < 20) {
             uint32_t lo4 = (uint32_t)lane << 2;
@@ -952,6 +1010,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     }
 
     // Everything else: more candidate cells, uncertified denominators, frame borders, uncovered pixels.
+    if (!SCAN && (MF_EXP_SKIP & 16)) return;
     uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
     const uint32_t limit = (int)f == n - 1 ? g.frame_bytes : 0xFFFFFFFFu;   // only the last frame has nothing behind it
     const float fWm1 = (float)(W - 1), fHm1 = (float)(H - 1);
@@ -1399,6 +1458,17 @@ __global__ __launch_bounds__(64) void crop_scan_kernel(const FootPlan* __restric
         __builtin_amdgcn_wave_barrier();             // (the next footprint reuses the wavefront's s_hi rows)
     }
 }
+
+#ifdef MF_EXP_PHASES
+}  // namespace mf
+extern "C" int mf_exp_phase_read(unsigned long long out[8], int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mf::mf_exp_phase), 8 * sizeof(unsigned long long)) != hipSuccess) return -2;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mf::mf_exp_phase), z, sizeof z) != hipSuccess) return -2; }
+    return 0;
+}
+namespace mf {
+#endif
 
 // Self-test of recip_unit_range against IEEE division: counts mismatching bit patterns.
 __global__ void selftest_recip_kernel(unsigned long long n, unsigned long long seed, unsigned long long* mismatches)
