@@ -27,7 +27,7 @@ __device__ static bool square_to_quad(const double p0[2], const double p1[2], co
     const double dx1 = p1[0] - p2[0], dx2 = p3[0] - p2[0];
     const double dy1 = p1[1] - p2[1], dy2 = p3[1] - p2[1];
     const double den = dx1 * dy2 - dx2 * dy1;
-    const bool ok = den != 0.0;
+    const bool ok = fabs(den) > 1e-10;            // (p1, p2, p3 collinear; the caller normalises the points: coordinates of O(1))
     const double g = (sx * dy2 - dx2 * sy) / den;
     const double h = (dx1 * sy - sx * dy1) / den;
     S[0] = (p1[0] - p0[0]) + g * p1[0]; S[1] = (p3[0] - p0[0]) + h * p3[0]; S[2] = p0[0];
@@ -83,6 +83,12 @@ __device__ static bool homography4(const double src[8], const double dst[8], dou
     const bool okd = square_to_quad(nm[0], nm[1], nm[3], nm[2], Sd), oks = square_to_quad(nM[0], nM[1], nM[3], nM[2], Ss);
     if (!okd || !oks) return false;
     adjugate3(Ss, As);
+    // Either quad with ANY three corners collinear (not only the three square_to_quad divides by) makes its square -> quad map singular:
+    // det = first row . first column of the adjugate; the normalised coordinates are O(1), so 1e-10 is "no area" (round 1-3's 8 x 8
+    // elimination met a zero pivot there).  Same operations in the oracles: the same decision.
+    const double det_s = (Ss[0] * As[0] + Ss[1] * As[3]) + Ss[2] * As[6];
+    const double det_d = (Sd[0] * (Sd[4] - Sd[5] * Sd[7]) + Sd[1] * (Sd[5] * Sd[6] - Sd[3])) + Sd[2] * (Sd[3] * Sd[7] - Sd[4] * Sd[6]);
+    if (!(fabs(det_s) > 1e-10) || !(fabs(det_d) > 1e-10)) return false;
     matmul3(Sd, As, H0);
     double Ht[9], Hd[9];
     matmul3(invHnorm, H0, Ht);

@@ -229,6 +229,8 @@ struct WarpGeom {
     uint32_t div_m, div_s, div_pass;             // t / nfx = (mulhi(t, div_m) + (t & div_pass)) >> div_s
     uint32_t frame_bytes, row_bytes;             // 3 W H, 3 W
     uint32_t rec_frame_bytes, edge_frame_bytes;  // R C records / edge sets of one frame
+    uint32_t cell_mul_x, cell_mul_y, mesh_cols, cell_last;   // the cell under a pixel of the UNWARPED grid: (mulhi(x, cell_mul_x), mulhi(y, cell_mul_y));
+                                                 // row length C; R C - 1 (the speculative matrix load of the hot path, warp.hip)
 };
 
 // Launchers (defined next to their kernels).

@@ -52,6 +52,7 @@
 #include "mf_common.h"
 #include <stdlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <type_traits>
 
@@ -577,6 +578,24 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     const uint32_t ty = (__umulhi(t, g.div_m) + (t & g.div_pass)) >> g.div_s, tx = t - ty * g.nfx;
     const int xa = (int)(tx * (uint32_t)FOOT_W), ya = (int)(ty * (uint32_t)FOOT_H);
     const int lane = threadIdx.x;
+#ifndef MF_NO_SPECMAT
+    // SPECULATIVE matrix load.  A hot wavefront's life starts with three DEPENDENT scalar round trips -- kernel arguments, plan + region
+    // words, the owner's inverse homography -- a quarter of its life (profiles/r05_phase_profile_cfg2.txt).  The owner of a hot footprint
+    // is almost always the cell under the footprint's centre in the unwarped grid, which needs no plan: its matrix is requested HERE,
+    // together with the plan words, and is there when they are.  The plan decides; a wrong guess (the neighbour cell owns the footprint,
+    // or it is not hot at all) costs one unused 72-byte scalar load.  Inline asm: the compiler would sink the loads to their only use,
+    // behind the plan's round trip; it does not know about them, so the hot path waits for them itself (spec_wait) before the first use.
+    typedef uint32_t spec16_t __attribute__((ext_vector_type(16)));
+    typedef uint32_t spec2_t __attribute__((ext_vector_type(2)));
+    spec16_t hg_lo;
+    spec2_t hg_hi;
+    const uint32_t k_guess = SCAN ? 0u : min(__umulhi((uint32_t)ya + FOOT_H / 2, g.cell_mul_y) * g.mesh_cols + __umulhi((uint32_t)xa + FOOT_W / 2, g.cell_mul_x), g.cell_last);
+    if (!SCAN) {
+        const uint64_t gaddr = (uint64_t)(uintptr_t)records + ((uint64_t)f * g.rec_frame_bytes + (uint64_t)k_guess * (uint32_t)(MF_CELL_DOUBLES * sizeof(double)));
+        static_assert(MF_CELL_OFF_HI * sizeof(double) == 0x48 && MF_CELL_DOUBLES * sizeof(double) == 256, "offsets in the asm below");
+        asm volatile("s_load_dwordx16 %0, %2, 0x48\n\ts_load_dwordx2 %1, %2, 0x88" : "=&s"(hg_lo), "=&s"(hg_hi) : "s"(gaddr));     // (early clobber: the address pair is read by both loads)
+    }
+#endif
     const uint32_t fp = f * g.per_frame + t;                              // the footprint's slot in plan / regions
     typedef const __attribute__((address_space(4))) uint32_t* cword_t;
     const cword_t pw = (cword_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(plan) + 16u * fp);
@@ -660,7 +679,25 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
 #endif
         float u[4], v[4];
 #ifndef MF_NO_FAST64
+#ifndef MF_NO_SPECMAT
+        bool have_coords = false;
+        if ((pv.x >> 16) & MF_PLAN_FAST64) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hg_lo), "+s"(hg_hi));      // (the speculative load: long there -- the plan words came behind it)
+            double Hi[9];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Hi[i] = __hiloint2double((int)hg_lo[2 * i + 1], (int)hg_lo[2 * i]);
+            Hi[8] = __hiloint2double((int)hg_hi[1], (int)hg_hi[0]);
+            if ((pv.x & 0xFFFu) != k_guess) {                             // (wave-uniform: the guess was the wrong cell)
+                const crec_t rec = frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Hi[i] = rec[MF_CELL_OFF_HI + i];
+            }
+            have_coords = coords_fast(Hi, xs0, yy, u, v);
+        }
+        if (!have_coords)
+#else
         if (!((pv.x >> 16) & MF_PLAN_FAST64) || !cell_coords_fast(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy, u, v))
+#endif
 #endif
         cell_coords<false>(frec + (pv.x & 0xFFFu) * MF_CELL_DOUBLES, xs0, yy, x0, 0xFu, u, v, true);
         uint32_t bx[4], by[4];
@@ -1629,6 +1666,11 @@ static uint32_t make_warp_geom(int W, int H, int R, int C, WarpGeom& g)
     g.row_bytes = 3u * (uint32_t)W;
     g.rec_frame_bytes = (uint32_t)(R * C) * (uint32_t)(MF_CELL_DOUBLES * sizeof(double));
     g.edge_frame_bytes = (uint32_t)(R * C) * (uint32_t)(MF_EDGE_FLOATS * sizeof(float));
+    // cell column under pixel x of the unwarped grid ~ floor(x C / (W - 1)) = mulhi(x, 2^32 C / (W - 1)) (a guess: the plan decides)
+    g.cell_mul_x = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)C) << 32) / (uint64_t)(W - 1));
+    g.cell_mul_y = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)R) << 32) / (uint64_t)(H - 1));
+    g.mesh_cols = (uint32_t)C;
+    g.cell_last = (uint32_t)(R * C - 1);
     const uint64_t cap = 0xFFFFFFFFull;
     uint64_t per_launch = 65535;
     per_launch = per_launch < cap / (16ull * g.per_frame) ? per_launch : cap / (16ull * g.per_frame);

@@ -236,7 +236,7 @@ def _square_to_quad(p0, p1, p2, p3):
     dx1 = p1[0] - p2[0]; dx2 = p3[0] - p2[0]
     dy1 = p1[1] - p2[1]; dy2 = p3[1] - p2[1]
     den = dx1 * dy2 - dx2 * dy1
-    if den == 0.0:
+    if not abs(den) > 1e-10:                 # p1, p2, p3 collinear (the caller normalises the points: coordinates of O(1))
         return None
     g = (sx * dy2 - dx2 * sy) / den
     h = (dx1 * sy - sx * dy1) / den
@@ -308,7 +308,14 @@ def find_homography_4pt(src_pts, dst_pts, solver='closed'):
         s_src = _square_to_quad(nM[0], nM[1], nM[3], nM[2])
         if s_dst is None or s_src is None:
             return None
-        H0 = np.array(_matmul3([s_dst[0:3], s_dst[3:6], s_dst[6:9]], _adjugate3(s_src)))
+        adj_src = _adjugate3(s_src)
+        # either quad with ANY three corners collinear: its square -> quad map is singular (normalised coordinates are O(1); the same
+        # operations, hence the same decision, as oracle/warp_oracle.c and csrc/cell_table.hip)
+        det_s = (s_src[0] * adj_src[0][0] + s_src[1] * adj_src[1][0]) + s_src[2] * adj_src[2][0]
+        det_d = (s_dst[0] * (s_dst[4] - s_dst[5] * s_dst[7]) + s_dst[1] * (s_dst[5] * s_dst[6] - s_dst[3])) + s_dst[2] * (s_dst[3] * s_dst[7] - s_dst[4] * s_dst[6])
+        if not abs(det_s) > 1e-10 or not abs(det_d) > 1e-10:
+            return None
+        H0 = np.array(_matmul3([s_dst[0:3], s_dst[3:6], s_dst[6:9]], adj_src))
     elif solver == 'gauss':
         h = solve8_partial_pivot(L[:, :8], -L[:, 8])
         if h is None:

@@ -87,7 +87,7 @@ static int square_to_quad(const double p0[2], const double p1[2], const double p
     const double dx1 = p1[0] - p2[0], dx2 = p3[0] - p2[0];
     const double dy1 = p1[1] - p2[1], dy2 = p3[1] - p2[1];
     const double den = dx1 * dy2 - dx2 * dy1;
-    if (den == 0.0) return 0;
+    if (!(fabs(den) > 1e-10)) return 0;          /* p1, p2, p3 collinear (normalised coordinates: O(1)) */
     const double g = (sx * dy2 - dx2 * sy) / den;
     const double h = (dx1 * sy - sx * dy1) / den;
     S[0] = (p1[0] - p0[0]) + g * p1[0]; S[1] = (p3[0] - p0[0]) + h * p3[0]; S[2] = p0[0];
@@ -146,6 +146,11 @@ int mfo_find_homography_4pt(const double src[8], const double dst[8], double H[9
     double Sd[9], Ss[9], As[9], H0[9];
     if (!square_to_quad(nm[0], nm[1], nm[3], nm[2], Sd) || !square_to_quad(nM[0], nM[1], nM[3], nM[2], Ss)) return 0;
     adjugate3(Ss, As);
+    {   /* either quad with ANY three corners collinear: its square -> quad map is singular (normalised coordinates are O(1)) */
+        const double det_s = (Ss[0] * As[0] + Ss[1] * As[3]) + Ss[2] * As[6];
+        const double det_d = (Sd[0] * (Sd[4] - Sd[5] * Sd[7]) + Sd[1] * (Sd[5] * Sd[6] - Sd[3])) + Sd[2] * (Sd[3] * Sd[7] - Sd[4] * Sd[6]);
+        if (!(fabs(det_s) > 1e-10) || !(fabs(det_d) > 1e-10)) return 0;
+    }
     matmul3(Sd, As, H0);
     double Ht[9], Hd[9];
     matmul3(invHnorm, H0, Ht);

@@ -420,6 +420,32 @@ def test_degenerate_mesh_is_reported(dev):
         _hip_warp(dev, frames, R, C, z, s)
 
 
+@pytest.mark.parametrize('moved,onto', [('TL', ('TR', 'BL')), ('TL', ('TR', 'BR')), ('BR', ('TR', 'BL')), ('TR', ('TL', 'BR'))])
+def test_three_collinear_corners_are_degenerate_whichever_corner(dev, moved, onto):
+    """one cell of one frame gets a corner moved onto the line through two others (the triple may include the TL corner: the
+    closed-form solver's own denominator only sees TR, BR, BL): the cell table counts it, the C oracle flags the same cells."""
+    from meshflow_amd import ops
+    from oracle import clib
+    H, W, R, C = 96, 128, 4, 4
+    gx = np.array([np.ceil((W - 1) * c / C) for c in range(C + 1)])
+    gy = np.array([np.ceil((H - 1) * r / R) for r in range(R + 1)])
+    pos = {'TL': (1, 1), 'TR': (1, 2), 'BL': (2, 1), 'BR': (2, 2)}                      # (row, col) of the corners of cell (1, 1)
+    z = np.zeros((1, R + 1, C + 1, 2))
+    s = z.copy()
+    (ra, ca), (rb, cb), (rm, cm) = pos[onto[0]], pos[onto[1]], pos[moved]
+    a, b = np.array([gx[ca], gy[ra]]), np.array([gx[cb], gy[rb]])
+    target = a + 0.5 * (b - a)
+    s[0, rm, cm] = target - np.array([gx[cm], gy[rm]])                                  # stabilized = grid + (stab - unstab)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    table = ops.cell_table(t(z), t(s), W, H, R, C)
+    torch.cuda.synchronize()
+    bad = int(table.status.item())
+    _, want_bad = clib.cell_table(W, H, R, C, z[0], s[0])
+    assert bad == want_bad and bad >= 1
+    with pytest.raises(ValueError, match='degenerate'):
+        table.check()
+
+
 def test_stabilizer_class_end_to_end(dev):
     """The drop-in boundary with the reference's own signatures (host buffers in and out)."""
     from meshflow_amd import synthetic

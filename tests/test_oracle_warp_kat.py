@@ -117,6 +117,31 @@ def test_find_homography_maps_the_four_points_and_matches_the_eigen_route():
     assert mo.find_homography_4pt([[0, 0], [0, 0], [0, 0], [0, 0]], [[0, 0], [1, 0], [0, 1], [1, 1]]) is None
 
 
+@pytest.mark.parametrize('triple', [(0, 1, 2), (0, 1, 3), (0, 2, 3), (1, 2, 3)])
+def test_find_homography_refuses_any_three_collinear_corners(triple):
+    """a quad with ANY three corners on a line has no homography (the 8 equations are rank deficient) -- also when the
+    triple includes the TL corner, which the closed form's own denominator does not look at.  NumPy and C oracle agree, for a
+    degenerate destination and for a degenerate source."""
+    rect = np.array([[10, 20], [130, 20], [10, 88], [130, 88]], dtype=np.float32)          # TL, TR, BL, BR
+    a, b, c = triple
+    bad = rect.copy()
+    bad[c] = bad[a] + 0.5 * (bad[b] - bad[a])                    # the third corner onto the line through the other two (exact in float32)
+    assert mo.find_homography_4pt(rect, bad) is None and mo.find_homography_4pt(bad, rect) is None
+    assert clib.find_homography_4pt(rect, bad) is None and clib.find_homography_4pt(bad, rect) is None
+    # one float32 ulp off the line is a (wild but well-defined) homography again, as it is for cv2.findHomography: only a system without
+    # a unique solution is refused
+    off = bad.copy()
+    off[c, 1] = np.nextafter(off[c, 1], np.float32(1e9)) if bad[a, 0] != bad[b, 0] else off[c, 1]
+    off[c, 0] = np.nextafter(off[c, 0], np.float32(1e9)) if bad[a, 0] == bad[b, 0] else off[c, 0]
+    assert mo.find_homography_4pt(rect, off) is not None and clib.find_homography_4pt(rect, off) is not None
+    good = rect + np.array([[1.5, -0.5], [-2, 1], [0.5, 2], [3, -1]], dtype=np.float32)     # an ordinary quad still solves
+    assert mo.find_homography_4pt(rect, good) is not None and clib.find_homography_4pt(rect, good) is not None
+    # (the elimination solver kept as a cross-check returns the SINGULAR matrix of such a system -- what cv2.findHomography would hand to
+    # cv2.warpPerspective, whose inverse is then the zero matrix: the closed form and the kernel report the cell as degenerate instead)
+    sing = mo.find_homography_4pt(rect, np.array([[10, 20], [70, 20], [130, 20], [130, 88]], np.float32), solver='gauss')
+    assert sing is None or abs(np.linalg.det(sing)) < 1e-9
+
+
 def test_invert3x3_closed_form():
     g = np.random.default_rng(1)
     for _ in range(20):
