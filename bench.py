@@ -487,6 +487,24 @@ class KernelPath:
                 'note': 'the same K steps with every kernel of a clip in order on ONE stream (Jacobi -> cell table + plan -> warp + scan '
                         '-> reduce), no overlap inside or across clips: the figure comparable with rounds 1-2'}
 
+    def warp_alone_ms(self, d_stab, reps=8):
+        """The warp kernel with NOTHING beside it (cell table + plan once, then `reps` launches between two events), outside any timed
+        region: what the in-pipeline launch time is to be read against when a long sweep shares the chip with the warp (gate 'plan')."""
+        import torch
+        from meshflow_amd import ops
+        lo, hi = self.range
+        table = ops.cell_table(self.d_disp[lo:hi], d_stab[lo:hi], self.W, self.H, self.R, self.C)
+        for _ in range(3):
+            ops.warp(self.d_frames, table, self.stab.color_outside_image_area_bgr, out=self.d_out)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            ops.warp(self.d_frames, table, self.stab.color_outside_image_area_bgr, out=self.d_out)
+        b.record()
+        torch.cuda.synchronize()
+        table.check()
+        return a.elapsed_time(b) / reps
+
     def jacobi_kernel_ms(self, omega, iters, reps=5):
         """The sweep kernel alone (the per-step figure includes the host-side coefficient set-up), outside any timed region."""
         import torch
@@ -523,11 +541,17 @@ def other_workload(name, device, steps, pcie_peak):
     m = kp.measure(steps, 3, False, sync, lambda t: t)
     warp_ms = float(np.mean([a.elapsed_time(b) for a, b in m['ev']]))
     jac_ms, jac_flops, series = kp.jacobi_kernel_ms(omega, iters)
+    gate = stab._sweep_gate(d_disp)
+    alone_ms = kp.warp_alone_ms(m['d_stab'])
     algo = 2.0 * H * W * 3 * F
     res = {'config': f'{W}x{H}, {F} frames, {R}x{C} mesh, omega={omega}, {iters} Jacobi sweeps', 'steps': steps,
            'ms_per_step': m['elapsed'] / steps * 1e3, 'value': F * steps / m['elapsed'], 'unit': 'frames/s',
            'warp': {'avg_launch_ms': warp_ms, 'algorithmic_bytes_per_launch': algo, 'achieved': algo / (warp_ms * 1e-3) / 1e9, 'unit': 'GB/s',
-                    'frac': algo / (warp_ms * 1e-3) / HBM_PEAK_BYTES_PER_S},
+                    'frac': algo / (warp_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
+                    'beside_the_warp': ('the next clip\'s Jacobi sweep (prep stream, gate "plan": a sweep this long is cheaper beside the warp than beside '
+                                        'cell table + plan)' if gate == 'plan' else 'nothing'),
+                    'alone': {'avg_launch_ms': alone_ms, 'frac': algo / (alone_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
+                              'note': 'the same launch with nothing beside it, 8 launches between two events outside the timed steps'}},
            'jacobi': {'kernel_ms': jac_ms, 'achieved': jac_flops / (jac_ms * 1e-3) / 1e12, 'unit': 'TFLOP/s', 'frac': jac_flops / (jac_ms * 1e-3) / 78.6e12,
                       'series': series},
            'crop_bounds': [int(v) for v in m['bounds'].tolist()]}
@@ -676,6 +700,8 @@ def main():
     if args.rectangle:
         stab.resident_rectangle = args.rectangle   # 'early': the rectangle from the table on the prep stream (the all-reduce of a sharded clip
                                                    # then runs beside the warp); the default takes it from the warp's own scan, behind the warp
+    if os.environ.get('MF_RESIDENT_GATE'):                       # tuning aid
+        stab.resident_gate = os.environ['MF_RESIDENT_GATE']
     serial_mode = args.pipeline == 'serial'
     kp = KernelPath(stab, d_frames, d_disp, hom, F, (lo, hi), W, H, R, C, device, collective=(world > 1 and not clips_mode), no_events=no_events)
     m = kp.measure(args.steps, args.warmup, serial_mode, barrier, max_over_ranks)
@@ -691,6 +717,7 @@ def main():
         extra['serial'] = kp.serial(args.steps, max(args.warmup, 3))
 
     warp_ms = float('nan') if no_events else float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    warp_alone = kp.warp_alone_ms(m['d_stab']) if (not serial_mode and stab._sweep_gate(d_disp) == 'plan') else None
     if os.environ.get('MF_BENCH_PER_STEP') and rank == 0 and not no_events:          # tuning aid: the launches one by one (clock transients)
         print('warp ms per step:', [round(a.elapsed_time(b), 3) for a, b in ev], file=sys.stderr)
     jac_ms = float('nan') if no_events else float(np.mean([a.elapsed_time(b) for a, b in jev]))
@@ -816,6 +843,7 @@ def main():
                          'traffic': traffic, 'traffic_source': 'profiles/traffic.json (PMC: size-resolved TCC_EA0_RDREQ read requests + WRITE_SIZE)'
                          if traffic else None,
                          'algorithmic_bytes_per_launch': algo_bytes, 'avg_launch_ms': warp_ms,
+                         'beside_the_warp': 'nothing' if (serial_mode or stab._sweep_gate(d_disp) != 'plan') else 'the next clip\'s Jacobi sweep (prep stream, gate "plan")',
                          'launches': (1 if serial_mode or stab.resident_chunks <= 0 else min(stab.resident_chunks, hi - lo)),
                          'launch_note': ('HIP events on the stream the warp kernel is launched on, directly in front of and behind it (nothing runs beside it in this '
                                          'arrangement)' if (serial_mode or stab.resident_chunks <= 0) else
@@ -823,7 +851,9 @@ def main():
                                          'last of its `launches` warp kernels (frame ranges of the clip), so the figure includes the gaps between them and '
                                          'the prep-stream kernels (next clip\'s sweep, tables, crop scan) sharing the chip; the kernel trace under profiles/ '
                                          'gives the kernels alone'),
-                         'note': 'bound by vector and scalar instruction issue (float64 coordinates, integer blend, one wavefront per 32x8 footprint), not by HBM: DESIGN.md 4.3'},
+                         'note': 'bound by vector and scalar instruction issue (float64 coordinates, integer blend, one wavefront per 32x8 footprint), not by HBM: DESIGN.md 4.3',
+                         **({'alone': {'avg_launch_ms': warp_alone, 'frac': algo_bytes / (warp_alone * 1e-3) / HBM_PEAK_BYTES_PER_S,
+                                       'note': 'the same launch with nothing beside it, 8 launches between two events outside the timed steps'}} if warp_alone else {})},
             'jacobi': {'avg_ms_in_pipeline': jac_ms, 'on_prep_stream': not serial_mode, 'kernel_ms': jac_kernel_ms,
                        'note': 'avg_ms_in_pipeline: HIP events around the stage (coefficient upload + sweep) on the stream it is issued on -- on the prep '
                                'stream it shares the chip with the previous clip\'s warp, so this is NOT the kernel\'s own time; kernel_ms: the kernel alone, measured after the timed region', 'series': jac_series, 'frames': F,

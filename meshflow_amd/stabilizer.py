@@ -443,6 +443,12 @@ class MeshFlowStabilizer:
     #      table(j) only): the rectangle is known earliest, the clip takes 2-8 % longer.
     resident_chunks = 0
     resident_rectangle = 'fused'     # 'early': rectangle from the table on the prep stream (a sharded run's all-reduce hides behind the warp)
+    # What the NEXT clip's sweep (prep stream) waits for.  'table': this clip has reached its cell table -- a short sweep (config 2: 48 us)
+    # then runs beside cell table + plan (~100 us, both leave most of the chip idle) and nothing runs beside the warp.  'plan': this clip's
+    # plan has ended -- a LONG sweep (config 3: 0.65 ms of float64 FMAs on every SIMD) beside cell table + plan makes those take 0.7 + 0.4 ms
+    # instead of 0.05 + 0.2; beside the first part of the warp it costs the warp what it takes itself, and the step is 7.5 % shorter
+    # (3.73 -> 3.45 ms; config 2: 1.277 -> 1.269).  'auto': 'plan' from 4 GFLOP of sweep on.
+    resident_gate = 'auto'
     resident_table_shapes = 4        # cell tables are kept for this many (W, H, mesh) geometries (two tables each, grow-only in the clip length)
 
     def _resident_state(self, dev):
@@ -514,6 +520,12 @@ class MeshFlowStabilizer:
         st['turn'] += 1
         return slot
 
+    def _sweep_gate(self, d_disp):
+        if self.resident_gate != 'auto':
+            return self.resident_gate
+        flops = float(self.optimization_num_iterations) * d_disp.shape[0] * (d_disp.numel() // d_disp.shape[0]) * (4 * self.temporal_smoothing_radius + 5)
+        return 'plan' if flops >= 4e9 else 'table'
+
     def _resident_jacobi(self, d_disp, frame_width, frame_height, adaptive_weights_definition, homographies, inputs_ready=None):
         """Stage 1 of the resident pipeline, on the prep stream: mfs.py:632-710.  `inputs_ready`: a torch.cuda.Event after which
         d_disp (and the frames) are valid, or None = whatever is queued on the current stream right now (safe, but then this clip's
@@ -533,7 +545,11 @@ class MeshFlowStabilizer:
         # 1.68 ms per step against 1.54 in order); left ungated, the queued sweeps of several clips fill the chip together (1.48).
         radius = self.temporal_smoothing_radius
         one_wave = d_disp.shape[0] <= 64 * (5 if radius <= 12 else 8 if radius <= 20 else 10)
-        if self.resident_chunks <= 0 and one_wave and len(st['ends']) >= 2:
+        gate = self._sweep_gate(d_disp)
+        st['gate'] = gate
+        if self.resident_chunks <= 0 and one_wave and gate == 'plan' and st.get('planned') is not None:
+            prep.wait_event(st['planned'])        # the previous clip's cell table + plan have ended: a LONG sweep runs beside its warp
+        elif self.resident_chunks <= 0 and one_wave and len(st['ends']) >= 2:
             prep.wait_event(st['ends'][-2])       # the warp two clips back has ended = the previous clip has reached its cell table
         with torch.cuda.stream(prep):
             d_stab = self._stabilized_vertex_displacements_device(d_disp, frame_width, frame_height, adaptive_weights_definition, homographies)
@@ -565,6 +581,9 @@ class MeshFlowStabilizer:
             # on, as the gate of a sweep)
             # (the same launches as mf_warp_clip_u8c3 with chunks = 0, issued from here so that the warp kernel can be bracketed)
             ops.cell_table(d_unstab, d_stab, W, H, self.mesh_row_count, self.mesh_col_count, table=table, reset_status=False, bounds=bounds)
+            if st.get('gate') == 'plan':
+                st['planned'] = torch.cuda.Event()
+                st['planned'].record(main)
             early = self.resident_rectangle == 'early'
             if early:                                             # rectangle from the table, on the prep stream, beside the start of the warp
                 tabled = torch.cuda.Event()

@@ -12,7 +12,7 @@ SHAPES = {'cfg2': (300, 1920, 1080, '16x16', 1), 'cfg4shard': (150, 3840, 2160, 
 METHOD = ('reads = 128*TCC_EA0_RDREQ_128B + 64*TCC_EA0_RDREQ_64B + 32*TCC_EA0_RDREQ_32B (sum over channels): checked on tools/calib_fetch.hip '
           'calib_wide16, where it returns the 1,866,240,000 bytes read exactly; the derived FETCH_SIZE tallies every request at 64 B on gfx950 '
           'and reads half of that (the guide\'s x2 rule). writes = WRITE_SIZE (KiB, exact on the same calibration kernel). Separate --pmc '
-          'passes (tools/profile_r04.sh), per launch of mf::warp_kernel, at the HEAD kernels.')
+          'passes (tools/profile_r05.sh), per launch of mf::warp_kernel, at the HEAD kernels.')
 
 
 def main():
