@@ -277,10 +277,12 @@ static int sweep_launches(const double* b, double* x, int F, int S, int iters, i
 static int launch_jacobi_tiled(const double* b, double* x, const double* taps, const double* lam, const double* inv_on,
                                int F, int S, int omega, int iters, hipStream_t st)
 {
-    constexpr int K = MF_JACOBI_TILE_K, WAVES = MF_JACOBI_TILE_WAVES, LEN = MF_JACOBI_TILE_LEN;
-    const int ks_max = (LEN / 4) / omega > 1 ? (LEN / 4) / omega : 1;
+    constexpr int K = MF_JACOBI_TILE_K, WAVES = MF_JACOBI_TILE_WAVES;
     const char* fr = getenv("MF_JACOBI_RUNTIME");                     // testing aid, read at every call: the run-time-radius form
     const bool force_runtime = fr && *fr == '1';
+    const int spec_len = force_runtime ? 0 : jacobi_tiled_spec_len(omega);
+    const int LEN = spec_len > 0 ? spec_len : MF_JACOBI_TILE_LEN;       // frames a tile holds: the specialised kernel's, or the run-time-radius form's
+    const int ks_max = (LEN / 4) / omega > 1 ? (LEN / 4) / omega : 1;
     return sweep_launches(b, x, F, S, iters, ks_max, st, [&](const double* src, double* dst, int ks) {
         JacobiTile tile;
         tile.x_in = src;
@@ -290,7 +292,7 @@ static int launch_jacobi_tiled(const double* b, double* x, const double* taps, c
         const int ntiles = (F + t_max - 1) / t_max;
         tile.T = (F + ntiles - 1) / ntiles;                           // (evened out: every tile costs the same whatever it writes)
         if (ntiles > 65535) { set_error("mf_jacobi_f64: F=%d needs %d time tiles (> 65535)", F, ntiles); return (int)MF_ERR_INVALID_ARG; }
-        if (!force_runtime) {
+        if (spec_len > 0) {
             const int rc = launch_jacobi_tiled_spec(b, dst, taps, lam, inv_on, F, S, omega, ks, tile, ntiles, st);
             if (rc != MF_JACOBI_NOT_HERE) return rc;
         }

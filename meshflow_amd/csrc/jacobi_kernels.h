@@ -266,6 +266,8 @@ int jacobi_simd_count();
 #define MF_JACOBI_TILE_LEN (64 * MF_JACOBI_TILE_WAVES * MF_JACOBI_TILE_K)
 int launch_jacobi_tiled_spec(const double* b, double* x, const double* taps, const double* lam, const double* inv_on, int F, int S, int omega,
                              int iters, const JacobiTile& tile, int ntiles, hipStream_t st);
+// Frames a tile of the specialised kernel for `omega` holds (0: none -- the run-time-radius form with MF_JACOBI_TILE_LEN frames takes it).
+int jacobi_tiled_spec_len(int omega);
 
 // jacobi_spec.hip, compiled once per group of radii (MF_JACOBI_GROUP = 0..3, radii 8 g + 1 .. 8 g + 8): launches the
 // kernel specialised for `omega` and the clip length, or returns MF_JACOBI_NOT_HERE when omega / F is not in its table.

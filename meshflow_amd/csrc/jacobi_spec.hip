@@ -80,11 +80,25 @@ int MF_CAT(launch_jacobi_spec_g, MF_JACOBI_GROUP)(const double* b, double* x, co
 // The tiled form (clips beyond 64 x 8 x 19 frames, jacobi_kernels.h) of the radii the BASELINE configs use; every other radius takes
 // jacobi.hip's run-time-radius tiled kernel.  Defined once: in the group that owns radius 10.
 #if MF_JACOBI_GROUP == 1
+// (omega = 30: the 19-frames-per-lane loop spills under its 256-register budget (16-18 TFLOP/s at 20,000 frames); MF_JACOBI_TILE30 = 10
+// takes the 10-frames-per-lane loop on tiles of 5,120 frames instead -- tuning aid, read once)
+static int tile30_k()
+{
+    static const int k = [] { const char* v = getenv("MF_JACOBI_TILE30"); return v && atoi(v) == 19 ? 19 : 10; }();
+    return k;
+}
+int jacobi_tiled_spec_len(int omega)
+{
+    if (omega == 10) return 64 * MF_JACOBI_TILE_WAVES * MF_JACOBI_TILE_K;
+    if (omega == 30) return 64 * MF_JACOBI_TILE_WAVES * tile30_k();
+    return 0;
+}
 int launch_jacobi_tiled_spec(const double* b, double* x, const double* taps, const double* lam, const double* inv_on, int F, int S, int omega,
                              int iters, const JacobiTile& tile, int ntiles, hipStream_t st)
 {
     if (omega == 10) return launch_wave_tiled<10, MF_JACOBI_TILE_K, MF_JACOBI_TILE_WAVES>(b, x, taps, lam, inv_on, F, S, iters, tile, ntiles, st);
-    if (omega == 30) return launch_wave_tiled<30, MF_JACOBI_TILE_K, MF_JACOBI_TILE_WAVES>(b, x, taps, lam, inv_on, F, S, iters, tile, ntiles, st);
+    if (omega == 30 && tile30_k() == 19) return launch_wave_tiled<30, 19, MF_JACOBI_TILE_WAVES>(b, x, taps, lam, inv_on, F, S, iters, tile, ntiles, st);
+    if (omega == 30) return launch_wave_tiled<30, 10, MF_JACOBI_TILE_WAVES>(b, x, taps, lam, inv_on, F, S, iters, tile, ntiles, st);
     return MF_JACOBI_NOT_HERE;
 }
 #endif
