@@ -76,7 +76,12 @@ int mf_stream_synchronize(void* stream);
  * reference's (F, R+1, C+1, 2) arrays).  x_start = b (mfs.py:699-703).  `iters` true Jacobi sweeps of
  *   x_new[t] = inv_on[t] * (b[t] + 2*lam[t] * sum_{d=-omega..omega, 0<=t+d<F} taps[d+omega]*x[t+d])
  * i.e. x <- diag(1/on) (b - off x) with off[t,t+d] = -2*lam[t]*taps[d+omega] (band includes d = 0,
- * mfs.py:767-781).  d_taps: [2*omega+1], d_lam, d_inv_on: [F].  d_b and d_x may not alias. */
+ * mfs.py:767-781).  d_taps: [2*omega+1], d_lam, d_inv_on: [F].  d_b and d_x may not alias.
+ * Any F, any omega (as the reference: mfs.py:193-213 reads every frame of the file): clips of up to 9,728 frames are swept with the
+ * whole time axis of a series in LDS; longer ones in time tiles with a halo of (sweeps per launch) x omega frames -- bit-identical -- which
+ * takes ceil(iters / k) launches and, from the second launch on, ONE scratch array of F*S doubles (hipMallocAsync / hipFreeAsync on
+ * `stream`); radii beyond 246 on such clips go sweep by sweep through global memory.  Every output sums its taps in ascending order from
+ * zero with one fma each, whatever the form. */
 int mf_jacobi_f64(const double* d_b, double* d_x, const double* d_taps, const double* d_lam,
                   const double* d_inv_on, int F, int S, int omega, int iters, void* stream);
 

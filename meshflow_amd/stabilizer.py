@@ -656,7 +656,6 @@ class MeshFlowStabilizer:
             raise ValueError(f'frame_range {lo, hi} does not match {n} frames')
         dev = d_frames.device
         st = self._resident_state(dev)
-        result = {}
 
         def jacobi_fn():
             if jacobi_events:
@@ -667,8 +666,7 @@ class MeshFlowStabilizer:
             return d_stab
 
         def warp_fn(lo_, hi_, d_stab):
-            frames, bounds, table = self._resident_warp(d_frames, d_disp[lo_:hi_], d_stab[lo_:hi_], out=out, warp_events=warp_events, check=check)
-            result['table'] = table
+            frames, bounds, _ = self._resident_warp(d_frames, d_disp[lo_:hi_], d_stab[lo_:hi_], out=out, warp_events=warp_events, check=check)
             return frames, bounds
 
         on_prep = self.resident_chunks > 0 or self.resident_rectangle == 'early'       # the rectangle is final on the prep stream, early
