@@ -24,7 +24,13 @@ from meshflow_amd import _lib, synthetic
 F, H, W, R, C, omega, iters = WORKLOADS[wl]
 import torch
 base = synthetic.frames_torch(4, H, W, torch.device('cuda:0'), seed=0).cpu().numpy()
-frames = [np.ascontiguousarray(base[i % 4]).copy() for i in range(F)]
+if os.environ.get('CONTIG'):               # the frames as rows of ONE array (the pipeline merges adjacent frames into one copy per chunk)
+    whole = np.empty((F, H, W, 3), np.uint8)
+    for i in range(F):
+        whole[i] = base[i % 4]
+    frames = [whole[i] for i in range(F)]
+else:
+    frames = [np.ascontiguousarray(base[i % 4]).copy() for i in range(F)]
 disp, hom = synthetic.motion(F, R, C, seed=0)
 from meshflow_amd.stabilizer import MeshFlowStabilizer
 stab = np.ascontiguousarray(MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=omega, optimization_num_iterations=iters,
