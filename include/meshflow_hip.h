@@ -213,13 +213,14 @@ int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab,
                       int32_t* crop /* [n][4] */, float* kernel_ms);
 /* The same for frames that are separate allocations (the reference's Python lists of per-frame arrays, mfs.py:997, 1100):
  * frames[i] / out[i] point to frame i, H*W*3 bytes each.  mf_warp_u8c3_host is this with frames[i] = frames + i*H*W*3.
- * Both move the clip in chunks of ~50 MB (8 frames at 1080p, 2 at 4K) on four upload and four download threads with their own
- * HIP streams (plus eight threads that fault the output pages in ahead of the downloads) through a RING of 18 chunk buffers per
- * direction -- device memory is O(chunk) whatever the length of the clip (1.8 GB of ring for any 1080p or 4K clip); a chunk is warped
+ * Both move the clip in chunks of ~16 MB (3 frames at 1080p, 1 at 4K) on four upload and four download threads with their own
+ * HIP streams (each takes the next chunk when it is free; plus eight threads that fault the output pages in ahead of the downloads)
+ * through a RING of ~900 MB of chunk buffers per direction (48 slots at 1080p, 36 at 4K) -- device memory is O(chunk) whatever the
+ * length of the clip (1.8 GB of ring for any 1080p or 4K clip); a chunk is warped
  * as soon as it has landed (its cell table + plan are built right in front of its warp) and travels back while later chunks are still
  * going up (pageable memory is fine; memory from mf_malloc_host makes the copies truly asynchronous).  MF_PIPE_CHUNK (frames per
  * chunk) / MF_PIPE_SLOTS / MF_PIPE_UP / MF_PIPE_DOWN / MF_PIPE_POPULATE in the environment retune it
- * (read at every call; MF_PIPE_TRACE=1 prints the call's wall-clock milestones on stderr).  Input and output frames must NOT overlap in memory (MF_ERR_INVALID_ARG): output pages are touched
+ * (read at every call; MF_PIPE_TRACE=1 prints the call's wall-clock milestones on stderr, 2 also every chunk's copy intervals).  Input and output frames must NOT overlap in memory (MF_ERR_INVALID_ARG): output pages are touched
  * while the input is still being read.  Device buffers and streams are kept between calls, grow-only, ONE CACHE PER DEVICE
  * (the calling thread's current device, mf_set_device): calls on one device are serialised, calls on different devices
  * from different host threads run concurrently; mf_host_cache_release() frees all of them. */

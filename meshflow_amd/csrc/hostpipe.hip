@@ -2,10 +2,10 @@
 // _get_stabilized_frames_and_crop_boundaries, mfs.py:909-1108, calls): frames in host memory in, stabilized frames in host
 // memory out, with the PCIe transfers chunked and overlapped with each other and with the kernels.
 //
-// The clip moves in chunks of ~50 MB (8 frames at 1080p, 2 at 4K; MF_PIPE_CHUNK = frames per chunk overrides) through a RING of
-// MF_PIPE_SLOTS (18) chunk-sized device buffers per direction: device memory is O(chunk), whatever the length of the clip (2,000 frames
-// of 1080p and all 1,200 frames of config 4's 4K clip go through 1.8 GB of ring).  UP host threads each own a HIP stream and copy
-// "their" chunks into the ring slot chunk k % slots -- once the download of the chunk that used the slot before has ended (an event
+// The clip moves in chunks of ~16 MB (3 frames at 1080p, 1 at 4K; MF_PIPE_CHUNK = frames per chunk overrides) through a RING of
+// ~900 MB of chunk-sized device buffers per direction (MF_PIPE_SLOTS overrides the slot count): device memory is O(chunk), whatever the
+// length of the clip (2,000 frames of 1080p and all 1,200 frames of config 4's 4K clip go through 1.8 GB of ring).  UP host threads each
+// own a HIP stream and copy the next chunk that has not gone up yet into the ring slot chunk k % slots -- once the download of the chunk that used the slot before has ended (an event
 // wait on the upload stream, no host synchronisation) -- (pageable memory is fine: the runtime stages it; pinned memory --
 // mf_malloc_host -- makes the copies truly asynchronous); the calling thread waits for chunk k's upload event, launches the cell table
 // + plan + warp of that chunk on the compute stream and records an event; DOWN host threads wait for it on their own streams and copy
@@ -27,6 +27,7 @@
 #include <stdio.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -39,12 +40,14 @@
 namespace mf {
 namespace {
 
-// Chunk size and ring depth (measured on MI355X hosts, profiles/r05_e2e_ring.txt; at a fixed ring of ~1.8 GB many small chunks beat few
-// large ones -- the uploads run further ahead of the downloads while the link has nothing to bring back yet, and the ramps at both ends
-// of a clip are shorter: 1080p 16 frames x 8 slots 5,200-5,240 frames/s, 8 x 18 5,470-5,480; 4K 16 frames per chunk 1,160-1,290,
-// 4 x 8 1,290-1,490, 2 x 18 1,410-1,440)
-constexpr size_t PIPE_CHUNK_BYTES = (size_t)50 << 20;    // bytes per chunk: 8 frames at 1080p, 2 at 4K (MF_PIPE_CHUNK = frames overrides)
-constexpr int PIPE_SLOTS = 18;     // ring slots per direction (MF_PIPE_SLOTS): 2 x 18 x 50 MB = 1.8 GB of device memory for a clip of any length
+// Chunk size and ring depth (measured on MI355X hosts, profiles/r05_e2e_ring.txt and r05_pcie_duplex.txt).  A chunk is usable only when
+// all of it has landed, so the downloads trail the uploads by (upload threads x chunk) at both ends of a clip -- with 50 MB chunks 4.5 ms
+// of a 48 ms cfg2 clip at each end -- and small chunks win although their kernels are less efficient (they hide behind the copies):
+// 1080p, interleaved repetitions, frames/s without | with the crop: 8 frames x 18 slots 5,330 | 5,510, 4 x 36 5,480 | 6,040,
+// 3 x 48 5,880 | 6,030, 2 x 64 5,660 | 5,910;  4K 2 x 18 1,570 | 1,510, 1 x 36 1,655 | 1,545.
+constexpr size_t PIPE_CHUNK_BYTES = (size_t)16 << 20;    // bytes per chunk: 3 frames at 1080p, 1 at 4K (MF_PIPE_CHUNK = frames overrides)
+constexpr size_t PIPE_RING_BYTES = (size_t)900 << 20;    // ring per direction: 48 slots at 1080p, 36 at 4K (MF_PIPE_SLOTS overrides), for a clip of any length
+constexpr int PIPE_SLOTS_MAX = 64;
 constexpr size_t PIPE_SCAN_TABLE_BYTES = (size_t)96 << 20;   // scratch table of the rectangle pre-pass: ~330 frames of 1080p at a 16 x 16 mesh per piece
 constexpr int PIPE_UP = 4;         // upload threads / streams   (2/2: 59 ms, 3/3: 64, 4/4: 58, 6/6: 57 per cfg2 clip)
 constexpr int PIPE_DOWN = 4;       // download threads / streams
@@ -220,7 +223,7 @@ int run_host_pipeline(PipeJob job)
     const int by_bytes = (int)std::min<size_t>(4096, std::max<size_t>(1, (PIPE_CHUNK_BYTES + fb / 2) / fb));
     const int cfg_chunk = env_int("MF_PIPE_CHUNK", by_bytes, 1, 4096), cfg_up = env_int("MF_PIPE_UP", PIPE_UP, 1, PIPE_MAX),
               cfg_down = env_int("MF_PIPE_DOWN", PIPE_DOWN, 1, PIPE_MAX), cfg_pop = env_int("MF_PIPE_POPULATE", PIPE_POPULATE, 0, PIPE_MAX),
-              cfg_slots = env_int("MF_PIPE_SLOTS", PIPE_SLOTS, 2, 64);
+              cfg_slots = env_int("MF_PIPE_SLOTS", (int)std::min<size_t>(PIPE_SLOTS_MAX, std::max<size_t>(4, PIPE_RING_BYTES / (fb * cfg_chunk))), 2, PIPE_SLOTS_MAX);
     const int chunk = n < cfg_chunk ? n : cfg_chunk;
     const int nchunks = (n + chunk - 1) / chunk;
     const int slots = nchunks < cfg_slots ? nchunks : cfg_slots;
@@ -309,10 +312,13 @@ int run_host_pipeline(PipeJob job)
     }
 
     // MF_PIPE_TRACE=1: wall-clock milestones of the call on stderr (where a slow host loses its time: page population, uploads, downloads)
-    const bool trace = env_int("MF_PIPE_TRACE", 0, 0, 1) != 0;
+    const int trace_level = env_int("MF_PIPE_TRACE", 0, 0, 2);         // 2: + begin / end of every chunk's copy calls, printed after the call
+    const bool trace = trace_level != 0;
+    std::vector<double> tr_up0(trace_level == 2 ? nchunks : 0), tr_up1(tr_up0.size()), tr_dn0(tr_up0.size()), tr_dn1(tr_up0.size()), tr_k(tr_up0.size());
     const auto t_begin = std::chrono::steady_clock::now();
     const auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     Shared sh;
+    std::atomic<int> next_up{0}, next_down{0};
     sh.up_ready.assign(nchunks, 0);
     sh.warp_ready.assign(nchunks, 0);
     sh.resize_ready.assign(nchunks, 0);
@@ -339,14 +345,18 @@ int run_host_pipeline(PipeJob job)
     for (int t = 0; t < n_up; ++t)
         workers.emplace_back([&, t] {
             if (hipSetDevice(dev) != hipSuccess) { sh.fail(hipErrorInvalidDevice, "hipSetDevice (upload thread)"); return; }
-            for (int k = t; k < nchunks; k += n_up) {
+            // the next chunk to whichever thread is free: the streams do not move data at the same rate (one of them typically runs a copy
+            // in less than half the time the others take beside it, profiles/r05_pcie_duplex.txt) and the kernels take the chunks in order
+            for (int k = next_up.fetch_add(1); k < nchunks; k = next_up.fetch_add(1)) {
                 const int i0 = k * chunk, i1 = chunk_end(k);
                 hipError_t e = hipSuccess;
                 if (k >= slots) {                            // the ring slot is free once the chunk that used it before has gone down
                     if (!sh.wait(sh.down_issued, k - slots)) return;
                     e = hipStreamWaitEvent(pc.up[t], down_done[k - slots], 0);
                 }
+                if (trace_level == 2) tr_up0[k] = since();
                 if (e == hipSuccess) e = copy_frames(slot_in(k), frames, i0, i1, fb, true, pc.up[t]);
+                if (trace_level == 2) tr_up1[k] = since();
                 if (e == hipSuccess) e = hipEventRecord(up_done[k], pc.up[t]);
                 if (e != hipSuccess) { sh.fail(e, "upload of a frame chunk"); return; }
                 sh.mark(sh.up_ready, k);
@@ -358,17 +368,21 @@ int run_host_pipeline(PipeJob job)
     for (int t = 0; t < n_down; ++t)
         workers.emplace_back([&, t] {
             if (hipSetDevice(dev) != hipSuccess) { sh.fail(hipErrorInvalidDevice, "hipSetDevice (download thread)"); return; }
-            for (int k = t; k < nchunks; k += n_down) {
+            for (int k = next_down.fetch_add(1); k < nchunks; k = next_down.fetch_add(1)) {
                 if (out) {
                     if (!sh.wait(sh.warp_ready, k) || !sh.wait(sh.populated, k)) return;
                     hipError_t e = hipStreamWaitEvent(pc.down[t], warp_done[k], 0);
+                    if (trace_level == 2) tr_dn0[k] = since();
                     if (e == hipSuccess) e = copy_frames(slot_out(k), out, k * chunk, chunk_end(k), fb, false, pc.down[t]);
+                    if (trace_level == 2) tr_dn1[k] = since();
                     if (e != hipSuccess) { sh.fail(e, "download of a frame chunk"); return; }
                 }
                 if (cropped) {
                     if (!sh.wait(sh.resize_ready, k) || !sh.wait(sh.populated2, k)) return;
                     hipError_t e = hipStreamWaitEvent(pc.down[t], resize_done[k], 0);
+                    if (trace_level == 2 && !out) tr_dn0[k] = since();
                     if (e == hipSuccess) e = copy_frames(slot_cropped(k), cropped, k * chunk, chunk_end(k), fb, false, pc.down[t]);
+                    if (trace_level == 2) tr_dn1[k] = since();
                     if (e != hipSuccess) { sh.fail(e, "download of a cropped frame chunk"); return; }
                 }
                 if (down_done[k]) {                          // both ring slots of chunk k are free behind this point of the stream
@@ -412,6 +426,7 @@ int run_host_pipeline(PipeJob job)
             sh.mark(sh.resize_ready, k);
         }
         if (kernel_ms) (void)hipEventRecord(t1[k], pc.compute);
+        if (trace_level == 2) tr_k[k] = since();
     }
     if (!sh.abort && job.warp) {
         // per-frame crop values (and, without the early scan, the clip-level rectangle and the degenerate-mesh count) in one wait
@@ -428,6 +443,8 @@ int run_host_pipeline(PipeJob job)
     if (trace) fprintf(stderr, "[mf pipe] %8.2f ms  every chunk's kernels issued\n", since());
     for (auto& w : workers) w.join();
     if (trace) fprintf(stderr, "[mf pipe] %8.2f ms  done (%d frames of %d x %d, %d chunks of %d, %d ring slots)\n", since(), n, W, H, nchunks, chunk, slots);
+    for (size_t k = 0; k < tr_up0.size(); ++k)
+        fprintf(stderr, "[mf pipe] chunk %3zu  up %7.2f .. %7.2f   kernels issued %7.2f   down %7.2f .. %7.2f\n", k, tr_up0[k], tr_up1[k], tr_k[k], tr_dn0[k], tr_dn1[k]);
     if (job.bounds) for (int i = 0; i < 4; ++i) job.bounds[i] = rect[i];
     if (status != 0) {
         (void)hipDeviceSynchronize();
