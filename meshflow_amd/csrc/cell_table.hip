@@ -16,6 +16,10 @@
 // the device between the two halves of the path.
 #include "mf_common.h"
 
+#ifndef MF_PLAN_EXP
+#define MF_PLAN_EXP 0          // 1-3: timing-only builds of the plan kernel (tools/plan_profile.sh); nothing of them is in the product
+#endif
+
 namespace mf {
 
 // Unit square (0,0), (1,0), (1,1), (0,1) -> p0, p1, p2, p3 (Heckbert 1989: the 8 equations of the 4-point problem solved by hand):
@@ -378,6 +382,10 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             }
         }
     overflow = boxed > 8;
+#if MF_PLAN_EXP == 2      // (timing-only build, tools/plan_profile.sh: the candidate shortlist alone)
+    p.e[0] = (uint16_t)boxed; p.e[1] = (uint16_t)shortlist[0]; p.e[2] = (uint16_t)shortlist[1]; region.flags_origin = 0; region.src_dwords = 0;
+    return;
+#endif
     for (int step = 0; step < boxed && !closed && !overflow; ++step) {
         const int k = (int)(((step < 4 ? shortlist[0] : shortlist[1]) >> (16 * (step & 3))) & 0xFFFFu);
         {
@@ -426,6 +434,10 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
         }
     }
     for (int i = 0; i < 4; ++i) { p.e[i] = (uint16_t)(ent[0] >> (16 * i)); p.e[4 + i] = (uint16_t)(ent[1] >> (16 * i)); }
+#if MF_PLAN_EXP == 3      // (timing-only build: shortlist + classification + corner mapping, no certificates / window)
+    region.flags_origin = (uint32_t)(umin + umax + vmin + vmax + wlo_all + whi_all) + (sane ? 1u : 0u) + (coded ? 2u : 0u); region.src_dwords = (uint32_t)codes;
+    return;
+#endif
     if (!overflow && cnt <= 4)
         for (int i = 0; i < 4; ++i) p.e[4 + i] = (uint16_t)(codes >> (16 * i));      // short list: room for the per-entry edge codes
     bool unit1 = false;                                            // ONE listed cell whose denominator allows the reciprocal guess
@@ -684,6 +696,10 @@ __global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __rest
         s_rrange[i] = (uint32_t)lo | (uint32_t)hi << 16;
     }
     __syncthreads();
+#if MF_PLAN_EXP == 1      // (timing-only build: launch + staging + range tables alone)
+    if (s_crange[threadIdx.x] == 0xFFFFFFFFu && s_edge[threadIdx.x] == 1.5f) plan[blockIdx.x].e[0] = 1;
+    return;
+#endif
 #pragma unroll 1
     for (int part = 0; part < MF_PLAN_PER_THREAD; ++part) {
     const int rem = rem0 + part * 256 + (int)threadIdx.x;

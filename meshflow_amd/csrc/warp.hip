@@ -73,8 +73,15 @@ typedef const __attribute__((address_space(4))) float* cedge_t;
 // a multi-wave workgroup keeps the slots of its finished wavefronts until the slowest one -- often on a slower ownership
 // path -- is done: 4 x 1 wavefronts 1.516 ms (cfg2) / 3.410 (cfg3), 2 x 1: 1.505 / 3.392, 1 x 1: 1.492 / 3.326; 4 x 2 and 4 x 4
 // (fewer dispatches) 1.65 / 1.89.
+// (Round 5, at the final kernels -- the launch rate is per WORKGROUP, an empty kernel of 4-wave workgroups launches 4 x as many
+// wavefronts per ns, tools/ubench_launch.hip -- 2 / 4 wavefronts per workgroup again: config 2 +3.6 / +4.1 %, config 3 +4.7 / +4.3 %,
+// 4K +3.4 / +4.1 %, an all-hot footprint stream +-0: the dispatcher is not what the kernel waits for.)
 // More than one footprint per wavefront (a vertical stack, or a run along x with the next footprint's plan and window prefetched
 // into a second LDS buffer behind counted vmcnt waits) is slower as well: 2 per wavefront +4 %, 4 per wavefront +9 %.
+// (Round 5: a wavefront that takes the hot footprint BELOW its own as well when both have the same owner -- one plan round trip, one
+// matrix, two windows, two batches of pixels, everything else through the regular code one footprint after the other; zero scratch,
+// byte-identical -- all-hot stream -0.7 %, 4K -0.2 %, config 2 +2.4 %, config 3 +5.2 %: what a wavefront does once per footprint is
+// not what bounds the kernel.  DESIGN.md section 4.3.)
 constexpr int FOOT_W = MF_FOOT_W;   // 8 lanes x 4 pixels
 constexpr int FOOT_H = MF_FOOT_H;   // 64 lanes / 8
 constexpr int MAX_MESH = 64;    // R, C <= 64
