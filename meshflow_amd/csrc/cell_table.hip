@@ -363,6 +363,9 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
     float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
     bool sane = true;
     float wlo_all = 1e30f, whi_all = -1e30f;                   // denominator range of every listed cell over the footprint
+    // largest sum of the magnitudes of a numerator's / the denominator's terms at the far corner over the listed cells (the premises of
+    // the warp kernel's cheap coordinate chain, below), and |h6| of the cell listed last: taken while the matrix is in registers
+    float sum_nx = 0.0f, sum_ny = 0.0f, sum_w = 0.0f, h6_last = 0.0f;
     bool coded = true;                                         // every MIXED entry has a one- or two-edge code
     // The candidate range comes from the FRAME's reach (the largest overhang of any cell's box over its grid rect); most of its cells
     // have a box that does not meet this footprint.  A first cheap pass keeps the cells whose own box does (descending order kept;
@@ -416,6 +419,14 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             // the window keeps 1/16 pixel of slack, the float32 error at coordinates up to 8192 is below 0.01)
             float h[9];
             hi_of(k, h);
+            {
+                const float ax = fabsf(h[0]) * cxs[1] + fabsf(h[1]) * cys[1] + fabsf(h[2]), ay = fabsf(h[3]) * cxs[1] + fabsf(h[4]) * cys[1] + fabsf(h[5]),
+                            aw = fabsf(h[6]) * cxs[1] + fabsf(h[7]) * cys[1] + fabsf(h[8]);
+                if (!(ax <= sum_nx)) sum_nx = ax;                   // (a NaN sticks: the comparisons below then fail)
+                if (!(ay <= sum_ny)) sum_ny = ay;
+                if (!(aw <= sum_w)) sum_w = aw;
+                h6_last = fabsf(h[6]);
+            }
             // (fused, the y part shared by the two corners of a footprint row: 18 operations for the twelve values instead of 48)
             const float wy[2] = { __builtin_fmaf(h[7], cys[0], h[8]), __builtin_fmaf(h[7], cys[1], h[8]) };
             const float nxy[2] = { __builtin_fmaf(h[1], cys[0], h[2]), __builtin_fmaf(h[1], cys[1], h[2]) };
@@ -442,15 +453,9 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
         for (int i = 0; i < 4; ++i) p.e[4 + i] = (uint16_t)(codes >> (16 * i));      // short list: room for the per-entry edge codes
     bool unit1 = false;                                            // ONE listed cell whose denominator allows the reciprocal guess
     if (cnt == 1 && sane) {
-        // one cell owns the footprint: its denominator range over the footprint (corners) and h6, for the warp kernel's reciprocal guess
-        float h[9];
-        hi_of((int)(p.e[0] & 0xFFFu), h);
-        float wlo = 1e30f, whi = -1e30f;
-        for (int q = 0; q < 4; ++q) {
-            const float w = h[6] * cxs[q & 1] + h[7] * cys[q >> 1] + h[8];
-            wlo = fminf(wlo, w); whi = fmaxf(whi, w);
-        }
-        unit1 = wlo > 0.52f && whi < 1.9f && fabsf(h[6]) <= 0.9f * 2.5e-4f * (wlo * wlo);
+        // one cell owns the footprint: its denominator range over the footprint (corners: wlo_all / whi_all are this cell's) and h6, for
+        // the warp kernel's reciprocal guess
+        unit1 = wlo_all > 0.52f && whi_all < 1.9f && h6_last <= 0.9f * 2.5e-4f * (wlo_all * wlo_all);
         if (unit1 && closed)
             p.e[1] = (uint16_t)MF_PLAN_UNIT;                       // (float32 evaluation: 1e-6 of error against margins of 4 % and 10 %)
     }
@@ -557,20 +562,10 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             // The premises of the warp kernel's cheap coordinate chain (warp.hip, cheap_quotients) for EVERY listed cell on this footprint:
             // no cancellation in the numerators -- the sum of the magnitudes of a numerator's terms (largest at the far corner: x, y >= 0)
             // at most 8 x the numerator, which is u w >= umin wlo for every listed cell -- denominator terms bounded, denominator above
-            // 0.52.  One pass for the three paths that use it (hot, pair, multi), from the matrices read again after the candidate loop.
-            bool cheap_all = interior && !overflow && cnt <= 4 && umin > 0.0f && vmin > 0.0f && wlo_all > 0.52f;
-            if (cheap_all) {
-                const float nx_lo = 7.9f * umin * wlo_all, ny_lo = 7.9f * vmin * wlo_all;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < cnt) {
-                        float h[9];
-                        hi_of((int)(p.e[i] & 0xFFFu), h);
-                        cheap_all = cheap_all && fabsf(h[0]) * cxs[1] + fabsf(h[1]) * cys[1] + fabsf(h[2]) <= nx_lo &&
-                                    fabsf(h[3]) * cxs[1] + fabsf(h[4]) * cys[1] + fabsf(h[5]) <= ny_lo &&
-                                    fabsf(h[6]) * cxs[1] + fabsf(h[7]) * cys[1] + fabsf(h[8]) <= 2.45f;
-                    }
-            }
+            // 0.52.  One test for the three paths that use it (hot, pair, multi).
+            // (the sums were taken in the candidate loop, largest over the listed cells)
+            const bool cheap_all = interior && !overflow && cnt <= 4 && umin > 0.0f && vmin > 0.0f && wlo_all > 0.52f &&
+                                   sum_nx <= 7.9f * umin * wlo_all && sum_ny <= 7.9f * vmin * wlo_all && sum_w <= 2.45f;
             if (deep && p.e[1] == (uint16_t)MF_PLAN_UNIT && (p.e[0] & (MF_PLAN_VALID | MF_PLAN_IN)) == (MF_PLAN_VALID | MF_PLAN_IN)) {
                 // FAST64: no cancellation in the numerators (sum of the terms' magnitudes at most 8 x the value, everywhere on
                 // the footprint: the former grows with x and y, the latter is smallest at a corner), denominator terms bounded --

@@ -186,6 +186,55 @@ def test_host_warp_crop_pipeline_equals_oracle(F, H, W, R, C, keep):
     np.testing.assert_array_equal(np.stack(ins), frames)    # inputs untouched
 
 
+def test_host_pipeline_any_thread_chunk_and_ring_setting_gives_the_same_bytes():
+    """The ring hands the next chunk to whichever copy thread is free: twelve random settings of upload / download / populate threads,
+    frames per chunk and ring slots (more threads than chunks, one slot more than two, one chunk for everything ...) all give the
+    oracle's frames, cropped frames, per-frame values and rectangle."""
+    import os
+    from meshflow_amd import _lib
+    from oracle import clib, meshflow_oracle as mo
+    F, H, W, R, C = 37, 96, 128, 5, 6
+    frames, disp, stab = _clip(F, H, W, R, C, seed=77)
+    want, want_crop, bad = clib.warp_clip(frames, R, C, disp, stab, (1, 2, 3))
+    assert bad == 0
+    rect = (want_crop[:, 0].max(), want_crop[:, 1].max(), want_crop[:, 2].min(), want_crop[:, 3].min())
+    want_cropped = np.stack(mo.crop_frames(list(want), rect))
+    border = (ctypes.c_uint8 * 3)(1, 2, 3)
+    ins = [f.copy() for f in frames]
+    pin = (ctypes.c_void_p * F)(*[f.ctypes.data for f in ins])
+    names = ('MF_PIPE_UP', 'MF_PIPE_DOWN', 'MF_PIPE_POPULATE', 'MF_PIPE_CHUNK', 'MF_PIPE_SLOTS')
+    old = {k: os.environ.get(k) for k in names}
+    rng = np.random.default_rng(5)
+    settings = [(1, 1, 0, 1, 2), (8, 8, 8, 37, 2), (8, 1, 1, 3, 3), (1, 8, 2, 2, 64)] + \
+               [tuple(int(v) for v in (rng.integers(1, 9), rng.integers(1, 9), rng.integers(0, 9), rng.integers(1, 12), rng.integers(2, 20))) for _ in range(8)]
+    try:
+        for setting in settings:
+            for k, v in zip(names, setting):
+                os.environ[k] = str(v)
+            outs = [np.zeros((H, W, 3), np.uint8) for _ in range(F)]
+            crs = [np.zeros((H, W, 3), np.uint8) for _ in range(F)]
+            pout = (ctypes.c_void_p * F)(*[f.ctypes.data for f in outs])
+            pcr = (ctypes.c_void_p * F)(*[f.ctypes.data for f in crs])
+            crop = np.zeros((F, 4), np.int32)
+            bounds = (ctypes.c_int32 * 4)()
+            _lib.check(_lib.lib.mf_warp_crop_u8c3_host_frames(pin, pout, pcr, _p(disp), _p(stab), F, W, H, R, C, border, _p(crop), bounds, None))
+            assert tuple(bounds) == tuple(int(v) for v in rect), setting
+            np.testing.assert_array_equal(crop, want_crop, err_msg=str(setting))
+            np.testing.assert_array_equal(np.stack(crs), want_cropped, err_msg=str(setting))
+            np.testing.assert_array_equal(np.stack(outs), want, err_msg=str(setting))
+            outs2 = [np.zeros((H, W, 3), np.uint8) for _ in range(F)]                         # the warp alone through the same ring
+            pout2 = (ctypes.c_void_p * F)(*[f.ctypes.data for f in outs2])
+            _lib.check(_lib.lib.mf_warp_u8c3_host_frames(pin, pout2, _p(disp), _p(stab), F, W, H, R, C, border, _p(crop), None))
+            np.testing.assert_array_equal(np.stack(outs2), want, err_msg=str(setting))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    np.testing.assert_array_equal(np.stack(ins), frames)
+
+
 def test_host_wrapper_rejects_overlapping_input_and_output():
     from meshflow_amd import _lib
     F, H, W, R, C = 8, 48, 64, 2, 2
