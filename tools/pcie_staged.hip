@@ -89,7 +89,26 @@ int main(int argc, char** argv)
     for (auto* v : {&up_done, &warp_done, &down_done}) for (auto& e : *v) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     std::vector<std::atomic<int>> up_ready(nchunks), warp_ready(nchunks), down_issued(nchunks), populated(nchunks);
     auto wait_flag = [](std::atomic<int>& f) { while (!f.load(std::memory_order_acquire)) std::this_thread::yield(); };
-    for (int mode = 0; mode < 3; ++mode) {
+    // RECREATE=n: the `direct` mode n times, each time on a NEW set of streams (the old ones destroyed first): is the duplex rate a
+    // property of the process or of the streams it happens to hold?
+    const int recreate = getenv("RECREATE") ? atoi(getenv("RECREATE")) : 0;
+    for (int mode = 0, round = 0; mode < 3; ++mode) {
+        if (recreate && mode == 1) {
+            if (++round >= recreate) break;
+            mode = 0;
+            for (auto& s_ : su) { CK(hipStreamDestroy(s_)); }
+            for (auto& s_ : sd) { CK(hipStreamDestroy(s_)); }
+            if (getenv("RECREATE_EXTRA")) {                  // shift the queue assignment: a few streams that stay alive
+                hipStream_t extra;
+                for (int i = 0; i < atoi(getenv("RECREATE_EXTRA")); ++i) { CK(hipStreamCreateWithFlags(&extra, hipStreamNonBlocking)); CK(hipMemsetAsync(d_up, 0, 64, extra)); }
+            }
+            for (auto& s_ : su) CK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+            for (auto& s_ : sd) CK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+            if (!getenv("NO_PRIME")) {
+                for (int t = 0; t < U; ++t) CK(hipMemcpyAsync(d_up, h_up + (size_t)t * (16 << 20), 16 << 20, hipMemcpyHostToDevice, su[t]));
+                CK(hipDeviceSynchronize());
+            }
+        }
         double best = 1e9;
         for (int rep = 0; rep < 4; ++rep) {
             CK(hipDeviceSynchronize());
