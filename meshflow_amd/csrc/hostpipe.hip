@@ -49,7 +49,7 @@ constexpr size_t PIPE_CHUNK_BYTES = (size_t)16 << 20;    // bytes per chunk: 3 f
 constexpr size_t PIPE_RING_BYTES = (size_t)900 << 20;    // ring per direction: 48 slots at 1080p, 36 at 4K (MF_PIPE_SLOTS overrides), for a clip of any length
 constexpr int PIPE_SLOTS_MAX = 64;
 constexpr size_t PIPE_SCAN_TABLE_BYTES = (size_t)96 << 20;   // scratch table of the rectangle pre-pass: ~330 frames of 1080p at a 16 x 16 mesh per piece
-constexpr int PIPE_UP = 4;         // upload threads / streams   (2/2: 59 ms, 3/3: 64, 4/4: 58, 6/6: 57 per cfg2 clip)
+constexpr int PIPE_UP = 4;         // upload threads / streams   (round 5, 16 MB chunks, frames/s at config 2: 3+3 5,730-6,080, 4+4 5,880-6,030, 6+6 5,070-5,100)
 constexpr int PIPE_DOWN = 4;       // download threads / streams
 constexpr int PIPE_POPULATE = 8;   // threads that fault the output pages in ahead of the downloads (MF_PIPE_POPULATE, 0 = none)
 constexpr int PIPE_MAX = 8;        // upper bound on either thread count (MF_PIPE_UP / MF_PIPE_DOWN / MF_PIPE_CHUNK tune them)
