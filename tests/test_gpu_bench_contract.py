@@ -112,6 +112,25 @@ def test_bench_two_ranks_started_by_bench_itself():
     assert d['crop_bounds'] == ops.crop_reduce(crop, 640, 360).tolist()
 
 
+def test_bench_two_ranks_under_the_drivers_own_launcher():
+    """The driver's command line for N > 1, word for word: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` (gloo, so that the two ranks can share the test box's one GPU): rank 0
+    prints the ONE JSON line, the other rank nothing."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['MESHFLOW_DIST_BACKEND'] = 'gloo'
+    port = 29500 + os.getpid() % 400
+    proc = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                           '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--workload', 'small', '--gpus', '2', '--steps', '2',
+                           '--warmup', '1'], cwd=REPO, capture_output=True, text=True, timeout=900, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    d = json.loads(lines[0])
+    _contract(d, 2, 2, 1)
+    assert d['communicator']['world_size'] == 2 and d['communicator']['backend'] == 'gloo'
+    assert d['gather_to_rank0_ms'] > 0 and 'gather_error' not in d and '128 total' in d['config']['workload']
+
+
 def test_bench_failed_rank_gives_nonzero_exit():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
     env['MESHFLOW_DIST_BACKEND'] = 'no-such-backend'
