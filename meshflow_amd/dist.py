@@ -53,14 +53,20 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def active():
+    """A process group exists (the collectives run, even over one rank)."""
+    return dist.is_initialized()
+
+
 def _through_host():
     """gloo moves tensors through host memory; device tensors are staged explicitly so that it works on every build."""
     return dist.is_initialized() and dist.get_backend() == 'gloo'
 
 
 def all_reduce_max(t):
-    """In-place MAX all-reduce of a small tensor on whatever backend is active."""
-    if world_size() == 1:
+    """In-place MAX all-reduce of a small tensor on whatever backend is active.  (No process group: nothing to do.  A group of ONE rank
+    still runs the collective -- the only way to exercise the RCCL path on a one-GPU box, tests/test_gpu_nccl_one_rank.py.)"""
+    if not dist.is_initialized():
         return t
     if _through_host() and t.is_cuda:
         h = t.cpu()
@@ -77,7 +83,7 @@ _SIGN = {}
 def allreduce_crop(bounds):
     """bounds: int32 tensor {left, top, right, bottom} of this rank's frames -> clip-level bounds on every
     rank (max left, max top, min right, min bottom; mfs.py:1103-1106) with ONE 16-byte all-reduce."""
-    if world_size() == 1:
+    if not dist.is_initialized():
         return bounds
     key = (bounds.device, bounds.dtype)
     sign = _SIGN.get(key)
@@ -93,7 +99,7 @@ def gather_frames(local_frames, num_frames, dst=0):
     Returns the (F, H, W, 3) stack on dst and None elsewhere.  One collective; shards are padded to
     ceil(F/G) frames because gather needs equal counts."""
     G = world_size()
-    if G == 1:
+    if not dist.is_initialized():
         return local_frames
     rank = dist.get_rank()
     per = -(-num_frames // G)

@@ -679,7 +679,7 @@ class MeshFlowStabilizer:
                                                              exchange_ctx=exchange_ctx if (on_prep and collective) else None)
         if on_prep:
             main = torch.cuda.current_stream(dev)
-            if collective and mfdist.world_size() > 1:
+            if collective and mfdist.active():
                 done = torch.cuda.Event()
                 done.record(st['prep'])
                 main.wait_event(done)                        # the exchanged rectangle, back in current-stream order
