@@ -48,6 +48,8 @@ SCRIPT = textwrap.dedent('''
     assert torch.equal(ragged, plain[:37])
     t = torch.tensor([3, -7, 9], dtype=torch.int32, device=dev)
     assert mfdist.all_reduce_max(t).tolist() == [3, -7, 9]
+    secs = torch.tensor([0.00125], dtype=torch.float64, device=dev)            # bench.py's max-over-ranks of the elapsed time
+    assert float(mfdist.all_reduce_max(secs).item()) == 0.00125
     dist.barrier()
     dist.destroy_process_group()
     print('NCCL-ONE-RANK-OK', want)
