@@ -389,6 +389,9 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
     p.e[0] = (uint16_t)boxed; p.e[1] = (uint16_t)shortlist[0]; p.e[2] = (uint16_t)shortlist[1]; region.flags_origin = 0; region.src_dwords = 0;
     return;
 #endif
+#if MF_PLAN_EXP == 4      // (timing-only build: at most ONE candidate classified per footprint -- what the candidate loop costs beyond its first trip)
+    if (boxed > 1) boxed = 1;
+#endif
     for (int step = 0; step < boxed && !closed && !overflow; ++step) {
         const int k = (int)(((step < 4 ? shortlist[0] : shortlist[1]) >> (16 * (step & 3))) & 0xFFFFu);
         {
