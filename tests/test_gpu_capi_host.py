@@ -32,7 +32,9 @@ def _clip(F, H, W, R, C, seed, **kw):
     return frames, np.ascontiguousarray(disp), np.ascontiguousarray(stab)
 
 
-@pytest.mark.parametrize('F,H,W,R,C', [(40, 72, 100, 3, 5), (16, 64, 96, 4, 4), (50, 96, 128, 8, 8), (3, 48, 64, 2, 2)])
+# (the last two: frame sizes that are no multiple of 4 bytes -- ring slots then start at unaligned device addresses, the warp takes its
+# unstaged path -- and a single-row mesh)
+@pytest.mark.parametrize('F,H,W,R,C', [(40, 72, 100, 3, 5), (16, 64, 96, 4, 4), (50, 96, 128, 8, 8), (3, 48, 64, 2, 2), (11, 50, 101, 3, 4), (7, 33, 67, 1, 6)])
 def test_host_wrapper_chunks_equal_the_oracle(F, H, W, R, C):
     from meshflow_amd import _lib
     from oracle import clib
@@ -233,6 +235,39 @@ def test_host_pipeline_any_thread_chunk_and_ring_setting_gives_the_same_bytes():
             else:
                 os.environ[k] = v
     np.testing.assert_array_equal(np.stack(ins), frames)
+
+
+def test_host_pipeline_with_frames_that_are_no_multiple_of_four_bytes(monkeypatch):
+    """101 x 50 frames (15,150 bytes) in chunks of 3 on a ring of 2 slots: every second slot starts at a device address that is not
+    4-byte aligned -- the warp must take its unstaged path there and the crop + resize its direct one; results as the oracle's."""
+    from meshflow_amd import _lib
+    from oracle import clib, meshflow_oracle as mo
+    F, H, W, R, C = 11, 50, 101, 3, 4
+    frames, disp, stab = _clip(F, H, W, R, C, seed=9, jitter_sigma=0.8)
+    want, want_crop, bad = clib.warp_clip(frames, R, C, disp, stab, (5, 6, 7))
+    assert bad == 0
+    rect = (want_crop[:, 0].max(), want_crop[:, 1].max(), want_crop[:, 2].min(), want_crop[:, 3].min())
+    want_cropped = np.stack(mo.crop_frames(list(want), rect))
+    monkeypatch.setenv('MF_PIPE_CHUNK', '3')
+    monkeypatch.setenv('MF_PIPE_SLOTS', '2')
+    border = (ctypes.c_uint8 * 3)(5, 6, 7)
+    ins = [f.copy() for f in frames]
+    outs = [np.zeros((H, W, 3), np.uint8) for _ in range(F)]
+    crs = [np.zeros((H, W, 3), np.uint8) for _ in range(F)]
+    pin = (ctypes.c_void_p * F)(*[f.ctypes.data for f in ins])
+    pout = (ctypes.c_void_p * F)(*[f.ctypes.data for f in outs])
+    pcr = (ctypes.c_void_p * F)(*[f.ctypes.data for f in crs])
+    crop = np.zeros((F, 4), np.int32)
+    bounds = (ctypes.c_int32 * 4)()
+    _lib.check(_lib.lib.mf_warp_crop_u8c3_host_frames(pin, pout, pcr, _p(disp), _p(stab), F, W, H, R, C, border, _p(crop), bounds, None))
+    assert tuple(bounds) == tuple(int(v) for v in rect)
+    np.testing.assert_array_equal(crop, want_crop)
+    np.testing.assert_array_equal(np.stack(outs), want)
+    np.testing.assert_array_equal(np.stack(crs), want_cropped)
+    outs2 = [np.zeros((H, W, 3), np.uint8) for _ in range(F)]
+    pout2 = (ctypes.c_void_p * F)(*[f.ctypes.data for f in outs2])
+    _lib.check(_lib.lib.mf_crop_resize_u8c3_host_frames(pout, pout2, F, W, H, *[int(v) for v in rect], None))
+    np.testing.assert_array_equal(np.stack(outs2), want_cropped)
 
 
 def test_host_wrapper_rejects_overlapping_input_and_output():
