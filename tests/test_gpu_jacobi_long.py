@@ -155,3 +155,23 @@ def test_stabilizer_accepts_a_long_clip(dev):
     taps, lam, on = mo.jacobi_band_coefficients(F, W, H, 0, hom, 10)                # the oracle's coefficients (row sums in another order)
     want = clib.jacobi_banded(disp.reshape(F, -1), taps, lam, np.reciprocal(on), 10, 30, openmp=True).reshape(disp.shape)
     assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
+
+
+def test_jacobi_corner_shapes_equal_the_oracle():
+    """The other end of the size range: 1,008 shapes with clips of 1-641 frames, radii from 1 to 300 (far beyond the clip), 0-7 sweeps,
+    1-130 series -- every one bit-identical to the C oracle (mfs.py:871-876 works for any of them)."""
+    import itertools
+    import torch
+    from meshflow_amd import ops
+    from oracle import clib
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(3)
+    for F, omega, iters, S in itertools.product((1, 2, 3, 5, 17, 64, 65, 321, 641), (1, 2, 10, 30, 33, 100, 300), (0, 1, 2, 7), (1, 2, 7, 130)):
+        b = rng.normal(size=(F, S))
+        taps = rng.uniform(0.1, 1.0, size=2 * omega + 1)
+        lam = rng.uniform(0.0, 0.95, size=F)
+        inv_on = 1.0 / (1.0 + 2.0 * rng.uniform(0.5, 3.0, size=F))
+        want = clib.jacobi_banded(b, taps, lam, inv_on, omega, iters)
+        got = ops.jacobi(torch.from_numpy(b).to(dev), torch.from_numpy(taps).to(dev), torch.from_numpy(lam).to(dev),
+                         torch.from_numpy(inv_on).to(dev), omega, iters).cpu().numpy()
+        assert np.array_equal(got, want), (F, omega, iters, S)
