@@ -1308,7 +1308,8 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
             // "deep interior": 2 <= ix <= W-3 and 2 <= iy <= H-3 for all four pixels.  Then both taps in x and
             // y are inside the frame, the 8-byte loads stay inside the row, and no crop flag can be set
             // (u >= 2 - 1/64 and u < W - 2, same for v).
-            const bool deep = dxm <= (uint32_t)(32 * (W - 3) + 31 - 64) && dym <= (uint32_t)(32 * (H - 3) + 31 - 64);
+            // (a frame of fewer than five columns or rows has no such pixel: the bounds would wrap around as unsigned numbers)
+            const bool deep = W >= 5 && H >= 5 && dxm <= (uint32_t)(32 * (W - 3) + 31 - 64) && dym <= (uint32_t)(32 * (H - 3) + 31 - 64);
             fast = __ballot(active && !deep) == 0;
         }
         uint3 d;                                                        // the lane's 12 output bytes

@@ -641,3 +641,37 @@ def test_stability_score_on_device_vs_host(dev, F, R, C):
     np.testing.assert_allclose(series.cpu().numpy(), en[:, 1:6].sum(1) / en.sum(1), rtol=1e-10, atol=1e-14)
     with pytest.raises(ValueError):                                           # F = 1: np.fft.fft of an empty profile raises too
         ops.stability_score(torch.zeros((1, 3, 3, 2), dtype=torch.float64, device=dev))
+
+
+def test_tiny_frames_equal_the_oracle(dev):
+    """Frames of 2-100 columns and 2-40 rows (a 4-column frame has no "deep interior" pixel at all: the bound of that test used to wrap
+    around as an unsigned number and sent its footprints down the unclamped path -- found by this sweep at the end of round 5), meshes
+    of 1-3 rows and columns, still and moving: frames, per-frame crop values and the degenerate-cell count as the C oracle's; the
+    scan-only kernel agrees with the fused scan."""
+    import itertools
+    import torch
+    from meshflow_amd import ops
+    from oracle import clib
+    rng = np.random.default_rng(11)
+    n = 0
+    for W, H, (R, C), nfr in itertools.product((2, 3, 4, 5, 6, 7, 8, 12, 31, 32, 33, 64, 100), (2, 3, 4, 5, 8, 9, 12, 13, 17, 40),
+                                               ((1, 1), (1, 2), (2, 1), (2, 3), (3, 3)), (1, 3)):
+        if C > W - 1 or R > H - 1:
+            continue
+        frames = rng.integers(0, 256, size=(nfr, H, W, 3), dtype=np.uint8)
+        unstab = np.zeros((nfr, R + 1, C + 1, 2))
+        scale = rng.choice([0.0, 0.3, 1.5, 4.0])
+        stab = rng.normal(0, 1, size=(nfr, 1, 1, 2)) * scale + rng.normal(0, 0.2, size=(nfr, R + 1, C + 1, 2)) * min(scale, 1.0)
+        want, want_crop, want_bad = clib.warp_clip(frames, R, C, unstab, stab, (9, 8, 7))
+        table = ops.cell_table(torch.from_numpy(unstab).to(dev), torch.from_numpy(stab).to(dev), W, H, R, C)
+        out = ops.warp(torch.from_numpy(frames).to(dev), table, (9, 8, 7))
+        assert int(table.status.item()) == want_bad, (W, H, R, C, nfr)
+        if want_bad:
+            continue
+        n += 1
+        assert np.array_equal(out.cpu().numpy(), want), (W, H, R, C, nfr, float(scale))
+        assert np.array_equal(table.crop.cpu().numpy(), want_crop), (W, H, R, C, nfr, float(scale))
+        table2 = ops.cell_table(torch.from_numpy(unstab).to(dev), torch.from_numpy(stab).to(dev), W, H, R, C)
+        ops.crop_scan(table2)
+        assert np.array_equal(table2.crop.cpu().numpy(), want_crop), ('scan', W, H, R, C, nfr, float(scale))
+    assert n > 800
