@@ -54,9 +54,11 @@ __device__ __forceinline__ uint32_t load_bgr(const uint8_t* __restrict__ frame, 
     uint32_t v;
     if ((size_t)o + 4 <= limit) {
         __builtin_memcpy(&v, frame + o, 4);
-    } else {
+    } else if (o != 0) {
         __builtin_memcpy(&v, frame + o - 1, 4);
         v >>= 8;
+    } else {                                             // a stack of ONE pixel: nothing in front of it either
+        v = (uint32_t)frame[0] | (uint32_t)frame[1] << 8 | (uint32_t)frame[2] << 16;
     }
     return v & 0xFFFFFFu;
 }

@@ -675,3 +675,40 @@ def test_tiny_frames_equal_the_oracle(dev):
         ops.crop_scan(table2)
         assert np.array_equal(table2.crop.cpu().numpy(), want_crop), ('scan', W, H, R, C, nfr, float(scale))
     assert n > 800
+
+
+def test_crop_resize_and_score_corner_cases(dev):
+    """`_crop_frames` (mfs.py:1111-1157) on frames of 1-300 columns and 1-40 rows with extreme rectangles (one pixel, one row, one column,
+    the whole frame, random ones): 2,000+ cases equal to the NumPy oracle.  (A stack of ONE pixel used to read the byte in front of its
+    allocation: found by this sweep at the end of round 5.)  The stability score (mfs.py:1216-1259) on clips of 1-65 frames."""
+    import itertools
+    import torch
+    from meshflow_amd import ops
+    from oracle import meshflow_oracle as mo
+    rng = np.random.default_rng(5)
+    n = 0
+    for W, H, nfr in itertools.product((1, 2, 3, 4, 5, 7, 8, 9, 31, 32, 33, 100, 255, 256, 257, 300), (1, 2, 3, 5, 8, 9, 17, 33, 40), (1, 3)):
+        frames = rng.integers(0, 256, size=(nfr, H, W, 3), dtype=np.uint8)
+        rects = {(0, 0, W - 1, H - 1), (0, 0, 0, 0), (W - 1, H - 1, W - 1, H - 1), (0, H - 1, W - 1, H - 1), (W - 1, 0, W - 1, H - 1)}
+        for _ in range(3):
+            l, r = sorted(rng.integers(0, W, size=2))
+            t, b = sorted(rng.integers(0, H, size=2))
+            rects.add((int(l), int(t), int(r), int(b)))
+        d_frames = torch.from_numpy(frames).to(dev)
+        for rect in sorted(rects):
+            n += 1
+            want = np.stack(mo.crop_frames(list(frames), rect))
+            assert np.array_equal(ops.crop_resize(d_frames, rect).cpu().numpy(), want), (W, H, nfr, rect)
+    assert n > 1500
+    for F, S in itertools.product((1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 33, 64, 65), (2, 8, 50)):
+        stab = np.cumsum(rng.normal(size=(F, S // 2, 1, 2)), axis=0)
+        d_stab = torch.from_numpy(np.ascontiguousarray(stab)).to(dev)
+        try:
+            want = mo.stability_score(stab)
+        except ValueError:                                  # a clip of one frame has no velocity profile: np.fft refuses (mfs.py:1241)
+            with pytest.raises(Exception):
+                ops.stability_score(d_stab)
+            continue
+        score, _ = ops.stability_score(d_stab)
+        got = float(score.item())
+        assert (np.isnan(got) and np.isnan(want)) or abs(got - want) <= 1e-12 * max(1.0, abs(want)), (F, S, got, want)
