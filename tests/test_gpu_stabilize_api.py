@@ -184,3 +184,62 @@ def test_streamed_stabilize_is_bypassed_when_an_opencv_side_method_is_replaced(c
 
     Custom(**KW).stabilize('in.m4v', 'never.m4v')
     assert seen == [('never.m4v', 10, 10)] and 'never.m4v' not in cv2_stub.WRITTEN
+
+
+def test_stabilize_clip_on_tiny_clips_and_dense_meshes():
+    """`stabilize_clip(crop=True)` on clips of 2-9 frames of 2 x 2 to 101 x 50 pixels, radii up to 40 (far beyond the clip): paths within
+    1e-9 of the NumPy oracle, frames / rectangle / cropped frames equal to the C oracle's warp of those paths and the NumPy crop of it.
+    A one-frame clip has no velocity profile: np.fft refuses it inside the stability score, as in the reference (mfs.py:1241).  Meshes
+    finer than a footprint (33 x 33 to 64 x 64 cells on frames of 65-200 pixels): the warp as the C oracle's."""
+    import itertools
+    import torch
+    from meshflow_amd import ops
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    from oracle import clib, meshflow_oracle as mo
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(21)
+    n = 0
+    for F, (W, H), (R, C), omega in itertools.product((1, 2, 3, 9), ((2, 2), (4, 4), (5, 3), (8, 8), (33, 9), (64, 48), (101, 50)),
+                                                      ((1, 1), (1, 3), (2, 2), (3, 1)), (1, 4, 40)):
+        if C > W - 1 or R > H - 1:
+            continue
+        frames = [rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8) for _ in range(F)]
+        vel = rng.normal(0, 0.6, size=(F, R + 1, C + 1, 2))
+        vel[0] = 0
+        disp = np.cumsum(vel, axis=0)
+        hom = np.tile(np.eye(3), (F, 1, 1))
+        hom[:, :2, 2] = rng.normal(0, 1.0, size=(F, 2))
+        hom[-1] = np.eye(3)
+        s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=omega, optimization_num_iterations=5, device='cuda:0')
+        if F == 1:
+            with pytest.raises(ValueError):
+                s.stabilize_clip(frames, disp, hom, crop=True)
+            continue
+        want_stab = mo.stabilized_vertex_displacements(W, H, 0, disp, hom, omega, 5)
+        _, first_crop, degenerate = clib.warp_clip(np.stack(frames), R, C, disp, want_stab, (0, 0, 255))
+        empty = first_crop[:, 2].min() < first_crop[:, 0].max() or first_crop[:, 3].min() < first_crop[:, 1].max()
+        if degenerate or empty:                              # (what cv2 would die of: the product refuses it, tested elsewhere)
+            with pytest.raises(Exception):
+                s.stabilize_clip(frames, disp, hom, crop=True)
+            continue
+        out, rect, stab, score, cropped = s.stabilize_clip(frames, disp, hom, crop=True)
+        n += 1
+        np.testing.assert_allclose(stab, want_stab, rtol=0, atol=1e-9)
+        want, want_crop, _ = clib.warp_clip(np.stack(frames), R, C, disp, np.ascontiguousarray(stab), (0, 0, 255))
+        want_rect = (int(want_crop[:, 0].max()), int(want_crop[:, 1].max()), int(want_crop[:, 2].min()), int(want_crop[:, 3].min()))
+        assert tuple(int(v) for v in rect) == want_rect, (F, W, H, R, C, omega)
+        assert np.array_equal(np.stack(out), want), (F, W, H, R, C, omega)
+        assert np.array_equal(np.stack(cropped), np.stack(mo.crop_frames(list(want), want_rect))), (F, W, H, R, C, omega)
+    assert n > 150
+    for (W, H), (R, C), nfr in itertools.product(((65, 66), (80, 130), (128, 64), (200, 65)), ((33, 33), (48, 64), (64, 64), (64, 20), (7, 64)), (1, 2)):
+        if C > W - 1 or R > H - 1:
+            continue
+        frames = rng.integers(0, 256, size=(nfr, H, W, 3), dtype=np.uint8)
+        unstab = np.zeros((nfr, R + 1, C + 1, 2))
+        stab = rng.normal(0, 1, size=(nfr, 1, 1, 2)) * 1.5 + rng.normal(0, 0.05, size=(nfr, R + 1, C + 1, 2))
+        want, want_crop, degenerate = clib.warp_clip(frames, R, C, unstab, stab, (1, 2, 3))
+        table = ops.cell_table(torch.from_numpy(unstab).to(dev), torch.from_numpy(stab).to(dev), W, H, R, C)
+        out = ops.warp(torch.from_numpy(frames).to(dev), table, (1, 2, 3))
+        assert int(table.status.item()) == degenerate
+        if not degenerate:
+            assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(table.crop.cpu().numpy(), want_crop), (W, H, R, C, nfr)
