@@ -570,6 +570,16 @@ class MeshFlowStabilizer:
         main = torch.cuda.current_stream(dev)
         chunks = self.resident_chunks if chunks is None else chunks
         n, H, W, _ = d_frames.shape
+        if n == 0:
+            # an EMPTY shard (a clip of fewer frames than ranks, or the tail of an uneven split): nothing to warp; the rectangle's
+            # neutral element (mfs.py:992-995), so that the rank still takes part in the all-reduce, and d_stab in stream order
+            if st.get('swept') is not None:
+                main.wait_event(st['swept'])
+            bounds = torch.tensor([0, 0, W - 1, H - 1], dtype=torch.int32, device=dev)
+            if self.resident_rectangle == 'early':
+                st['scanned'] = torch.cuda.Event()
+                st['scanned'].record(main)
+            return (out if out is not None else d_frames.new_empty((0, H, W, 3))), bounds, None
         slot = self._resident_slot(st, n, W, H)
         table = slot['table']
         bounds = torch.empty(4, dtype=torch.int32, device=dev)           # this clip's own: never rewritten by a later one

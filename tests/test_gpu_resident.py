@@ -234,3 +234,37 @@ def test_resident_table_cache_is_bounded(dev):
         assert out.shape == (5, H, W, 3)
     s.finish()
     assert len(s._resident['tables']) == 3
+
+
+def test_frame_range_shards_down_to_empty_ones():
+    """`stabilize_resident(frame_range=(lo, hi))` on every shard of an uneven 8-way split of a 12-frame clip (ceil(12 / 8) = 2 frames per
+    rank: six ranks with two frames, two EMPTY ones) and on one-frame shards: the shards' frames are the slices of the whole clip's, the
+    paths the same everywhere, and max / min over the shards' rectangles (an empty shard contributes the neutral element,
+    mfs.py:992-995) is the whole clip's rectangle -- what the 16-byte all-reduce of an N-GPU job computes."""
+    import numpy as np
+    import torch
+    from meshflow_amd import host, synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    dev = torch.device('cuda:0')
+    F, H, W, R, C = 12, 120, 160, 4, 4
+    disp, hom = synthetic.motion(F, R, C, seed=1)
+    d_frames = synthetic.frames_torch(F, H, W, dev, seed=1)
+    d_disp = torch.from_numpy(disp).to(dev)
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=3, optimization_num_iterations=5, device='cuda:0')
+    full, b_full, stab_full = s.stabilize_resident(d_frames, d_disp, hom)
+    s.finish()
+    for rectangle in ('late', 'early'):
+        s.resident_rectangle = rectangle
+        rects, empties = [], 0
+        ranges = [host.shard_range(F, 8, g) for g in range(8)] + [(0, 1), (11, 12)]
+        for lo, hi in ranges:
+            frames, bounds, stab = s.stabilize_resident(d_frames[lo:hi], d_disp, hom, frame_range=(lo, hi))
+            s.finish()
+            assert tuple(frames.shape) == (hi - lo, H, W, 3) and torch.equal(frames, full[lo:hi]) and torch.equal(stab, stab_full)
+            if hi == lo:
+                empties += 1
+                assert bounds.tolist() == [0, 0, W - 1, H - 1]
+            rects.append(bounds.tolist())
+        assert empties == 2
+        r = np.array(rects[:8])
+        assert [int(r[:, 0].max()), int(r[:, 1].max()), int(r[:, 2].min()), int(r[:, 3].min())] == b_full.tolist()
