@@ -34,7 +34,7 @@ def _clip(F, H, W, R, C, seed, **kw):
 
 # (the last two: frame sizes that are no multiple of 4 bytes -- ring slots then start at unaligned device addresses, the warp takes its
 # unstaged path -- and a single-row mesh)
-@pytest.mark.parametrize('F,H,W,R,C', [(40, 72, 100, 3, 5), (16, 64, 96, 4, 4), (50, 96, 128, 8, 8), (3, 48, 64, 2, 2), (11, 50, 101, 3, 4), (7, 33, 67, 1, 6)])
+@pytest.mark.parametrize('F,H,W,R,C', [(40, 72, 100, 3, 5), (16, 64, 96, 4, 4), (50, 96, 128, 8, 8), (3, 48, 64, 2, 2), (11, 50, 101, 3, 4), (7, 33, 67, 1, 6), (1, 40, 64, 2, 2), (2, 9, 5, 1, 1)])
 def test_host_wrapper_chunks_equal_the_oracle(F, H, W, R, C):
     from meshflow_amd import _lib
     from oracle import clib
@@ -155,7 +155,7 @@ def test_rccl_entry_points_single_rank():
     assert n.value == 0
 
 
-@pytest.mark.parametrize('F,H,W,R,C,keep', [(40, 72, 100, 3, 5, True), (21, 96, 128, 8, 8, False)])
+@pytest.mark.parametrize('F,H,W,R,C,keep', [(40, 72, 100, 3, 5, True), (21, 96, 128, 8, 8, False), (1, 40, 64, 2, 2, True), (2, 17, 9, 1, 2, False)])
 def test_host_warp_crop_pipeline_equals_oracle(F, H, W, R, C, keep):
     """mf_warp_crop_u8c3_host_frames = warp (mfs.py:909-1108) + clip-level rectangle (mfs.py:1103-1106) + _crop_frames
     (mfs.py:1111-1157) in ONE host-to-host pipeline: cropped frames equal the NumPy oracle's crop of the C oracle's warp."""
