@@ -243,3 +243,41 @@ def test_stabilize_clip_on_tiny_clips_and_dense_meshes():
         assert int(table.status.item()) == degenerate
         if not degenerate:
             assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(table.crop.cpu().numpy(), want_crop), (W, H, R, C, nfr)
+
+
+def test_drop_in_methods_accept_the_forms_numpy_code_hands_them():
+    """The reference's methods take whatever NumPy takes (mfs.py:632, 909): views into a bigger stack, channel-reversed views
+    (`frame[..., ::-1]`, the BGR / RGB idiom), Fortran-ordered frames, one 4-d array instead of a list, the transposed VIEW the
+    reference's own path method returns (mfs.py:706-708), nested lists, float32 paths (promoted exactly, as NumPy would)."""
+    from meshflow_amd import synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    from oracle import clib
+    F, H, W, R, C = 9, 48, 64, 3, 4
+    frames, disp, hom = synthetic.clip(F, H, W, R, C, seed=2, kind='noise', jitter_sigma=0.7)
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=3, optimization_num_iterations=7, device='cuda:0')
+    stab = s._get_stabilized_vertex_displacements(F, list(frames), 0, disp, hom)
+
+    def expect(un, st):
+        want, want_crop, bad = clib.warp_clip(frames, R, C, np.ascontiguousarray(un, dtype=np.float64), np.ascontiguousarray(st, dtype=np.float64), (0, 0, 255))
+        assert bad == 0
+        return want, (int(want_crop[:, 0].max()), int(want_crop[:, 1].max()), int(want_crop[:, 2].min()), int(want_crop[:, 3].min()))
+
+    def check(fr, un, st):
+        want, rect = expect(un, st)
+        out, b = s._get_stabilized_frames_and_crop_boundaries(F, fr, un, st)
+        assert np.array_equal(np.stack(out), want) and tuple(int(v) for v in b) == rect
+
+    view = lambda a: np.moveaxis(np.ascontiguousarray(np.moveaxis(a, 0, 2)), 2, 0)      # non-contiguous, as mfs.py:706-708 returns it
+    big = np.zeros((F, H + 6, W + 10, 3), np.uint8)
+    big[:, 3:3 + H, 5:5 + W] = frames
+    rev = np.ascontiguousarray(frames[..., ::-1])
+    check(list(frames), disp, stab)
+    check([big[i, 3:3 + H, 5:5 + W] for i in range(F)], disp, stab)
+    check([rev[i][..., ::-1] for i in range(F)], disp, stab)
+    check([np.asfortranarray(f) for f in frames], disp, stab)
+    check(frames, disp, stab)
+    check(list(frames), view(disp), view(stab))
+    check(list(frames), disp.tolist(), stab.tolist())
+    check(list(frames), disp.astype(np.float32), stab)
+    assert np.array_equal(s._get_stabilized_vertex_displacements(F, list(frames), 0, view(disp), hom), stab)
+    assert np.array_equal(s._get_stabilized_vertex_displacements(F, list(frames), 0, disp.tolist(), hom.tolist()), stab)
