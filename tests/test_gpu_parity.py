@@ -675,6 +675,18 @@ def test_tiny_frames_equal_the_oracle(dev):
         ops.crop_scan(table2)
         assert np.array_equal(table2.crop.cpu().numpy(), want_crop), ('scan', W, H, R, C, nfr, float(scale))
     assert n > 800
+    # meshes finer than the pixel grid: vertex coordinates repeat (mfs.py:881-906 rounds them up), the cells between them have no
+    # homography -- the reference would die inside cv2; here the count of such cells is the oracle's and nothing faults
+    for (W, H), (R, C) in itertools.product(((2, 2), (3, 5), (4, 4), (8, 3), (16, 16), (33, 20)), ((2, 2), (4, 4), (8, 16), (16, 8), (40, 40), (64, 64))):
+        frames = rng.integers(0, 256, size=(2, H, W, 3), dtype=np.uint8)
+        unstab = np.zeros((2, R + 1, C + 1, 2))
+        stab = rng.normal(0, 0.3, size=(2, R + 1, C + 1, 2))
+        want, want_crop, want_bad = clib.warp_clip(frames, R, C, unstab, stab, (1, 2, 3))
+        table = ops.cell_table(torch.from_numpy(unstab).to(dev), torch.from_numpy(stab).to(dev), W, H, R, C)
+        out = ops.warp(torch.from_numpy(frames).to(dev), table, (1, 2, 3))
+        assert int(table.status.item()) == want_bad, (W, H, R, C)
+        if not want_bad:
+            assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(table.crop.cpu().numpy(), want_crop), (W, H, R, C)
 
 
 def test_crop_resize_and_score_corner_cases(dev):
