@@ -2,7 +2,9 @@
 tests/: random frame sizes, mesh shapes and motion strengths, including geometries where most footprints take the plan-certified
 hot / pair / multi paths (large cells) and ones that stress the general path (small cells, strong jitter).
 
-    python tools/fuzz_warp.py [cases] [seed] [large]        (needs an MI355X; every case must be bit-identical)
+    python tools/fuzz_warp.py [cases] [seed] [large|tiny]   (needs an MI355X; every case must be bit-identical)
+`tiny`: frames of 2-40 x 2-30 pixels, meshes up to the pixel grid and (one case in ten) beyond it -- the end of the size range where the
+two bugs of late round 5 sat (no campaign before drew a width below 32).
 """
 import os
 import sys
@@ -16,7 +18,7 @@ from oracle import clib
 
 
 
-def run(cases, seed, verbose=True, large=False):
+def run(cases, seed, verbose=True, large=False, tiny=False):
   rng = np.random.default_rng(seed)
   dev = torch.device('cuda:0')
   bad_total = 0
@@ -28,6 +30,11 @@ def run(cases, seed, verbose=True, large=False):
       R, C = int(rng.integers(1, 9)), int(rng.integers(1, 9))
       if rng.random() < 0.2:
           R, C = int(rng.integers(8, 33)), int(rng.integers(8, 33))
+      if tiny:
+          W, H = int(rng.integers(2, 41)), int(rng.integers(2, 31))
+          R, C = int(rng.integers(1, max(2, H))), int(rng.integers(1, max(2, W)))
+          if rng.random() < 0.1:
+              R, C = int(rng.integers(1, 65)), int(rng.integers(1, 65))       # finer than the pixel grid: degenerate cells, counted
       n = int(rng.integers(1, 4))
       style = rng.random()
       nvert = n * (R + 1) * (C + 1) * 2
@@ -68,6 +75,6 @@ def run(cases, seed, verbose=True, large=False):
 
 if __name__ == '__main__':
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    n_bad = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0, large='large' in sys.argv[3:])
+    n_bad = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0, large='large' in sys.argv[3:], tiny='tiny' in sys.argv[3:])
     print(f'{n_cases} cases, {n_bad} mismatches')
     sys.exit(1 if n_bad else 0)
