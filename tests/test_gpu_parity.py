@@ -270,7 +270,8 @@ def test_warp_stress_geometries_bit_exact(dev, H, W, R, C, sigma, seed):
     np.testing.assert_array_equal(crop, want_crop)
 
 
-@pytest.mark.parametrize('H,W,R,C', [(24, 32764, 1, 64), (40, 16384, 2, 64), (16388, 32, 64, 1), (20, 8196, 1, 3)])
+@pytest.mark.parametrize('H,W,R,C', [(24, 32764, 1, 64), (40, 16384, 2, 64), (16388, 32, 64, 1), (20, 8196, 1, 3),
+                                     (2, 32767, 1, 1), (32767, 3, 64, 1), (9, 32767, 2, 33), (32767, 4, 9, 1)])       # (the limits themselves, thin)
 def test_warp_extreme_aspect_ratios_bit_exact(dev, H, W, R, C):
     """Frames at the size limits (coordinates up to 32767: staging offsets, float32 edge margins that scale with the frame,
     15-bit region fields), very wide and very tall."""
