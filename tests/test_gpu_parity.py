@@ -725,3 +725,34 @@ def test_crop_resize_and_score_corner_cases(dev):
         score, _ = ops.stability_score(d_stab)
         got = float(score.item())
         assert (np.isnan(got) and np.isnan(want)) or abs(got - want) <= 1e-12 * max(1.0, abs(want)), (F, S, got, want)
+
+
+def test_device_clip_beyond_four_gigabytes(dev):
+    """720 frames of 1080p = 4.48 GB per stack: the byte offsets of frames 690+ lie beyond 2^32 inside ONE launch of the warp, the scan
+    and the crop + resize.  The big launch equals small launches on the same frames (first, around the 4 GiB line, last), and the C
+    oracle on the three frames around the line."""
+    import torch
+    from meshflow_amd import ops, synthetic
+    from oracle import clib
+    F, H, W, R, C = 720, 1080, 1920, 16, 16
+    disp, _ = synthetic.motion(F, R, C, seed=3)
+    stab = np.ascontiguousarray(disp + 0.8 * synthetic.normal(np.arange(disp.size).reshape(disp.shape), seed=9))
+    d_frames = synthetic.frames_torch(F, H, W, dev, seed=3)
+    d_un, d_st = torch.from_numpy(disp).to(dev), torch.from_numpy(stab).to(dev)
+    table = ops.cell_table(d_un, d_st, W, H, R, C)
+    out = ops.warp(d_frames, table, (0, 0, 255))
+    crop = table.crop.clone()
+    table.check()
+    for lo, hi in ((0, 3), (688, 693), (717, 720)):
+        t2 = ops.cell_table(d_un[lo:hi], d_st[lo:hi], W, H, R, C)
+        o2 = ops.warp(d_frames[lo:hi].contiguous(), t2, (0, 0, 255))
+        assert torch.equal(o2, out[lo:hi]) and torch.equal(t2.crop, crop[lo:hi]), (lo, hi)
+    want, want_crop, bad = clib.warp_clip(d_frames[689:692].cpu().numpy(), R, C, disp[689:692], stab[689:692], (0, 0, 255), use_bbox=True, openmp=True)
+    assert bad == 0 and np.array_equal(out[689:692].cpu().numpy(), want) and np.array_equal(crop[689:692].cpu().numpy(), want_crop)
+    rect = (13, 11, 1909, 1068)
+    resized = ops.crop_resize(out, rect)
+    for lo, hi in ((0, 2), (689, 692), (718, 720)):
+        assert torch.equal(ops.crop_resize(out[lo:hi].contiguous(), rect), resized[lo:hi]), (lo, hi)
+    scan_table = ops.cell_table(d_un, d_st, W, H, R, C)
+    ops.crop_scan(scan_table)
+    assert torch.equal(scan_table.crop, crop)
