@@ -298,7 +298,7 @@ int launch_crop_resize(const uint8_t* frames, uint8_t* out, int n, int W, int H,
                        void* work, hipStream_t st)
 {
     if (const int rc = check_d16_zero_fill(st)) return rc;
-    if (n <= 0 || n > 65535 || W < 1 || H < 1 || W > 32767 || H > 32767) {
+    if (n <= 0 || W < 1 || H < 1 || W > 32767 || H > 32767) {           // (any number of frames that make_tile_order can count: 2^31 tiles)
         set_error("mf_crop_resize_u8c3: unsupported shape n=%d W=%d H=%d", n, W, H);
         return MF_ERR_INVALID_ARG;
     }

@@ -1690,7 +1690,8 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
                 uint32_t border, int32_t* crop, hipStream_t st)
 {
     if (const int rc = check_d16_zero_fill(st)) return rc;
-    if (n <= 0 || n > 65535 || W < 2 || H < 2 || W > 32767 || H > 32767 || R <= 0 || C <= 0 || R > MAX_MESH ||
+    // (any number of frames: the launches below take at most 65,535 -- the grid's y extent -- at a time)
+    if (n <= 0 || W < 2 || H < 2 || W > 32767 || H > 32767 || R <= 0 || C <= 0 || R > MAX_MESH ||
         C > MAX_MESH) {
         set_error("mf_warp_u8c3: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
         return MF_ERR_INVALID_ARG;

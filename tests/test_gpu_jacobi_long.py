@@ -175,3 +175,49 @@ def test_jacobi_corner_shapes_equal_the_oracle():
         got = ops.jacobi(torch.from_numpy(b).to(dev), torch.from_numpy(taps).to(dev), torch.from_numpy(lam).to(dev),
                          torch.from_numpy(inv_on).to(dev), omega, iters).cpu().numpy()
         assert np.array_equal(got, want), (F, omega, iters, S)
+
+
+def test_seventy_thousand_frames_through_every_stage():
+    """A clip of 70,000 frames (32 x 16 pixels: 39 minutes at 30 fps) -- more than one launch's 65,535 (the grid's y extent) -- through the
+    device operators and through `stabilize_resident` / `stabilize_clip`: warp, scan, rectangle and crop + resize equal the oracles on
+    frames at both ends and around frame 65,535; the paths within 1e-9 of the banded oracle.  (`mf_warp_u8c3` and `mf_crop_resize_u8c3`
+    refused more than 65,535 frames per call until the end of round 5 although their launch loops handled them.)"""
+    import torch
+    from meshflow_amd import host, ops
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    from oracle import clib, meshflow_oracle as mo
+    dev = torch.device('cuda:0')
+    F, H, W, R, C = 70000, 16, 32, 2, 3
+    rng = np.random.default_rng(6)
+    frames = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
+    vel = rng.normal(0, 0.05, size=(F, R + 1, C + 1, 2))
+    vel[0] = 0
+    disp = np.cumsum(vel, axis=0)
+    hom = np.tile(np.eye(3), (F, 1, 1))
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=4, optimization_num_iterations=6, device='cuda:0')
+    d_frames, d_disp = torch.from_numpy(frames).to(dev), torch.from_numpy(disp).to(dev)
+    out, bounds, d_stab = s.stabilize_resident(d_frames, d_disp, hom)
+    s.finish()
+    stab = d_stab.cpu().numpy()
+    taps, lam, inv_on = host.jacobi_band_coefficients(F, W, H, 0, hom, 4)
+    want_stab = clib.jacobi_banded(disp.reshape(F, -1), taps, lam, inv_on, 4, 6).reshape(disp.shape)
+    np.testing.assert_allclose(stab, want_stab, rtol=0, atol=1e-9)
+    o = out.cpu().numpy()
+    rows = []
+    for lo, hi in ((0, 40), (65500, 65600), (69960, 70000)):
+        want, want_crop, bad = clib.warp_clip(frames[lo:hi], R, C, disp[lo:hi], np.ascontiguousarray(stab[lo:hi]), (0, 0, 255))
+        assert bad == 0 and np.array_equal(o[lo:hi], want), (lo, hi)
+        rows.append(want_crop)
+    table = ops.cell_table(d_disp, d_stab, W, H, R, C)
+    ops.crop_scan(table)
+    crop = table.crop.cpu().numpy()
+    assert np.array_equal(crop[0:40], rows[0]) and np.array_equal(crop[65500:65600], rows[1]) and np.array_equal(crop[69960:], rows[2])
+    rect = [int(crop[:, 0].max()), int(crop[:, 1].max()), int(crop[:, 2].min()), int(crop[:, 3].min())]
+    assert bounds.tolist() == rect and ops.crop_reduce(table.crop, W, H).tolist() == rect
+    resized = ops.crop_resize(out, rect).cpu().numpy()
+    for lo, hi in ((0, 20), (65530, 65540), (69990, 70000)):
+        assert np.array_equal(resized[lo:hi], np.stack(mo.crop_frames(list(o[lo:hi]), rect))), (lo, hi)
+    host_out, host_rect, host_stab, score, cropped = s.stabilize_clip(list(frames), disp, hom, crop=True)
+    assert [int(v) for v in host_rect] == rect and np.array_equal(host_stab, stab)
+    for i in (0, 1, 65535, 65536, 69999):
+        assert np.array_equal(host_out[i], o[i]) and np.array_equal(cropped[i], resized[i]), i
