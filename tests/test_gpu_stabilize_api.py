@@ -281,3 +281,43 @@ def test_drop_in_methods_accept_the_forms_numpy_code_hands_them():
     check(list(frames), disp.astype(np.float32), stab)
     assert np.array_equal(s._get_stabilized_vertex_displacements(F, list(frames), 0, view(disp), hom), stab)
     assert np.array_equal(s._get_stabilized_vertex_displacements(F, list(frames), 0, disp.tolist(), hom.tolist()), stab)
+
+
+def test_stabilize_clip_from_several_host_threads():
+    """The reference is re-entrant per instance (single-threaded NumPy, no shared state).  Here: four host threads with a stabilizer
+    each (different clip shapes), then four threads sharing ONE stabilizer, twelve clips per thread through `stabilize_clip(crop=True)`
+    -- the C pipeline serialises the calls on a device; every result equals the single-threaded one."""
+    import threading
+    from meshflow_amd import synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    clips = []
+    for seed in range(4):
+        F, H, W, R, C = 24 + 4 * seed, 120, 160 + 32 * seed, 4, 4 + seed
+        frames, disp, hom = synthetic.clip(F, H, W, R, C, seed=seed, kind='noise', jitter_sigma=0.8)
+        clips.append((list(frames), disp, hom, R, C))
+    make = lambda R, C: MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=4, optimization_num_iterations=8, device='cuda:0')
+    ref = []
+    for fr, disp, hom, R, C in clips:
+        out, rect, stab, score, cropped = make(R, C).stabilize_clip(fr, disp, hom, crop=True)
+        ref.append((np.stack(out), tuple(int(v) for v in rect), stab, np.stack(cropped)))
+    errors = []
+
+    def worker(i, shared):
+        fr, disp, hom, R, C = clips[i]
+        s = shared if shared is not None else make(R, C)
+        for _ in range(12):
+            try:
+                out, rect, stab, score, cropped = s.stabilize_clip(fr, disp, hom, crop=True)
+                if not (np.array_equal(np.stack(out), ref[i][0]) and tuple(int(v) for v in rect) == ref[i][1]
+                        and np.array_equal(stab, ref[i][2]) and np.array_equal(np.stack(cropped), ref[i][3])):
+                    errors.append(('mismatch', i))
+            except Exception as e:                                   # noqa: BLE001 -- reported below
+                errors.append((type(e).__name__, str(e)[:100]))
+
+    for shared in (None, make(clips[0][3], clips[0][4])):
+        threads = [threading.Thread(target=worker, args=(i if shared is None else 0, shared)) for i in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors[:4]
