@@ -653,7 +653,10 @@ class MeshFlowStabilizer:
         comes first, and names the clip by its serial number; check=True waits for it before returning (one blocking device-to-host
         read per clip: the calls no longer overlap), check='never' skips it.  Clips after a degenerate one are unaffected.
         warp_events / jacobi_events: pairs of torch events recorded around the warp kernel (caller's stream) and the sweep stage (prep
-        stream) -- bench.py's roofline brackets."""
+        stream) -- bench.py's roofline brackets.
+        One host thread per stabilizer object here: the calls of a pipeline are ordered by construction (table slots take turns, the
+        deferred verdicts are kept per slot); threads that want their own pipelines take their own objects (the host-memory methods,
+        `stabilize_clip` and the drop-in pair, may be called from several threads on one object: tests/test_gpu_stabilize_api.py)."""
         import torch
         from . import dist as mfdist
         self._check_definition(adaptive_weights_definition)
