@@ -756,3 +756,32 @@ def test_device_clip_beyond_four_gigabytes(dev):
     scan_table = ops.cell_table(d_un, d_st, W, H, R, C)
     ops.crop_scan(scan_table)
     assert torch.equal(scan_table.crop, crop)
+
+
+def test_non_finite_and_huge_paths_never_fault(dev):
+    """NaN, +-inf, 1e300, 1e18, 1e7, -1e5 and a denormal in the stabilized paths -- at one vertex, in one frame, everywhere: the cell
+    table counts exactly the cells the oracle counts as having no homography, the frames of the remaining ones equal the oracle's,
+    and nothing faults (the reference would die inside cv2 on most of these)."""
+    import torch
+    from meshflow_amd import ops
+    from oracle import clib
+    rng = np.random.default_rng(2)
+    H, W, R, C, n = 48, 64, 3, 4, 3
+    frames = rng.integers(0, 256, size=(n, H, W, 3), dtype=np.uint8)
+    unstab = np.zeros((n, R + 1, C + 1, 2))
+    for poison in (np.nan, np.inf, -np.inf, 1e300, 1e18, 1e7, -1e5, 5e-324):
+        for where in range(3):
+            stab = rng.normal(0, 0.5, size=(n, R + 1, C + 1, 2))
+            if where == 0:
+                stab[1, 2, 2, 0] = poison
+            elif where == 1:
+                stab[1] = poison
+            else:
+                stab[:] = poison
+            want, want_crop, want_bad = clib.warp_clip(frames, R, C, unstab, stab, (1, 2, 3))
+            table = ops.cell_table(torch.from_numpy(unstab).to(dev), torch.from_numpy(stab).to(dev), W, H, R, C)
+            out = ops.warp(torch.from_numpy(frames).to(dev), table, (1, 2, 3))
+            torch.cuda.synchronize()
+            assert int(table.status.item()) == want_bad, (poison, where)
+            if not want_bad:
+                assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(table.crop.cpu().numpy(), want_crop), (poison, where)
