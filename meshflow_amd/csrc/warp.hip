@@ -596,8 +596,14 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     typedef uint32_t spec2_t __attribute__((ext_vector_type(2)));
     spec16_t hg_lo;
     spec2_t hg_hi;
-    const uint32_t k_guess = SCAN ? 0u : min(__umulhi((uint32_t)ya + FOOT_H / 2, g.cell_mul_y) * g.mesh_cols + __umulhi((uint32_t)xa + FOOT_W / 2, g.cell_mul_x), g.cell_last);
-    if (!SCAN) {
+    // ONLY in the instantiation that has a hot path (STAGE_OK && !SCAN).  Anywhere else the registers would be dead right behind the asm
+    // statement, the compiler would hand them to the plan words' loads two lines further down, and -- scalar loads return out of order
+    // -- whichever load lands last would win: a footprint of a frame stack that is not 4-byte aligned (odd frame sizes cut into frame
+    // ranges: warp_kernel<false>) then ran on a few bytes of some cell's matrix instead of its plan about once in 200 launches and left
+    // rows unwritten (found by a sweep over mf_warp_clip_u8c3's chunkings at the end of round 5).
+    constexpr bool SPECULATE = STAGE_OK && !SCAN;
+    const uint32_t k_guess = !SPECULATE ? 0u : min(__umulhi((uint32_t)ya + FOOT_H / 2, g.cell_mul_y) * g.mesh_cols + __umulhi((uint32_t)xa + FOOT_W / 2, g.cell_mul_x), g.cell_last);
+    if (SPECULATE) {
         const uint64_t gaddr = (uint64_t)(uintptr_t)records + ((uint64_t)f * g.rec_frame_bytes + (uint64_t)k_guess * (uint32_t)(MF_CELL_DOUBLES * sizeof(double)));
         static_assert(MF_CELL_OFF_HI * sizeof(double) == 0x48 && MF_CELL_DOUBLES * sizeof(double) == 256, "offsets in the asm below");
         asm volatile("s_load_dwordx16 %0, %2, 0x48\n\ts_load_dwordx2 %1, %2, 0x88" : "=&s"(hg_lo), "=&s"(hg_hi) : "s"(gaddr));     // (early clobber: the address pair is read by both loads)

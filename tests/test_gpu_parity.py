@@ -785,3 +785,42 @@ def test_non_finite_and_huge_paths_never_fault(dev):
             assert int(table.status.item()) == want_bad, (poison, where)
             if not want_bad:
                 assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(table.crop.cpu().numpy(), want_crop), (poison, where)
+
+
+def test_unaligned_frame_stacks_repeatedly(dev):
+    """Frame stacks that do not start on a 4-byte boundary (odd frame sizes cut into frame ranges, a caller's slice) run
+    `warp_kernel<false>`.  Until the end of round 5 that instantiation still issued the hot path's speculative matrix load: its
+    destination registers were dead there, the compiler reused them for the lane mask while the load was in flight, and about one
+    launch in 200 left rows unwritten.  600 launches from an odd address and every chunking of `mf_warp_clip_u8c3` on 9 x 17 pixel
+    frames: every byte as the aligned launch wrote it."""
+    import itertools
+    import torch
+    from meshflow_amd import ops, synthetic
+    n, H, W, R, C = 33, 17, 9, 1, 1
+    frames, disp, _ = synthetic.clip(n, H, W, R, C, seed=50, kind='noise', jitter_sigma=0.8)
+    stab = np.ascontiguousarray(disp + 0.5 * synthetic.normal(np.arange(disp.size).reshape(disp.shape), seed=33))
+    d_un, d_st = torch.from_numpy(disp).to(dev), torch.from_numpy(stab).to(dev)
+    d_fr = torch.from_numpy(frames).to(dev)
+    table = ops.cell_table(d_un, d_st, W, H, R, C)
+    ref = ops.warp(d_fr, table, (4, 5, 6)).clone()
+    table.check()
+    raw_in = torch.zeros(d_fr.numel() + 8, dtype=torch.uint8, device=dev)
+    raw_out = torch.zeros(d_fr.numel() + 8, dtype=torch.uint8, device=dev)
+    for shift in (1, 2, 3):
+        src = raw_in[shift:shift + d_fr.numel()].view(d_fr.shape)
+        src.copy_(d_fr)
+        dst = raw_out[shift:shift + d_fr.numel()].view(d_fr.shape)
+        for _ in range(200):
+            dst.fill_(0xEE)
+            ops.warp(src, table, (4, 5, 6), out=dst)
+            assert torch.equal(dst, ref), shift
+    for trial, (chunks, own) in enumerate(itertools.product((1, 2, 3, 7, 33, 40), (False, True))):
+        prep = torch.cuda.Stream(device=dev) if own else None
+        for _ in range(60):
+            t2 = ops.CellTable(n, W, H, R, C, dev)
+            out = torch.full_like(d_fr, 0xEE)
+            if prep is not None:
+                prep.wait_stream(torch.cuda.current_stream())
+            got, bounds = ops.warp_clip(d_fr, d_un, d_st, t2, (4, 5, 6), out=out, chunks=chunks, prep_stream=prep)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref) and torch.equal(t2.crop, table.crop), (chunks, own)
