@@ -49,11 +49,16 @@ def run(cases, seed, verbose=True, large=False, tiny=False):
           stab = rng.uniform(5.0, 15.0) * synthetic.normal(idx, seed=3000 + case)
       frames = synthetic.frames_numpy(n, H, W, seed=case, kind='noise')
       want, want_crop, bad = clib.warp_clip(frames, R, C, unstab, stab)
-      d_fr = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
+      # three cases in four from / into a stack that does NOT start on a 4-byte boundary (warp_kernel<false>: no staged windows)
+      shift = case % 4
+      raw_in = torch.zeros(frames.size + 8, dtype=torch.uint8, device=dev)
+      raw_out = torch.full((frames.size + 8,), 0xEE, dtype=torch.uint8, device=dev)
+      d_fr = raw_in[shift:shift + frames.size].view(frames.shape)
+      d_fr.copy_(torch.from_numpy(np.ascontiguousarray(frames)).to(dev))
       try:
           table = ops.cell_table(torch.from_numpy(unstab).to(dev), torch.from_numpy(np.ascontiguousarray(stab)).to(dev), W, H, R, C)
           scanned = ops.crop_scan(table).clone()                  # the scan-only pass (mf_crop_scan_f64) must fill the same values
-          out = ops.warp(d_fr, table, (0, 0, 255))
+          out = ops.warp(d_fr, table, (0, 0, 255), out=raw_out[shift:shift + frames.size].view(frames.shape))
           torch.cuda.synchronize()
           table.check()
       except ValueError as e:
