@@ -11,6 +11,8 @@ from meshflow_amd.stabilizer import MeshFlowStabilizer
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 F, H, W, R, C = 96, 720, 1280, 16, 16
+if len(sys.argv) > 3 and sys.argv[3] == 'odd':            # frames of 333 x 251 pixels = 250,749 bytes: every other ring slot starts at an odd address
+    F, H, W, R, C = 150, 251, 333, 7, 5
 dev = torch.device('cuda:0')
 base = synthetic.frames_torch(8, H, W, dev, seed=3).cpu().numpy()
 frames = [np.ascontiguousarray(base[i % 8] ^ np.uint8(i)) for i in range(F)]
