@@ -708,10 +708,17 @@ def test_crop_resize_and_score_corner_cases(dev):
             t, b = sorted(rng.integers(0, H, size=2))
             rects.add((int(l), int(t), int(r), int(b)))
         d_frames = torch.from_numpy(frames).to(dev)
+        # (and from / into stacks that do not start on a 4-byte boundary)
+        raw_in = torch.zeros(frames.size + 8, dtype=torch.uint8, device=dev)
+        raw_out = torch.zeros(frames.size + 8, dtype=torch.uint8, device=dev)
+        src = raw_in[1:1 + frames.size].view(frames.shape)
+        src.copy_(d_frames)
+        dst = raw_out[3:3 + frames.size].view(frames.shape)
         for rect in sorted(rects):
             n += 1
             want = np.stack(mo.crop_frames(list(frames), rect))
             assert np.array_equal(ops.crop_resize(d_frames, rect).cpu().numpy(), want), (W, H, nfr, rect)
+            assert np.array_equal(ops.crop_resize(src, rect, out=dst).cpu().numpy(), want), ('unaligned', W, H, nfr, rect)
     assert n > 1500
     for F, S in itertools.product((1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 33, 64, 65), (2, 8, 50)):
         stab = np.cumsum(rng.normal(size=(F, S // 2, 1, 2)), axis=0)
