@@ -268,3 +268,56 @@ def test_frame_range_shards_down_to_empty_ones():
         assert empties == 2
         r = np.array(rects[:8])
         assert [int(r[:, 0].max()), int(r[:, 1].max()), int(r[:, 2].min()), int(r[:, 3].min())] == b_full.tolist()
+
+
+def test_resident_pipelines_of_several_threads_on_streams_of_their_own():
+    """Four host threads, each with its own stabilizer and torch stream, 100 resident clips each without waiting for one another (in
+    order and in two frame ranges, whose events the library shares per device): every clip's frames, rectangle and paths equal the
+    single-threaded result."""
+    import threading
+    import torch
+    from meshflow_amd import synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    dev = torch.device('cuda:0')
+    jobs = []
+    for i, (F, H, W, R, C) in enumerate(((40, 360, 640, 16, 16), (30, 250, 333, 7, 5), (24, 720, 1280, 8, 8), (50, 96, 128, 4, 4))):
+        disp, hom = synthetic.motion(F, R, C, seed=i)
+        d_frames = synthetic.frames_torch(F, H, W, dev, seed=i)
+        d_disp = torch.from_numpy(disp).to(dev)
+        s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=5, optimization_num_iterations=20, device='cuda:0')
+        out, b, st = s.stabilize_resident(d_frames, d_disp, hom)
+        s.finish()
+        torch.cuda.synchronize()
+        jobs.append((d_frames, d_disp, hom, (R, C), out.clone(), b.tolist(), st.clone()))
+    errors = []
+
+    def worker(i, chunks):
+        d_frames, d_disp, hom, (R, C), ref, ref_bounds, ref_stab = jobs[i]
+        s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=5, optimization_num_iterations=20, device='cuda:0')
+        s.resident_chunks = chunks
+        stream = torch.cuda.Stream(device=dev)
+        try:
+            with torch.cuda.stream(stream):
+                queue = []
+                for _ in range(100):
+                    queue.append(s.stabilize_resident(d_frames, d_disp, hom))
+                    if len(queue) >= 4:
+                        out, b, st = queue.pop(0)
+                        stream.synchronize()
+                        if not (torch.equal(out, ref) and b.tolist() == ref_bounds and torch.equal(st, ref_stab)):
+                            errors.append(('mismatch', i, chunks))
+                s.finish()
+                stream.synchronize()
+                for out, b, st in queue:
+                    if not (torch.equal(out, ref) and b.tolist() == ref_bounds and torch.equal(st, ref_stab)):
+                        errors.append(('mismatch at the end', i, chunks))
+        except Exception as e:                                       # noqa: BLE001 -- reported below
+            errors.append((type(e).__name__, str(e)[:100]))
+
+    for chunks in (0, 2):
+        threads = [threading.Thread(target=worker, args=(i, chunks)) for i in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors[:4]
