@@ -5,8 +5,17 @@ Python, in csrc/hostpipe.hip (ONE implementation: `mf_warp_u8c3_host_frames`, `m
 import numpy as np
 
 
+def _need_u8(a):
+    """cv2.remap runs its 8-bit fixed-point path on uint8 frames only (mfs.py:1063-1069: what a VideoCapture delivers); float or 16-bit
+    frames would take other OpenCV code with other arithmetic -- refused instead of silently cast."""
+    if a.dtype != np.uint8:
+        raise TypeError(f'frames must be uint8 (got {a.dtype}): the warp reproduces cv2.remap\'s 8-bit fixed-point interpolation')
+
+
 def _as_frame(frame, height, width):
-    a = np.ascontiguousarray(frame, dtype=np.uint8)
+    a = np.asarray(frame)
+    _need_u8(a)
+    a = np.ascontiguousarray(a)
     if a.shape != (height, width, 3):
         raise ValueError(f'every frame must have shape ({height}, {width}, 3), got {a.shape}')
     return a
@@ -19,7 +28,8 @@ class HostClip:
         if isinstance(frames, np.ndarray):
             if frames.ndim != 4 or frames.shape[0] != num_frames or frames.shape[3] != 3:
                 raise ValueError('frames must be num_frames arrays of shape (H, W, 3)')
-            self.array = np.ascontiguousarray(frames, dtype=np.uint8)
+            _need_u8(frames)
+            self.array = np.ascontiguousarray(frames)
             self.frames = None
             self.height, self.width = self.array.shape[1:3]
         else:
@@ -28,6 +38,7 @@ class HostClip:
             first = np.asarray(frames[0])
             if first.ndim != 3 or first.shape[2] != 3:
                 raise ValueError('frames must be num_frames arrays of shape (H, W, 3)')
+            _need_u8(first)
             self.array = None
             self.frames = frames
             self.height, self.width = first.shape[:2]

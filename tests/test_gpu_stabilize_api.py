@@ -321,3 +321,38 @@ def test_stabilize_clip_from_several_host_threads():
         for t in threads:
             t.join()
         assert not errors, errors[:4]
+
+
+def test_malformed_inputs_are_refused_with_python_errors():
+    """The reference's error convention is Python exceptions (mfs.py:136-146, 205-208): a frame of another size, a grey or 4-channel
+    frame, a clip shorter than its paths, paths of another mesh, homographies of another length, an empty clip, an unknown
+    definition -> ValueError; frames that are not uint8 (float or 16-bit frames would take another cv2.remap code path) -> TypeError.
+    Read-only frames and the same frame object six times are fine.  The path method looks at the first frame's SHAPE only."""
+    from meshflow_amd import synthetic
+    from meshflow_amd.stabilizer import MeshFlowStabilizer
+    F, H, W, R, C = 6, 48, 64, 2, 2
+    frames, disp, hom = synthetic.clip(F, H, W, R, C, seed=3, kind='noise')
+    fl = list(frames)
+    s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=3, optimization_num_iterations=5, device='cuda:0')
+    for bad in (fl[:3] + [np.zeros((40, 64, 3), np.uint8)] + fl[4:], fl[:3] + [np.zeros((48, 64), np.uint8)] + fl[4:],
+                [np.zeros((48, 64, 4), np.uint8)] * F, fl[:4], []):
+        with pytest.raises(ValueError):
+            s.stabilize_clip(bad, disp, hom)
+    with pytest.raises(ValueError):
+        s.stabilize_clip(fl, disp[:, :2], hom)
+    with pytest.raises(ValueError):
+        s.stabilize_clip(fl, disp, hom[:3])
+    with pytest.raises(ValueError):
+        s.stabilize_clip(fl, disp, hom, adaptive_weights_definition=7)
+    for bad in ([f.astype(np.float32) for f in fl], [f.astype(np.uint16) for f in fl], frames.astype(np.float64)):
+        with pytest.raises(TypeError):
+            s.stabilize_clip(bad, disp, hom)
+        with pytest.raises(TypeError):
+            s._get_stabilized_frames_and_crop_boundaries(F, bad, disp, disp)
+    ref = s.stabilize_clip(fl, disp, hom, crop=True)
+    ro = s.stabilize_clip([np.frombuffer(f.tobytes(), np.uint8).reshape(f.shape) for f in fl], disp, hom, crop=True)
+    assert np.array_equal(np.stack(ro[0]), np.stack(ref[0])) and np.array_equal(np.stack(ro[4]), np.stack(ref[4]))
+    same = s.stabilize_clip([fl[0]] * F, disp, hom, crop=True)
+    assert len(same[0]) == F
+    stab = s._get_stabilized_vertex_displacements(F, [f.astype(np.float32) for f in fl], 0, disp, hom)      # (shape only: mfs.py:679)
+    assert np.array_equal(stab, ref[2])
