@@ -1446,6 +1446,8 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
             const uint32_t o = ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u;
             if (fast_store) {                                           // W % 4 == 0: an active lane's four pixels are all inside
                 *reinterpret_cast<uint3*>(dst + o) = d;
+            } else if (x0 + 3 < W) {                                    // all four inside, at a byte address of any alignment: one unaligned 12-byte store
+                __builtin_memcpy(dst + o, &d, 12);
             } else {
                 const int nb = 3 * min(4, W - x0);                       // W % 4 != 0: byte by byte, up to the row end
 #pragma unroll 1
