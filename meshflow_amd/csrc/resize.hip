@@ -136,12 +136,13 @@ __device__ __forceinline__ void vpass_store(const uint32_t (&T0)[4][3], const ui
         const uint32_t vR = (mulhi_u24(b0s, T0[j][2]) + mulhi_u24(b1s, T1[j][2]) + 2u) >> 2;
         px[j] = vB | (vG << 8) | (vR << 16);
     }
-    if ((W & 3) == 0 && x0 + 3 < W) {
+    if (x0 + 3 < W) {
         uint3 d;
         d.x = px[0] | (px[1] << 24);
         d.y = (px[1] >> 8) | (px[2] << 16);
         d.z = (px[2] >> 16) | (px[3] << 8);
-        *reinterpret_cast<uint3*>(dst + o) = d;
+        if ((W & 3) == 0) *reinterpret_cast<uint3*>(dst + o) = d;
+        else __builtin_memcpy(dst + o, &d, 12);                  // (a row of W % 4 != 0 starts anywhere: one unaligned 12-byte store)
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
