@@ -215,8 +215,8 @@ int mf_warp_u8c3_host(const uint8_t* frames, uint8_t* out, const double* unstab,
  * frames[i] / out[i] point to frame i, H*W*3 bytes each.  mf_warp_u8c3_host is this with frames[i] = frames + i*H*W*3.
  * Both move the clip in chunks of ~16 MB (3 frames at 1080p, 1 at 4K) on four upload and four download threads with their own
  * HIP streams (each takes the next chunk when it is free; plus eight threads that fault the output pages in ahead of the downloads)
- * through a RING of ~900 MB of chunk buffers per direction (48 slots at 1080p, 36 at 4K) -- device memory is O(chunk) whatever the
- * length of the clip (1.8 GB of ring for any 1080p or 4K clip); a chunk is warped
+ * through a RING of ~720 MB of chunk buffers per direction (40 slots at 1080p, 30 at 4K) -- device memory is O(chunk) whatever the
+ * length of the clip (1.5 GB of ring, ~1.75 GB in all at the peak, for any 1080p or 4K clip); a chunk is warped
  * as soon as it has landed (its cell table + plan are built right in front of its warp) and travels back while later chunks are still
  * going up (pageable memory is fine; memory from mf_malloc_host makes the copies truly asynchronous).  MF_PIPE_CHUNK (frames per
  * chunk) / MF_PIPE_SLOTS / MF_PIPE_UP / MF_PIPE_DOWN / MF_PIPE_POPULATE in the environment retune it

@@ -3,8 +3,8 @@
 // memory out, with the PCIe transfers chunked and overlapped with each other and with the kernels.
 //
 // The clip moves in chunks of ~16 MB (3 frames at 1080p, 1 at 4K; MF_PIPE_CHUNK = frames per chunk overrides) through a RING of
-// ~900 MB of chunk-sized device buffers per direction (MF_PIPE_SLOTS overrides the slot count): device memory is O(chunk), whatever the
-// length of the clip (2,000 frames of 1080p and all 1,200 frames of config 4's 4K clip go through 1.8 GB of ring).  UP host threads each
+// ~720 MB of chunk-sized device buffers per direction (MF_PIPE_SLOTS overrides the slot count): device memory is O(chunk), whatever the
+// length of the clip (2,000 frames of 1080p and all 1,200 frames of config 4's 4K clip go through 1.5 GB of ring).  UP host threads each
 // own a HIP stream and copy the next chunk that has not gone up yet into the ring slot chunk k % slots -- once the download of the chunk that used the slot before has ended (an event
 // wait on the upload stream, no host synchronisation) -- (pageable memory is fine: the runtime stages it; pinned memory --
 // mf_malloc_host -- makes the copies truly asynchronous); the calling thread waits for chunk k's upload event, launches the cell table
@@ -46,7 +46,9 @@ namespace {
 // 1080p, interleaved repetitions, frames/s without | with the crop: 8 frames x 18 slots 5,330 | 5,510, 4 x 36 5,480 | 6,040,
 // 3 x 48 5,880 | 6,030, 2 x 64 5,660 | 5,910;  4K 2 x 18 1,570 | 1,510, 1 x 36 1,655 | 1,545.
 constexpr size_t PIPE_CHUNK_BYTES = (size_t)16 << 20;    // bytes per chunk: 3 frames at 1080p, 1 at 4K (MF_PIPE_CHUNK = frames overrides)
-constexpr size_t PIPE_RING_BYTES = (size_t)900 << 20;    // ring per direction: 48 slots at 1080p, 36 at 4K (MF_PIPE_SLOTS overrides), for a clip of any length
+// (720 MiB: 40 slots at 1080p, 30 at 4K.  900 MiB were no faster and left the whole pipeline -- rings + a 92 MiB scan table + vertex paths,
+// with a transient of up to ~190 MiB on top -- at 2.04-2.09 GiB of device memory; now 1.55 GiB steady, 1.73 at the peak.)
+constexpr size_t PIPE_RING_BYTES = (size_t)720 << 20;    // ring per direction (MF_PIPE_SLOTS overrides the slot count), for a clip of any length
 constexpr int PIPE_SLOTS_MAX = 64;
 constexpr size_t PIPE_SCAN_TABLE_BYTES = (size_t)96 << 20;   // scratch table of the rectangle pre-pass: ~330 frames of 1080p at a 16 x 16 mesh per piece
 constexpr int PIPE_UP = 4;         // upload threads / streams   (round 5, 16 MB chunks, frames/s at config 2: 3+3 5,730-6,080, 4+4 5,880-6,030, 6+6 5,070-5,100)
