@@ -328,14 +328,14 @@ def visible_gpus():
         return None if os.path.exists('/dev/kfd') else 0          # no kernel driver at all: no GPU
 
 
-def launch_children(args):
+def launch_children(args, script=None, argv=None, check_gpus=True):
     """`python bench.py --gpus N` by itself: N fresh child processes, one per GPU, with torchrun's environment.  Nothing in
     this parent touches a GPU, torch.cuda or HIP (the device count comes from /sys, else --gpus is trusted); children are separate
     processes started with subprocess -- never an exec of a process that has initialised the GPU.  Exit code: the first non-zero
     child code; when a rank dies the others are terminated by exact PID, and killed if they ignore that for 10 s (a rank stuck in a
-    collective may)."""
+    collective may).  (script / argv / check_gpus: tests/test_bench_launcher.py starts eight stand-in ranks on a box without GPUs.)"""
     backend = os.environ.get('MESHFLOW_DIST_BACKEND', 'nccl')
-    visible = visible_gpus()
+    visible = visible_gpus() if check_gpus else None
     if visible is not None and (visible < 1 or (backend == 'nccl' and visible < args.gpus)):
         print(f'bench.py: --gpus {args.gpus} but {visible} GPU(s) visible (one rank per GPU under RCCL; '
               f'MESHFLOW_DIST_BACKEND=gloo lets ranks share a GPU for functional tests)', file=sys.stderr)
@@ -351,7 +351,7 @@ def launch_children(args):
         # "hipIpcGetMemHandle: invalid argument" -- the build environment's own note; an operator's setting wins)
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cpus() // args.gpus)))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv)), env=env))
     rc = 0
     pending = list(procs)
     deadline = None                              # set when the survivors have been asked to stop

@@ -259,7 +259,11 @@ int mf_host_cache_release(void);
  *   mf_gather_frames         d_shards[g] (shard_bytes[g] bytes on device g, the stabilized frames of rank g's frame range) ->
  *                            d_dst on device `root`, back to back in rank order: one group of ncclSend / ncclRecv with
  *                            per-rank byte counts (shards are ragged when ndev does not divide the frame count)
- *   mf_comm_destroy          frees the communicators and streams */
+ *   mf_comm_destroy          frees the communicators and streams
+ * STATUS: exercised with ONE rank only (tests/test_gpu_nccl_one_rank.py; no multi-GPU node was ever available to the build).  It is
+ * the exchange for a single-process C/C++ host that binds this library directly; the Python product and
+ * `bench.py --gpus N` do NOT use it -- their one exchange implementation is meshflow_amd/dist.py (one process per GPU,
+ * torch.distributed: "nccl" = RCCL), covered at world_size 2 and 8 under gloo (tests/test_dist_gloo.py, tests/test_dist_gloo8.py). */
 int mf_comm_init_all(int ndev);
 int mf_comm_size(int* ndev);
 int mf_allreduce_crop(int32_t* const* d_bounds);

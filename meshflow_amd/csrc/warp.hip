@@ -668,7 +668,12 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     // taps are addressed by absolute LDS byte address (= LDS_PITCH iy + 3 ix - lds_origin): the window base is folded in
     const uint32_t lds_origin = (rg & MF_REGION_ORIGIN_MASK) - (uint32_t)(uintptr_t)&s_src[0];
     const crec_t frec = (crec_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(records) + f * g.rec_frame_bytes);
+#ifdef MF_ROWMAP
+    const int y_nat = ya + (lane >> 3);
+    const int y = y_nat;
+#else
     const int y = ya + (lane >> 3);
+#endif
     const int x0 = xa + (lane & 7) * 4;                                  // first of this lane's 4 pixels
     const double xs0 = (double)x0, yy = (double)y;
 
@@ -689,6 +694,14 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
             uint8_t* __restrict__ dst2 = out + (uint64_t)f * g.frame_bytes;
             *reinterpret_cast<uint3*>(dst2 + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d2;
         }
+#endif
+#ifdef MF_ROWMAP
+        // COMPACT windows (pitch 112 bytes = 28 banks): with the natural lane -> row mapping the four rows a group of 32 lanes covers
+        // start 0, 28, 24, 20 banks apart (mod 32) and eight lanes of a row take every third bank -- rows 0 and 3 collide on four banks:
+        // every byte-tap instruction takes 3 LDS cycles per lane group instead of 2.  Rows 0, 2, 4, 6 (lanes 0-31) and 1, 3, 5, 7
+        // (lanes 32-63) start 0, 24, 16, 8 banks apart: no two lanes of a group on one bank.
+        const int y = (rg & MF_REGION_COMPACT) ? ya + (int)((((uint32_t)lane >> 2) & 6u) | ((uint32_t)lane >> 5)) : y_nat;
+        const double yy = (double)y;
 #endif
         float u[4], v[4];
 #ifndef MF_NO_FAST64

@@ -1,8 +1,11 @@
 """bench.py --gpus N without a launcher: the parent refuses cleanly (exit code 2, no JSON) when the box has too few GPUs --
-here: none -- before starting any child."""
+here: none -- before starting any child; and its launcher with EIGHT stand-in ranks (tests/fake_rank.py) under gloo: environment,
+free port, rank 0's single line, and what happens when a rank dies or hangs."""
+import json
 import os
 import subprocess
 import sys
+import time
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -46,3 +49,39 @@ def test_scale_all_dry_run_commands_parse():
     # and the launcher's own default run: flags of the driver's command line
     a = parser.parse_args(['--gpus', '8', '--steps', '20', '--warmup', '5'])
     assert (a.gpus, a.steps, a.warmup, a.workload, a.mode) == (8, 20, 5, 'cfg2', 'shard')
+
+
+_LAUNCH = """
+import sys, types
+sys.path.insert(0, {repo!r})
+import bench
+raise SystemExit(bench.launch_children(types.SimpleNamespace(gpus=8), script={script!r}, argv={argv!r}, check_gpus=False))
+"""
+
+
+def _launch8(argv, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['MESHFLOW_DIST_BACKEND'] = 'gloo'
+    code = _LAUNCH.format(repo=REPO, script=os.path.join(REPO, 'tests', 'fake_rank.py'), argv=argv)
+    t0 = time.monotonic()
+    proc = subprocess.run([sys.executable, '-c', code], cwd=REPO, capture_output=True, text=True, timeout=timeout, env=env)
+    return proc, time.monotonic() - t0
+
+
+def test_launcher_eight_ranks_one_line():
+    """Eight children with torchrun's environment on a port the launcher picked: every collective bench.py's timing uses completes, the
+    ragged partition (300 = 38 x 7 + 34) sums to the clip, rank 0 alone prints."""
+    proc, _ = _launch8(['--frames', '300'])
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip() and not l.startswith('[Gloo]')]       # (gloo announces its peers on stdout)
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {'n_gpus': 8, 'elapsed': 0.008, 'frames': 300, 'bounds': [7, 14, 93, 36]}
+
+
+def test_launcher_ends_the_others_when_a_rank_dies():
+    """Rank 5 exits with code 3 before the first barrier; rank 6 ignores SIGTERM.  The launcher returns 3, has terminated the
+    stranded ranks and killed the deaf one -- within its 10 s grace period, not after gloo's timeout."""
+    proc, took = _launch8(['--die', '5', '3', '--hang', '6'])
+    assert proc.returncode == 3 and not [l for l in proc.stdout.splitlines() if l.startswith('{')]
+    assert took < 60
