@@ -376,7 +376,7 @@ def launch_children(args, script=None, argv=None, check_gpus=True):
 
 class KernelPath:
     """The timed step: K passes of the PRODUCT's device-resident pipeline through its PUBLIC method, `MeshFlowStabilizer.stabilize_resident`
-    (no private stages, default degenerate-mesh check: deferred, `finish()` once inside the timed region) -- host coefficient set-up, Jacobi
+    (no private stages; the degenerate-mesh check opted into its DEFERRED form, `finish()` once inside the timed region) -- host coefficient set-up, Jacobi
     sweep on the stabilizer's prep stream, cell table + plan, the warp alone, the clip rectangle folded together by the kernel (-> 16-byte
     all-reduce at N > 1), inputs resident in HBM, clips issued back to back.  HIP events bracket the warp kernel on the caller's stream and
     the sweep stage on the prep stream (the streams they are launched on).  `serial`: the same kernels in order on ONE stream (private
@@ -396,7 +396,7 @@ class KernelPath:
         we, je = events if events else (None, None)
         _, bounds, d_stab = self.stab.stabilize_resident(self.d_frames, self.d_disp, self.hom, out=self.d_out, frame_range=self.range,
                                                          inputs_ready=self.inputs_ready, collective=self.collective,
-                                                         warp_events=we, jacobi_events=je)
+                                                         warp_events=we, jacobi_events=je, check='deferred')
         return d_stab, bounds
 
     def serial_step(self, events=None):

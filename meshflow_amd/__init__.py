@@ -1,5 +1,5 @@
 """meshflow_amd: MI355X-native implementation of MeshFlowStabilizer's dense inner path
 (Jacobi temporal smoothing + per-cell mesh warp).  See DESIGN.md."""
-from .stabilizer import MeshFlowStabilizer  # noqa: F401
+from .stabilizer import DegenerateMeshError, MeshFlowStabilizer  # noqa: F401
 
-__all__ = ['MeshFlowStabilizer']
+__all__ = ['MeshFlowStabilizer', 'DegenerateMeshError']

@@ -560,6 +560,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             // u < 1 but u >= ix_lo + 1/16 - 1/100; |u - (W-1)| < 1 needs u > W - 2 but u < ix_hi - 1/16 + 1/100 (mfs.py:1075-1098).
             const bool interior = whole && inside;
             const bool deep = covered && interior;
+            bool certified = false;                  // one of the warp kernel's three certified shapes: hot, pair, multi
             region.flags_origin = MF_REGION_STAGED | (deep ? MF_REGION_DEEP : 0u) | (noflag ? MF_REGION_NOFLAG : 0u) | ((uint32_t)sy0 * MF_STAGE_PITCH + bs);
             region.src_dwords = ((uint32_t)sy0 * (3u * (uint32_t)W) + bs) >> 2;
             // The premises of the warp kernel's cheap coordinate chain (warp.hip, cheap_quotients) for EVERY listed cell on this footprint:
@@ -575,17 +576,7 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
                 // the premises of the warp kernel's error bound for its cheap coordinate chain (warp.hip, cell_coords_fast)
                 const bool fast64 = cheap_all;
                 p.e[1] = (uint16_t)(MF_PLAN_UNIT | MF_PLAN_HOT | (fast64 ? MF_PLAN_FAST64 : 0u));
-#ifndef MF_NO_COMPACT            // (A/B switch shared with warp.hip: both sides must agree on the window layout)
-                // COMPACT window: 9 rows x 112 bytes hold every tap -> one global->LDS load instead of two
-                const uint32_t cbs = (3u * (uint32_t)ix_lo) & ~3u;
-                if (iy_hi - iy_lo + 1 <= MF_COMPACT_ROWS && 3u * (uint32_t)ix_hi + 3u <= cbs + MF_COMPACT_PITCH &&
-                    iy_lo + MF_COMPACT_ROWS <= H - 1 && cbs + 16u <= 3u * (uint32_t)W) {      // (the load's 64th chunk: the first 16 bytes of
-                                                                                            // row sy0 + 9 from byte cbs -- inside that row, hence
-                                                                                            // inside the clip even on its last frame)
-                    region.flags_origin = MF_REGION_STAGED | MF_REGION_DEEP | MF_REGION_NOFLAG | MF_REGION_COMPACT | ((uint32_t)iy_lo * MF_COMPACT_PITCH + cbs);
-                    region.src_dwords = ((uint32_t)iy_lo * (3u * (uint32_t)W) + cbs) >> 2;
-                }
-#endif
+                certified = true;
             }
             // the pair shape (`covered`: the second cell is IN, or the two single-edge masks overlap across the footprint)
             if (deep && !overflow && cnt == 2 && single_ok[0] && !(p.e[0] & MF_PLAN_IN) && wlo_all > 0.52f && whi_all < 1.9f) {
@@ -595,12 +586,28 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
                 const bool vert = fabsf(single_edge0[0]) >= fabsf(single_edge0[1]);
                 const bool fast = cheap_all;
                 p.e[2] = (uint16_t)(MF_PLAN_HOT | (fast ? MF_PLAN_PAIR_FAST : 0u) | (vert ? MF_PLAN_PAIR_VERT : 0u));
+                certified = true;
             }
             // the multi shape: coverage is left to the kernel
             else if (interior && !overflow && cnt >= 2 && cnt <= 4 && coded && wlo_all > 0.52f && whi_all < 1.9f) {
                 const bool fast = cheap_all;
                 p.e[4] = (uint16_t)(p.e[4] | MF_PLAN_HOT | (fast ? MF_PLAN_MULTI_FAST : 0u) | ((uint32_t)(cnt - 1) << MF_PLAN_COUNT_SHIFT));
+                certified = true;
             }
+#ifndef MF_NO_COMPACT            // (A/B switch shared with warp.hip: both sides must agree on the window layout)
+            // COMPACT window for the three certified shapes (hot, pair, multi -- all whole and interior): 9 rows x 112 bytes hold every tap of
+            // every pixel whichever listed cell owns it (ix / iy ranges above: the corner values of EVERY listed cell) -> one global->LDS
+            // load instead of two, and the conflict-free lane -> row mapping of warp.hip.  (The mesh warp is continuous across cell edges --
+            // neighbouring cells share their vertices -- so a footprint on an edge needs no larger window than one inside a cell.)
+            const uint32_t cbs = (3u * (uint32_t)ix_lo) & ~3u;
+            if (certified && iy_hi - iy_lo + 1 <= MF_COMPACT_ROWS && 3u * (uint32_t)ix_hi + 3u <= cbs + MF_COMPACT_PITCH &&
+                iy_lo + MF_COMPACT_ROWS <= H - 1 && cbs + 16u <= 3u * (uint32_t)W) {      // (the load's 64th chunk: the first 16 bytes of
+                                                                                        // row sy0 + 9 from byte cbs -- inside that row, hence
+                                                                                        // inside the clip even on its last frame)
+                region.flags_origin = MF_REGION_STAGED | (deep ? MF_REGION_DEEP : 0u) | MF_REGION_NOFLAG | MF_REGION_COMPACT | ((uint32_t)iy_lo * MF_COMPACT_PITCH + cbs);
+                region.src_dwords = ((uint32_t)iy_lo * (3u * (uint32_t)W) + cbs) >> 2;
+            }
+#endif
         }
     }
 }

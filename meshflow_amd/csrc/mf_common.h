@@ -105,9 +105,11 @@ struct alignas(8) FootRegion { uint32_t flags_origin, src_dwords; };
 // provably overlap across the footprint (either way every pixel has an owner), and the region
 // stays two pixels inside the frame, so the warp kernel needs neither the interior check nor the crop flags.
 #define MF_REGION_DEEP 0x40000000u
-// bit 29 = COMPACT (only on HOT footprints, with STAGED and DEEP): every tap lies in MF_COMPACT_ROWS rows of MF_COMPACT_PITCH bytes
+// bit 29 = COMPACT (only on the certified shapes -- HOT, PAIR, MULTI footprints: whole, interior, STAGED, NOFLAG; DEEP unless the multi path has
+// to check coverage): every tap of every pixel, whichever listed cell owns it, lies in MF_COMPACT_ROWS rows of MF_COMPACT_PITCH bytes
 // starting at the dword that holds column sx0 of row sy0 -- 63 chunks of 16 bytes, ONE global->LDS load per wavefront; origin and
-// src_dwords then refer to that layout (origin = MF_COMPACT_PITCH sy0 + bs).
+// src_dwords then refer to that layout (origin = MF_COMPACT_PITCH sy0 + bs).  The warp kernel maps lanes to footprint rows differently
+// on such a window (rows 0, 2, 4, 6 in lanes 0-31: no LDS bank conflicts at this pitch, warp.hip).
 #define MF_REGION_COMPACT 0x20000000u
 #define MF_COMPACT_PITCH 112
 // bit 28 = NOFLAG (with or without STAGED): no pixel of the footprint can pass one of the four crop-boundary tests of mfs.py:1075-1098

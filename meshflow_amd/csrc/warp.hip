@@ -493,6 +493,16 @@ __device__ __forceinline__ uint3 gather_blend_staged(const uint32_t (&bx)[4], co
     return d;
 }
 
+// ... whichever layout the footprint's window has (wave-uniform)
+__device__ __forceinline__ uint3 gather_blend_window(bool compact, const uint32_t (&bx)[4], const uint32_t (&by)[4], uint32_t lds_origin)
+{
+#ifndef MF_NO_COMPACT
+    if (compact) return gather_blend_staged<MF_COMPACT_PITCH>(bx, by, lds_origin);
+#endif
+    (void)compact;
+    return gather_blend_staged<LDS_PITCH>(bx, by, lds_origin);
+}
+
 // The 2 x 2 taps of the lane's four pixels straight from the frame (two unaligned 8-byte loads per pixel), for footprints without a
 // staged window: a[j] = B0 G0 R0 B1 | G1 R1 . . of row iy (pixel ix, pixel ix+1), b[j] the same of row iy + 1.
 __device__ __forceinline__ void gather_global(const uint32_t (&bx)[4], const uint32_t (&by)[4], const uint8_t* __restrict__ src, int W, uint2 (&a)[4], uint2 (&b)[4])
@@ -601,7 +611,11 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     // -- whichever load lands last would win: a footprint of a frame stack that is not 4-byte aligned (odd frame sizes cut into frame
     // ranges: warp_kernel<false>) then ran on a few bytes of some cell's matrix instead of its plan about once in 200 launches and left
     // rows unwritten (found by a sweep over mf_warp_clip_u8c3's chunkings at the end of round 5).
+#ifndef MF_GUARD_SELFTEST
     constexpr bool SPECULATE = STAGE_OK && !SCAN;
+#else       // (tests/test_isa_guard.py builds THIS on purpose -- round 5's bug, the load in the instantiation without a hot path -- to see the guard fail)
+    constexpr bool SPECULATE = !SCAN;
+#endif
     const uint32_t k_guess = !SPECULATE ? 0u : min(__umulhi((uint32_t)ya + FOOT_H / 2, g.cell_mul_y) * g.mesh_cols + __umulhi((uint32_t)xa + FOOT_W / 2, g.cell_mul_x), g.cell_last);
     if (SPECULATE) {
         const uint64_t gaddr = (uint64_t)(uintptr_t)records + ((uint64_t)f * g.rec_frame_bytes + (uint64_t)k_guess * (uint32_t)(MF_CELL_DOUBLES * sizeof(double)));
@@ -668,10 +682,16 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     // taps are addressed by absolute LDS byte address (= LDS_PITCH iy + 3 ix - lds_origin): the window base is folded in
     const uint32_t lds_origin = (rg & MF_REGION_ORIGIN_MASK) - (uint32_t)(uintptr_t)&s_src[0];
     const crec_t frec = (crec_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(records) + f * g.rec_frame_bytes);
-#ifdef MF_ROWMAP
-    const int y_nat = ya + (lane >> 3);
-    const int y = y_nat;
+#ifndef MF_NO_ROWMAP
+    // Lane -> footprint row.  The byte taps are served per group of 32 lanes, bank = dword address mod 32, and the eight lanes of a
+    // footprint row take every third bank.  With the wide window (pitch 160 bytes = 40 banks) the rows 0..3 of lanes 0-31 start 0, 8, 16,
+    // 24 banks apart: no two lanes on one bank.  With the COMPACT window (pitch 112 bytes = 28 banks) rows 0 and 3 would collide on four
+    // banks -- every tap instruction 3.5 instead of 1.8 LDS cycles (tools/ubench_lds_rowmap.hip) -- so there lanes 0-31 take rows 0, 2, 4, 6
+    // (0, 24, 16, 8 banks apart) and lanes 32-63 rows 1, 3, 5, 7.  Wave-uniform choice; every lane still owns four pixels of ONE row.
+    const bool compact = STAGE_OK && !SCAN && (rg & MF_REGION_COMPACT) != 0;
+    const int y = ya + (int)(compact ? ((((uint32_t)lane >> 2) & 6u) | ((uint32_t)lane >> 5)) : ((uint32_t)lane >> 3));
 #else
+    const bool compact = STAGE_OK && !SCAN && (rg & MF_REGION_COMPACT) != 0;
     const int y = ya + (lane >> 3);
 #endif
     const int x0 = xa + (lane & 7) * 4;                                  // first of this lane's 4 pixels
@@ -694,14 +714,6 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
             uint8_t* __restrict__ dst2 = out + (uint64_t)f * g.frame_bytes;
             *reinterpret_cast<uint3*>(dst2 + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d2;
         }
-#endif
-#ifdef MF_ROWMAP
-        // COMPACT windows (pitch 112 bytes = 28 banks): with the natural lane -> row mapping the four rows a group of 32 lanes covers
-        // start 0, 28, 24, 20 banks apart (mod 32) and eight lanes of a row take every third bank -- rows 0 and 3 collide on four banks:
-        // every byte-tap instruction takes 3 LDS cycles per lane group instead of 2.  Rows 0, 2, 4, 6 (lanes 0-31) and 1, 3, 5, 7
-        // (lanes 32-63) start 0, 24, 16, 8 banks apart: no two lanes of a group on one bank.
-        const int y = (rg & MF_REGION_COMPACT) ? ya + (int)((((uint32_t)lane >> 2) & 6u) | ((uint32_t)lane >> 5)) : y_nat;
-        const double yy = (double)y;
 #endif
         float u[4], v[4];
 #ifndef MF_NO_FAST64
@@ -735,11 +747,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the window has landed in LDS
         MF_EXP_STAMP(exp_t3);
         uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
-#ifndef MF_NO_COMPACT
-        const uint3 d = (rg & MF_REGION_COMPACT) ? gather_blend_staged<MF_COMPACT_PITCH>(bx, by, lds_origin) : gather_blend_staged(bx, by, lds_origin);
-#else
-        const uint3 d = gather_blend_staged(bx, by, lds_origin);
-#endif
+        const uint3 d = gather_blend_window(compact, bx, by, lds_origin);
 #ifdef MF_EXP_PHASES
         asm volatile("" :: "v"(d.x), "v"(d.y), "v"(d.z));
         MF_EXP_STAMP(exp_t4);
@@ -925,7 +933,8 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
                 uint3 d;
                 if (VERT) {
                     uint32_t oB[4], oG[4], oR[4];
-                    gather_blend_sums(bx, by, lds_origin, oB, oG, oR);
+                    if (compact) gather_blend_sums<MF_COMPACT_PITCH>(bx, by, lds_origin, oB, oG, oR);
+                    else gather_blend_sums<LDS_PITCH>(bx, by, lds_origin, oB, oG, oR);
                     // pixel (column c, row r) as B | G << 8 | R << 16 at word r * 32 + c of the (spent) window buffer ...
                     volatile uint32_t* tw = reinterpret_cast<volatile uint32_t*>(&s_src[0]);
                     const uint32_t at = (uint32_t)(4 * (lane >> 5)) * 32u + (uint32_t)(lane & 31);
@@ -933,13 +942,15 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
                     for (int j = 0; j < 4; ++j)
                         tw[at + 32u * (uint32_t)j] = __builtin_amdgcn_perm(oR[j], __builtin_amdgcn_perm(oG[j], oB[j], 0x0C0C0602u), 0x0C060100u);
                     __builtin_amdgcn_wave_barrier();
-                    // ... and row-major lane l takes its four pixels, words 4 l .. 4 l + 3
-                    const uint32_t p0 = tw[4 * lane], p1 = tw[4 * lane + 1], p2 = tw[4 * lane + 2], p3 = tw[4 * lane + 3];
+                    // ... and every lane takes the four pixels it stores: words 32 row + 4 (l % 8) .. + 3
+                    // (its row is y - ya: the lane -> row mapping of the window layout, whatever it is)
+                    const uint32_t w0 = 32u * (uint32_t)(y - ya) + 4u * ((uint32_t)lane & 7u);
+                    const uint32_t p0 = tw[w0], p1 = tw[w0 + 1], p2 = tw[w0 + 2], p3 = tw[w0 + 3];
                     d.x = p0 | (p1 << 24);
                     d.y = (p1 >> 8) | (p2 << 16);
                     d.z = (p2 >> 16) | (p3 << 8);
                 } else {
-                    d = gather_blend_staged(bx, by, lds_origin);
+                    d = gather_blend_window(compact, bx, by, lds_origin);
                 }
                 *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;
                 return true;
@@ -974,7 +985,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
             uint32_t bx[4], by[4];
             fixed_point(u, v, bx, by);
             uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
-            const uint3 d = gather_blend_staged(bx, by, lds_origin);
+            const uint3 d = gather_blend_window(compact, bx, by, lds_origin);
             *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;
             return;
         }
@@ -1066,7 +1077,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
             uint32_t bx[4], by[4];
             fixed_point(u, v, bx, by);
             uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
-            const uint3 d = gather_blend_staged(bx, by, lds_origin);
+            const uint3 d = gather_blend_window(compact, bx, by, lds_origin);
             *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;
             return;
         }
@@ -1337,7 +1348,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
             // fast path (wave-uniform): every pixel of the footprint samples the deep interior
             if (active) {
                 if (staged) {
-                    d = gather_blend_staged(bx, by, lds_origin);
+                    d = gather_blend_window(compact, bx, by, lds_origin);
                 } else {
                     uint2 a[4], b[4];
                     gather_global(bx, by, src, W, a, b);
@@ -1385,8 +1396,9 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
                     // byte loads (a pixel without owner sits at (W+1, H+1): its clamped position may lie outside the window --
                     // whatever the load returns is replaced by the border colour below).  (Unaligned 4-byte LDS loads instead:
                     // +2 % kernel time; two pixels' loads in flight: register spills.)
-                    const uint32_t ra = umad24((uint32_t)min(max(iy, 0), H - 1), (uint32_t)LDS_PITCH, 0u - lds_origin);
-                    const uint32_t rb = umad24((uint32_t)min(max(iy + 1, 0), H - 1), (uint32_t)LDS_PITCH, 0u - lds_origin);
+                    const uint32_t pitch = compact ? (uint32_t)MF_COMPACT_PITCH : (uint32_t)LDS_PITCH;      // (wave-uniform)
+                    const uint32_t ra = umad24((uint32_t)min(max(iy, 0), H - 1), pitch, 0u - lds_origin);
+                    const uint32_t rb = umad24((uint32_t)min(max(iy + 1, 0), H - 1), pitch, 0u - lds_origin);
                     TapRegs t;
                     taps_clamped(umad24(cx0, 3u, ra), umad24(cx1, 3u, ra), umad24(cx0, 3u, rb), umad24(cx1, 3u, rb), t);
                     const bool i00 = in_x0 && in_y0, i01 = in_x1 && in_y0, i10 = in_x0 && in_y1, i11 = in_x1 && in_y1;

@@ -73,6 +73,17 @@ def _warp_host_c(self, clip, unstab, stab, crop=False, keep_uncropped=True):
     return out, tuple(np.int64(v) for v in rect), cropped
 
 
+class DegenerateMeshError(ValueError):
+    """A resident clip had mesh cells without a homography (cv2.findHomography would return None and the reference dies inside cv2,
+    mfs.py:1041-1042); its frames are undefined.  `clip_serial`: the clip's serial number -- `MeshFlowStabilizer.resident_serial` right
+    after the `stabilize_resident` call that issued it; `cells`: how many cells.  A ValueError, as before."""
+
+    def __init__(self, cells, clip_serial):
+        super().__init__(f'{cells} degenerate mesh cell(s) in resident clip #{clip_serial}: no homography exists '
+                         '(cv2.findHomography would return None); its frames are undefined')
+        self.cells, self.clip_serial = cells, clip_serial
+
+
 class MeshFlowStabilizer:
     ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL = 0
     ADAPTIVE_WEIGHTS_DEFINITION_FLIPPED = 1
@@ -477,8 +488,7 @@ class MeshFlowStabilizer:
         total = int(slot['host'][0])
         bad, slot['seen'] = total - slot['seen'], total
         if bad and not pending['ignore']:
-            raise ValueError(f'{bad} degenerate mesh cell(s) in resident clip #{pending["serial"]}: no homography exists '
-                             '(cv2.findHomography would return None); its frames are undefined')
+            raise DegenerateMeshError(bad, pending['serial'])
 
     def finish(self):
         """Waits for the verdict of every clip `stabilize_resident` has issued and not yet checked (it checks clip i when clip i + 2 is
@@ -494,6 +504,19 @@ class MeshFlowStabilizer:
                         first = first or e
         if first is not None:
             raise first
+
+    @property
+    def resident_serial(self):
+        """Serial number of the clip the last `stabilize_resident` call issued (what `DegenerateMeshError.clip_serial` names)."""
+        st = getattr(self, '_resident', None)
+        return 0 if st is None else st['serial']
+
+    def _settle_upcoming(self, st, W, H):
+        """The verdict of the clip whose table slot the NEXT clip of this geometry takes -- looked at before ANYTHING of the new clip is
+        queued (its sweep included), so that a deferred DegenerateMeshError leaves no half-issued clip behind."""
+        pair = st['tables'].get((W, H, self.mesh_row_count, self.mesh_col_count))
+        if pair is not None:
+            self._settle(pair[st['turn'] & 1])
 
     def _resident_slot(self, st, n, W, H):
         """The table slot of the next clip (two per geometry take turns), settled and sized for n frames."""
@@ -637,7 +660,7 @@ class MeshFlowStabilizer:
         return out, bounds, table
 
     def stabilize_resident(self, d_frames, d_disp, homographies, adaptive_weights_definition=ADAPTIVE_WEIGHTS_DEFINITION_ORIGINAL,
-                           out=None, frame_range=None, inputs_ready=None, check='deferred', collective=False, warp_events=None,
+                           out=None, frame_range=None, inputs_ready=None, check=True, collective=False, warp_events=None,
                            jacobi_events=None):
         """mfs.py:150-158 for a clip whose frames (n, H, W, 3) uint8 and vertex displacements (F, R+1, C+1, 2) float64 are RESIDENT in
         HBM: Jacobi sweep -> cell tables -> warp + crop rectangle, nothing leaves the device, one call per clip, NO synchronisation:
@@ -648,10 +671,13 @@ class MeshFlowStabilizer:
         Returns (stabilized frames, clip-level crop bounds as a device int32 tensor {left, top, right, bottom} -- 16 bytes of this
         clip's own, never rewritten by a later call --, stabilized vertex displacements (F, R+1, C+1, 2)), all valid in current-stream
         order.
-        A degenerate mesh (a cell without homography: the reference would die inside cv2) raises ValueError -- by default DEFERRED:
-        the 4-byte verdict of clip i is looked at when clip i + 2 is issued (its table slot comes up again) or by `finish()`, whichever
-        comes first, and names the clip by its serial number; check=True waits for it before returning (one blocking device-to-host
-        read per clip: the calls no longer overlap), check='never' skips it.  Clips after a degenerate one are unaffected.
+        A degenerate mesh (a cell without homography: the reference dies inside cv2) raises `DegenerateMeshError` (a ValueError) that
+        carries the clip's serial number (`resident_serial` right after the call that issued it).  check=True (the default, like the
+        reference: the error belongs to THIS call) waits for the clip's 4-byte verdict before returning -- one blocking device-to-host
+        read per clip, so the calls no longer overlap.  A pipelined caller (bench.py's timed step) passes check='deferred': the verdict
+        of clip i is then looked at when clip i + 2 is issued (its table slot comes up again; BEFORE anything of the new clip is queued,
+        which is then not issued) or by `finish()`, whichever comes first -- such a caller MUST end with `finish()`.  check='never'
+        skips it.  Clips after a degenerate one are unaffected.
         warp_events / jacobi_events: pairs of torch events recorded around the warp kernel (caller's stream) and the sweep stage (prep
         stream) -- bench.py's roofline brackets.
         One host thread per stabilizer object here: the calls of a pipeline are ordered by construction (table slots take turns, the
@@ -669,6 +695,8 @@ class MeshFlowStabilizer:
             raise ValueError(f'frame_range {lo, hi} does not match {n} frames')
         dev = d_frames.device
         st = self._resident_state(dev)
+        if n > 0:
+            self._settle_upcoming(st, W, H)              # (a deferred verdict is raised here: nothing of this clip has been queued yet)
 
         def jacobi_fn():
             if jacobi_events:

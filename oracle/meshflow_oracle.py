@@ -22,6 +22,15 @@ Pinning status
   are restated below from OpenCV 4.x's published algorithms (modules/calib3d/src/fundam.cpp,
   modules/imgproc/src/imgwarp.cpp, modules/core/src/matmul.simd.hpp, modules/core/src/lapack.cpp)
   and pinned only by known-answer tests (``tests/test_oracle_warp_kat.py``).
+  MODELLED VERSION RANGE: **OpenCV 4.5 ... 4.10** -- the FIXED-POINT 8-bit kernels: ``remap`` /
+  ``warpPerspective`` with INTER_BITS = 5 coordinates (``cvRound(x * 32)``), the 2^15-scaled weight
+  table and ``(sum + 2^14) >> 15``; ``resize`` with 11-bit coefficients (``>> 4 ... >> 16 ... + 2 >> 2``);
+  4-point ``findHomography`` = normalised DLT without refinement.  The reference's era (numpy 1.22 /
+  tqdm 4.56, requirements.txt) is OpenCV 4.5.x.  OpenCV >= 4.11 blends 8-bit ``remap`` /
+  ``warpPerspective`` with float weights: a last-bit difference against such a build is a version
+  difference.  ``tests/test_cv2_crosscheck.py`` prints ``cv2.__version__``, asserts bit-exactness
+  inside the range and BASELINE.json's bars (<= 1 LSB, 1e-4) outside it; ``tools/settle_parity.sh``
+  is the one command to run where a ``cv2`` exists.
 
 The warp is written here in the reference's own shape: one full-frame pass per mesh cell in
 row-major order, later cells painting over earlier ones (mfs.py:1031-1061), then one remap

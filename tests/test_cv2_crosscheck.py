@@ -1,10 +1,23 @@
-"""Optional cross-check of the oracle's OpenCV restatements against a real OpenCV.
+"""Optional cross-check of the oracle's OpenCV restatements against a real OpenCV -- the ONE run that settles "parity unpinned".
 
 OpenCV is not installed in the build image nor on the GPU box, so these tests normally SKIP; wherever `cv2`
 is importable they pin the restated calls of the warp path, cv2.resize and the two calls of the vertex-motion row
-(perspectiveTransform on float64 points, medianBlur) against the real thing.
-Ties (a coordinate within ~1e-9 of a 1/32-pixel rounding boundary) may differ, hence the small allowances."""
+(perspectiveTransform on float64 points, medianBlur) against the real thing.  `tools/settle_parity.sh` is the one command to run on
+such a box; it prints (and writes, $MESHFLOW_PARITY_REPORT) a JSON verdict.
+
+WHICH OpenCV is modelled.  The oracle restates the FIXED-POINT 8-bit kernels: `remap` / `warpPerspective` with INTER_BITS = 5
+coordinates and the 2^15-weight table (imgwarp.cpp), `resize` with 11-bit coefficients (resize.cpp), the 4-point `findHomography` through
+the normalised DLT (fundam.cpp).  Those are OpenCV 4.5 ... 4.10 (the reference's era -- numpy 1.22 / tqdm 4.56 in its requirements --
+is 4.5.x; 3.4 / 4.0-4.4 share the kernels but were never the target).  OpenCV >= 4.11 replaced the linear `remap` / `warpAffine` /
+`warpPerspective` kernels for 8-bit images by ones that blend with float weights: against such a build the pixel results may differ in
+the last bit, which is a VERSION difference, not a parity failure.  Therefore:
+  * inside the modelled range every comparison is BIT-EXACT (up to the stated rounding ties of the two homography solvers);
+  * outside it the assertions are BASELINE.json's bars -- <= 1 LSB on uint8 pixels, 1e-4 on coordinates -- and the number of
+    values that are not bit-equal is reported as information (`mismatching` in the report), never asserted."""
+import atexit
+import json
 import os
+import re
 import sys
 
 import numpy as np
@@ -15,6 +28,62 @@ cv2 = pytest.importorskip('cv2')
 from meshflow_amd import synthetic                      # noqa: E402
 from oracle import meshflow_oracle as mo                # noqa: E402
 
+MODELLED_RANGE = ((4, 5, 0), (4, 11, 0))                # [first modelled release, first release with the float-weight kernels)
+
+
+def _cv2_version():
+    v = getattr(cv2, '__version__', None)
+    if v is None:                                       # the stand-in of tests/test_cv2_crosscheck_bitrot.py: the oracle itself
+        return None
+    m = re.match(r'(\d+)\.(\d+)(?:\.(\d+))?', v)
+    return (int(m.group(1)), int(m.group(2)), int(m.group(3) or 0)) if m else (0, 0, 0)
+
+
+CV2_VERSION = _cv2_version()
+BIT_EXACT = CV2_VERSION is None or MODELLED_RANGE[0] <= CV2_VERSION < MODELLED_RANGE[1]
+_REPORT = {'cv2_version': getattr(cv2, '__version__', 'stand-in (the oracle itself: proves nothing about OpenCV)'),
+           'modelled_range': 'OpenCV %d.%d.%d <= version < %d.%d.%d (fixed-point remap / warpPerspective / resize)' % (MODELLED_RANGE[0] + MODELLED_RANGE[1]),
+           'assertion_mode': 'bit-exact' if BIT_EXACT else 'BASELINE.json bars (<= 1 LSB pixels, 1e-4 coordinates); mismatch counts are information',
+           'checks': []}
+print(f'[cv2 cross-check] cv2 {_REPORT["cv2_version"]}; modelled: {_REPORT["modelled_range"]}; asserting {_REPORT["assertion_mode"]}', file=sys.stderr)
+
+
+def _write_report():
+    path = os.environ.get('MESHFLOW_PARITY_REPORT')
+    if path and CV2_VERSION is not None:
+        with open(path, 'w') as fh:
+            json.dump(_REPORT, fh, indent=1)
+
+
+atexit.register(_write_report)
+
+
+def check_pixels(got, ref, what, ties=0):
+    """uint8 (or boolean mask) results: bit-exact up to `ties` values inside the modelled range, <= 1 LSB outside it."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, what
+    diff = np.abs(got.astype(np.int64) - ref.astype(np.int64))
+    mism = int((diff != 0).sum())
+    _REPORT['checks'].append({'check': what, 'kind': 'pixels', 'values': int(got.size), 'mismatching': mism, 'max_abs': int(diff.max()) if diff.size else 0})
+    if BIT_EXACT:
+        assert mism <= ties, f'{what}: {mism} of {got.size} values differ (cv2 {_REPORT["cv2_version"]} is inside the modelled range)'
+    else:
+        assert diff.max() <= 1, f'{what}: max |difference| {int(diff.max())} LSB (bar: 1)'
+
+
+def check_coords(got, ref, what, exact=True, rtol=0.0, atol=0.0):
+    """floating-point results: bit-exact (or within the stated solver tolerance) inside the modelled range, 1e-4 outside it."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    err = np.abs(got - ref)
+    mism = int((err != 0).sum())
+    _REPORT['checks'].append({'check': what, 'kind': 'coordinates', 'values': int(got.size), 'mismatching': mism, 'max_abs': float(err.max()) if err.size else 0.0})
+    if BIT_EXACT and exact:
+        assert mism == 0, f'{what}: {mism} of {got.size} values differ'
+    elif BIT_EXACT:
+        np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol, err_msg=what)
+    else:
+        assert err.max() <= 1e-4 * max(1.0, float(np.abs(ref).max())), f'{what}: max |difference| {err.max()}'
+
 
 def test_find_homography_4pt():
     g = np.random.default_rng(0)
@@ -23,7 +92,7 @@ def test_find_homography_4pt():
         dst = src.astype(np.float64) + g.normal(0, 3, (4, 2))
         ref, _ = cv2.findHomography(src, dst)
         got = mo.find_homography_4pt(src, dst)
-        np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-9)
+        check_coords(got, ref, 'findHomography 4 points (mfs.py:1041-1042)', exact=False, rtol=1e-8, atol=1e-9)
 
 
 def test_perspective_transform():
@@ -31,7 +100,7 @@ def test_perspective_transform():
     H = np.eye(3) + 0.01 * g.normal(size=(3, 3)); H[2, :2] *= 1e-3
     xy = np.swapaxes(np.indices((64, 48), dtype=np.float32), 0, 2).reshape(-1, 1, 2)
     ref = cv2.perspectiveTransform(xy, H)
-    np.testing.assert_array_equal(mo.perspective_transform_f32(xy, H), ref)
+    check_coords(mo.perspective_transform_f32(xy, H), ref, 'perspectiveTransform float32 points (mfs.py:1054)')
 
 
 def test_warp_perspective_mask_pattern():
@@ -43,7 +112,7 @@ def test_warp_perspective_mask_pattern():
         mask = np.zeros((32, 48)); mask[T:B + 1, L:Rt + 1] = 255
         ref = cv2.warpPerspective(mask, Hf, (48, 32)) != 0
         got = mo.warp_perspective_rect_mask((L, T, Rt, B), Hf, 48, 32)
-        assert (ref != got).sum() <= 1          # at most a rounding tie
+        check_pixels(got, ref, 'warpPerspective mask pattern (mfs.py:1052)', ties=1)          # at most a rounding tie
 
 
 def test_remap_bilinear_constant_border():
@@ -52,13 +121,13 @@ def test_remap_bilinear_constant_border():
     mx = (np.arange(60, dtype=np.float32)[None, :] + g.normal(0, 3, (40, 60))).astype(np.float32)
     my = (np.arange(40, dtype=np.float32)[:, None] + g.normal(0, 3, (40, 60))).astype(np.float32)
     ref = cv2.remap(src, mx.reshape(40, 60, 1), my.reshape(40, 60, 1), cv2.INTER_LINEAR, borderValue=(0, 0, 255))
-    np.testing.assert_array_equal(mo.remap_bilinear_u8c3(src, mx, my, (0, 0, 255)), ref)
+    check_pixels(mo.remap_bilinear_u8c3(src, mx, my, (0, 0, 255)), ref, 'remap bilinear constant border (mfs.py:1063-1069)')
 
 
 def test_resize_linear():
     src = synthetic.frames_numpy(1, 37, 53, seed=4, kind='noise')[0]
     for (w, h) in ((60, 40), (53, 37), (106, 74), (55, 38)):
-        np.testing.assert_array_equal(mo.resize_linear_u8(src, w, h), cv2.resize(src, (w, h)))
+        check_pixels(mo.resize_linear_u8(src, w, h), cv2.resize(src, (w, h)), f'resize to {w}x{h} (mfs.py:1150)')
 
 
 def test_whole_warp_against_reference_loop():
@@ -83,8 +152,7 @@ def test_whole_warp_against_reference_loop():
             map_x = np.where(m, pts[..., 0], map_x); map_y = np.where(m, pts[..., 1], map_y)
     ref = cv2.remap(frames[1], map_x.reshape(H, W, 1).astype(np.float32), map_y.reshape(H, W, 1).astype(np.float32),
                     cv2.INTER_LINEAR, borderValue=(0, 0, 255))
-    diff = np.abs(got.astype(int) - ref.astype(int))
-    assert (diff > 0).mean() < 1e-3           # only rounding ties of the two homography solvers may differ
+    check_pixels(got, ref, 'whole warp of one frame against the reference loop (mfs.py:1031-1069)', ties=int(1e-3 * got.size))   # only rounding ties of the two homography solvers may differ
 
 
 def test_perspective_transform_float64_points():
@@ -95,7 +163,7 @@ def test_perspective_transform_float64_points():
     H = np.identity(3) + rng.normal(0, 0.01, (3, 3))
     H[2, :2] = rng.normal(0, 1e-6, 2)
     H[2, 2] = 1.0
-    assert np.array_equal(cv2.perspectiveTransform(pts, H), mt.perspective_transform_f64(pts, H))
+    check_coords(mt.perspective_transform_f64(pts, H), cv2.perspectiveTransform(pts, H), 'perspectiveTransform float64 points (mfs.py:420)')
 
 
 def test_median_blur_3x3_float32():
@@ -104,7 +172,7 @@ def test_median_blur_3x3_float32():
     rng = np.random.default_rng(6)
     for shape in ((17, 17), (33, 33), (4, 6), (2, 2)):
         img = rng.normal(0, 3, shape).astype(np.float32)
-        assert np.array_equal(cv2.medianBlur(img, 3), mt.median_blur3_f32(img))
+        check_coords(mt.median_blur3_f32(img), cv2.medianBlur(img, 3), f'medianBlur 3x3 float32 {shape} (mfs.py:359-360)')
 
 
 def test_vertex_velocities_against_reference_code_with_real_cv2():
@@ -124,7 +192,7 @@ def test_vertex_velocities_against_reference_code_with_real_cv2():
     for t in range(3):
         want = s._get_unstabilized_vertex_velocities(frames[t], frames[t + 1])[0]
         got = mt.unstabilized_vertex_velocities(W, H, R, C, er, ec, feats[t][0], feats[t][1], hom[t])
-        assert np.array_equal(want, got)
+        check_coords(got, want, 'vertex velocities against the reference code (mfs.py:287-452)')
 
 
 # ---- config-2 geometry (1920x1080, 16x16 mesh) and the committed goldens: one run anywhere `cv2` exists settles rows a-7 / a-8 / a-9 /
@@ -153,7 +221,7 @@ def test_cfg2_find_homography_both_directions():
     for ub, sb, _ in cells:
         for src, dst in ((ub, sb), (sb, ub)):
             ref, _ = cv2.findHomography(src, dst)
-            np.testing.assert_allclose(mo.find_homography_4pt(src, dst), ref, rtol=1e-8, atol=1e-8)
+            check_coords(mo.find_homography_4pt(src, dst), ref, 'findHomography on config-2 cells (mfs.py:1041-1042)', exact=False, rtol=1e-8, atol=1e-8)
 
 
 def test_cfg2_warp_perspective_mask_and_perspective_transform():
@@ -166,8 +234,8 @@ def test_cfg2_warp_perspective_mask_and_perspective_transform():
         mask = np.zeros((H, W)); mask[T:B + 1, L:Rt + 1] = 255
         ref = cv2.warpPerspective(mask, Hf, (W, H)) != 0
         got = mo.warp_perspective_rect_mask((L, T, Rt, B), Hf, W, H)
-        assert (ref != got).sum() <= 2                                  # at most a rounding tie or two along 400 px of edge
-        np.testing.assert_array_equal(mo.perspective_transform_f32(xy, Hi), cv2.perspectiveTransform(xy, Hi))
+        check_pixels(got, ref, 'warpPerspective mask pattern at 1920x1080 (mfs.py:1052)', ties=2)      # at most a rounding tie or two along 400 px of edge
+        check_coords(mo.perspective_transform_f32(xy, Hi), cv2.perspectiveTransform(xy, Hi), 'perspectiveTransform of every 1080p pixel (mfs.py:1054)')
 
 
 def test_cfg2_remap_full_frame():
@@ -178,7 +246,7 @@ def test_cfg2_remap_full_frame():
     mx = (xx + 9.0 * np.sin(yy / 97.0) - 3.3).astype(np.float32)
     my = (yy + 7.0 * np.cos(xx / 131.0) + 2.7).astype(np.float32)
     ref = cv2.remap(src, mx.reshape(H, W, 1), my.reshape(H, W, 1), cv2.INTER_LINEAR, borderValue=(0, 0, 255))
-    np.testing.assert_array_equal(mo.remap_bilinear_u8c3(src, mx, my, (0, 0, 255)), ref)
+    check_pixels(mo.remap_bilinear_u8c3(src, mx, my, (0, 0, 255)), ref, 'remap of a 1920x1080 frame (mfs.py:1063-1069)')
 
 
 def test_cfg2_resize_of_the_real_crop_rectangle():
@@ -187,8 +255,8 @@ def test_cfg2_resize_of_the_real_crop_rectangle():
     frame = synthetic.frames_numpy(1, H, W, seed=0, kind='noise')[0]
     for (l, t, r, b) in ((13, 11, 1909, 1068), (0, 0, W - 1, H - 1), (100, 37, 1500, 1000)):
         crop = frame[t:b + 1, l:r + 1]
-        np.testing.assert_array_equal(mo.resize_linear_u8(crop, W, H), cv2.resize(crop, (W, H)))
-        np.testing.assert_array_equal(mo.crop_frames([frame], (l, t, r, b))[0], cv2.resize(crop, (W, H)))
+        check_pixels(mo.resize_linear_u8(crop, W, H), cv2.resize(crop, (W, H)), f'resize of crop rectangle {(l, t, r, b)} to 1920x1080 (mfs.py:1150)')
+        check_pixels(mo.crop_frames([frame], (l, t, r, b))[0], cv2.resize(crop, (W, H)), f'_crop_frames {(l, t, r, b)} (mfs.py:1111-1157)')
 
 
 @pytest.mark.parametrize('name', ['warp_small', 'warp_ragged', 'warp_jitter', 'warp_shift', 'warp_mesh16'])
@@ -205,6 +273,8 @@ def test_reference_with_real_cv2_reproduces_the_committed_goldens(name):
     s = mfs.MeshFlowStabilizer(mesh_row_count=int(g['R']), mesh_col_count=int(g['C']),
                                color_outside_image_area_bgr=tuple(int(v) for v in g['border']))
     out, bounds = s._get_stabilized_frames_and_crop_boundaries(int(g['F']), list(g['frames']), g['unstab'], g['stab'])
-    assert tuple(int(b) for b in bounds) == tuple(int(b) for b in g['bounds'])
-    diff = np.stack(out) != g['out']
-    assert diff.mean() < 1e-4, f'{int(diff.sum())} bytes differ'
+    if BIT_EXACT:
+        assert tuple(int(b) for b in bounds) == tuple(int(b) for b in g['bounds'])
+    else:                                                    # (a last-bit coordinate can move a crop edge by a pixel)
+        assert max(abs(int(a) - int(b)) for a, b in zip(bounds, g['bounds'])) <= 1
+    check_pixels(np.stack(out), g['out'], f'reference warp with the real cv2 against golden {name} (mfs.py:909-1108)', ties=int(1e-4 * g['out'].size))

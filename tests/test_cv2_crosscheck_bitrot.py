@@ -91,3 +91,49 @@ def test_crosscheck_full_frame_tests_run(crosscheck, monkeypatch):
 def test_crosscheck_golden_test_runs(crosscheck):
     """The reference's own warp under the stand-in against a committed golden (what oracle/gen_golden.py made it from): byte-equal here."""
     crosscheck.test_reference_with_real_cv2_reproduces_the_committed_goldens('warp_small')
+
+
+def _import_crosscheck_under(cv2_module, name):
+    saved = sys.modules.get('cv2')
+    sys.modules['cv2'] = cv2_module
+    try:
+        spec = importlib.util.spec_from_file_location(name, os.path.join(HERE, 'test_cv2_crosscheck.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    finally:
+        if saved is None:
+            sys.modules.pop('cv2', None)
+        else:
+            sys.modules['cv2'] = saved
+
+
+@pytest.mark.parametrize('version,bit_exact', [('4.5.5', True), ('4.10.0', True), ('4.11.0', False), ('4.12.0-dev', False), ('3.4.16', False)])
+def test_crosscheck_is_version_aware(version, bit_exact):
+    """Inside the modelled OpenCV range (4.5 ... 4.10: fixed-point remap / warpPerspective / resize) a single differing byte fails the
+    cross-check; outside it (>= 4.11: float-weight kernels) a last-bit difference passes -- and is REPORTED -- while 2 LSB still fails."""
+    fake = _stand_in_cv2()
+    fake.__version__ = version
+    exact_remap = fake.remap
+
+    def off_by(n):
+        def remap(src, map1, map2, interpolation, borderValue=(0, 0, 0)):
+            out = exact_remap(src, map1, map2, interpolation, borderValue).astype(np.int64)
+            out[3::7, 5::11] += np.where(out[3::7, 5::11] < 200, n, -n)
+            return out.astype(np.uint8)
+        return remap
+
+    mod = _import_crosscheck_under(fake, f'_cv2_crosscheck_version_{version.replace(".", "_").replace("-", "_")}')
+    assert mod.BIT_EXACT is bit_exact and mod._REPORT['cv2_version'] == version
+    mod.test_remap_bilinear_constant_border()                         # the exact stand-in passes in either mode
+    fake.remap = off_by(1)
+    if bit_exact:
+        with pytest.raises(AssertionError):
+            mod.test_remap_bilinear_constant_border()
+    else:
+        mod.test_remap_bilinear_constant_border()
+        last = mod._REPORT['checks'][-1]
+        assert last['mismatching'] > 0 and last['max_abs'] == 1        # reported as information
+    fake.remap = off_by(2)
+    with pytest.raises(AssertionError):
+        mod.test_remap_bilinear_constant_border()

@@ -403,7 +403,7 @@ def test_host_pipeline_leaves_the_current_device_alone(dev):
         out, bounds, stab, score, cropped = s.stabilize_clip(list(frames), disp, hom, crop=True)
         assert torch.cuda.current_device() == before
         assert s._torch_device().index == (before if name == 'cuda' else last)
-        assert len(out) == F and len(cropped) == F
+        assert out is None and len(cropped) == F
 
 
 # ---- the ring of chunk buffers: device memory O(chunk), clips of any length ----
@@ -480,8 +480,8 @@ def test_2000_frame_1080p_clip_in_two_gigabytes_of_device_memory(dev):
     from meshflow_amd.stabilizer import MeshFlowStabilizer
     import psutil
     F, H, W, R, C = 2000, 1080, 1920, 16, 16
-    if psutil.virtual_memory().available < 40 * 2**30:
-        pytest.skip('needs ~26 GB of host memory for the two 2,000-frame output stacks')
+    if psutil.virtual_memory().available < 18 * 2**30:
+        pytest.skip('needs ~13 GB of host memory for the 2,000 cropped output frames')
     base = synthetic.frames_torch(40, H, W, dev, seed=2, kind='pattern').cpu().numpy()
     frames = [base[i % 40] for i in range(F)]                     # 40 distinct frames, cycled (input frames may repeat; outputs may not)
     disp, hom = synthetic.motion(F, R, C, seed=2)
@@ -502,7 +502,8 @@ def test_2000_frame_1080p_clip_in_two_gigabytes_of_device_memory(dev):
     th = threading.Thread(target=watch)
     th.start()
     try:
-        out, bounds, stab, score, cropped = s.stabilize_clip(frames, disp, hom, crop=True, keep_uncropped=True)
+        # (keep_uncropped=False: ONE 12.4 GB output list -- the cropped frames -- instead of two, so that the test fits any box)
+        out, bounds, stab, score, cropped = s.stabilize_clip(frames, disp, hom, crop=True, keep_uncropped=False)
     finally:
         stop[0] = True
         th.join()
@@ -515,7 +516,6 @@ def test_2000_frame_1080p_clip_in_two_gigabytes_of_device_memory(dev):
     for i0 in (0, 16 * 61 + 3, F - 16):
         d_in = torch.from_numpy(np.stack(frames[i0:i0 + 16])).to(dev)
         d_out, crop_rows, _, d_cropped = _device_warp_crop(d_in, disp[i0:i0 + 16], stab[i0:i0 + 16], R, C, rect)
-        assert np.array_equal(np.stack(out[i0:i0 + 16]), d_out.cpu().numpy())
         assert np.array_equal(np.stack(cropped[i0:i0 + 16]), d_cropped.cpu().numpy())
     # the rectangle: every frame's rows through the crop scan of the whole clip's table, in pieces
     from meshflow_amd import ops
@@ -526,55 +526,75 @@ def test_2000_frame_1080p_clip_in_two_gigabytes_of_device_memory(dev):
         rows = ops.crop_scan(table).cpu().numpy()
         lo = [max(lo[0], rows[:, 0].max()), max(lo[1], rows[:, 1].max()), min(lo[2], rows[:, 2].min()), min(lo[3], rows[:, 3].min())]
     assert rect == tuple(int(v) for v in lo)
-    del out, cropped
+    del cropped
 
 
 def test_full_config4_clip_through_one_gpu(dev):
     """BASELINE config 4 WHOLE -- 1,200 frames of 3840 x 2160 (29.9 GB each way) -- host to host through ONE GPU's ring (4-frame chunks,
-    1.6 GB of device memory).  Motion = an integer global shift per frame, so every frame has the analytic answer: interior pixels
-    moved by exactly that shift, the uncovered band in the border colour, crop rows (dx, 0, W-1, H-1+dy)-like values; sampled frames
-    are also held against the device operators."""
+    1.6 GB of device memory), as the EIGHT frame-range shards of 150 frames the eight ranks of the real run take (host.shard_range), one
+    after the other into ONE reused 3.7 GB output stack: 4.4 GB of host memory instead of 60, so the test runs on any box.  Motion =
+    an integer global shift per frame, so every frame has the analytic answer: interior pixels moved by exactly that shift, the
+    uncovered band in the border colour; every frame of every shard is checked against it, sampled frames also against the device
+    operators, and the clip-level rectangle folded over the shards (what the 16-byte all-reduce does, mfs.py:1103-1106) against the
+    crop scan of the whole clip's table."""
     import time
     import psutil
     import torch
-    from meshflow_amd import _lib, synthetic
-    F, H, W, R, C = 1200, 2160, 3840, 16, 16
-    if psutil.virtual_memory().available < 80 * 2**30:
-        pytest.skip('needs ~65 GB of host memory for the 1,200 output frames and the input')
+    from meshflow_amd import _lib, host, ops, synthetic
+    F, H, W, R, C, G = 1200, 2160, 3840, 16, 16, 8
+    if psutil.virtual_memory().available < 8 * 2**30:
+        pytest.skip('needs ~4.4 GB of host memory: one 150-frame output stack and 24 input frames')
     base = synthetic.frames_torch(24, H, W, dev, seed=7, kind='pattern').cpu().numpy()          # 24 distinct input frames, cycled
-    frames = [base[i % 24] for i in range(F)]
     disp, hom = synthetic.motion(F, R, C, seed=4)
     unstab = np.ascontiguousarray(disp)
     shift = np.zeros((F, 2))
     shift[:, 0] = (np.arange(F) % 7) - 3                                        # dx in -3..3
     shift[:, 1] = (np.arange(F) % 5) - 2                                        # dy in -2..2
     stab = np.ascontiguousarray(unstab + shift[:, None, None, :])               # content moves by (dx, dy)
-    out = np.empty((F, H, W, 3), np.uint8)
+    per = -(-F // G)
+    out = np.empty((per, H, W, 3), np.uint8)
     fb = H * W * 3
-    pin = (ctypes.c_void_p * F)(*[f.ctypes.data for f in frames])
-    pout = (ctypes.c_void_p * F)(*[out.ctypes.data + i * fb for i in range(F)])
     crop = np.zeros((F, 4), np.int32)
     border = (ctypes.c_uint8 * 3)(0, 0, 255)
+    red = np.array([0, 0, 255], np.uint8)
     _lib.lib.mf_host_cache_release()
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     before = _hbm_used()
-    t0 = time.perf_counter()
-    _lib.check(_lib.lib.mf_warp_u8c3_host_frames(pin, pout, _p(unstab), _p(stab), F, W, H, R, C, border, _p(crop), None))
-    dt = time.perf_counter() - t0
-    grown = _hbm_used() - before
+    grown, dt, checked = 0, 0.0, 0
+    for g in range(G):
+        lo, hi = host.shard_range(F, G, g)
+        n = hi - lo
+        pin = (ctypes.c_void_p * n)(*[base[i % 24].ctypes.data for i in range(lo, hi)])
+        pout = (ctypes.c_void_p * n)(*[out.ctypes.data + i * fb for i in range(n)])
+        out[:n, ::64, ::64] = 7                                                  # (stale bytes of the previous shard must not pass for results)
+        t0 = time.perf_counter()
+        _lib.check(_lib.lib.mf_warp_u8c3_host_frames(pin, pout, _p(unstab[lo:hi]), _p(stab[lo:hi]), n, W, H, R, C, border, _p(crop[lo:hi]), None))
+        dt += time.perf_counter() - t0
+        grown = max(grown, _hbm_used() - before)
+        for f in range(lo, hi):                                                  # EVERY frame against the analytic answer
+            dx, dy = int(shift[f, 0]), int(shift[f, 1])
+            src, got = base[f % 24], out[f - lo]
+            ys, xs = slice(max(dy, 0) + 2, H + min(dy, 0) - 2), slice(max(dx, 0) + 2, W + min(dx, 0) - 2)
+            # (row and column samples of the interior on every frame, the whole interior on every 29th: 1,200 full 4K compares are a minute of host time)
+            if f % 29 == 0:
+                assert np.array_equal(got[ys, xs], src[ys.start - dy:ys.stop - dy, xs.start - dx:xs.stop - dx]), f
+            else:
+                assert np.array_equal(got[ys, xs][::16, ::8], src[ys.start - dy:ys.stop - dy, xs.start - dx:xs.stop - dx][::16, ::8]), f
+            if dx > 1:
+                assert (got[:, :dx - 1] == red).all(), f                         # the uncovered band, in the border colour
+            checked += 1
+        for f in (lo, lo + 77):                                                  # and byte for byte against the device operators
+            if f % 3 == 0 or f == lo:
+                d_out, crop_rows, _, _ = _device_warp_crop(torch.from_numpy(base[f % 24][None]).to(dev), unstab[f:f + 1], stab[f:f + 1], R, C, (0, 0, W - 1, H - 1))
+                assert np.array_equal(out[f - lo], d_out[0].cpu().numpy())
+                assert np.array_equal(crop[f], crop_rows[0])
+    assert checked == F
     print(f'full config 4 through one GPU: {dt:.2f} s = {F / dt:.0f} frames/s, {2 * F * fb / dt / 1e9:.1f} GB/s both ways, ring {grown / 2**30:.2f} GiB')
     assert grown <= 2 * 2**30
-    for f in list(range(0, F, 97)) + [F - 1]:
-        dx, dy = int(shift[f, 0]), int(shift[f, 1])
-        src = frames[f]
-        got = out[f]
-        ys, xs = slice(max(dy, 0) + 2, H + min(dy, 0) - 2), slice(max(dx, 0) + 2, W + min(dx, 0) - 2)
-        assert np.array_equal(got[ys, xs], src[ys.start - dy:ys.stop - dy, xs.start - dx:xs.stop - dx]), f
-        if dx > 1:
-            assert (got[:, :dx - 1] == np.array([0, 0, 255], np.uint8)).all(), f                 # the uncovered band, in the border colour
-    for f in (0, 601, F - 1):                                                   # and byte for byte against the device operators
-        d_out, crop_rows, _, _ = _device_warp_crop(torch.from_numpy(frames[f][None]).to(dev), unstab[f:f + 1], stab[f:f + 1], R, C, (0, 0, W - 1, H - 1))
-        assert np.array_equal(out[f], d_out[0].cpu().numpy())
-        assert np.array_equal(crop[f], crop_rows[0])
+    # the clip-level rectangle: the shards' rows folded together = the crop scan of the whole clip's table
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rows = ops.crop_scan(ops.cell_table(t(unstab), t(stab), W, H, R, C)).cpu().numpy()
+    assert np.array_equal(rows, crop)
+    assert (crop[:, 0].max(), crop[:, 1].max(), crop[:, 2].min(), crop[:, 3].min()) == (rows[:, 0].max(), rows[:, 1].max(), rows[:, 2].min(), rows[:, 3].min())
     del out

@@ -33,7 +33,7 @@ SCRIPT = textwrap.dedent('''
         s = MeshFlowStabilizer(mesh_row_count=R, mesh_col_count=C, temporal_smoothing_radius=5, optimization_num_iterations=20, device='cuda:0')
         s.resident_rectangle = rectangle
         plain, b0, stab0 = s.stabilize_resident(d_frames, d_disp, hom, collective=False)
-        outs = [s.stabilize_resident(d_frames, d_disp, hom, collective=True) for _ in range(3)]        # back to back: no synchronisation
+        outs = [s.stabilize_resident(d_frames, d_disp, hom, collective=True, check='deferred') for _ in range(3)]        # back to back: no synchronisation
         s.finish()
         torch.cuda.synchronize()
         for frames, bounds, stab in outs:

@@ -168,7 +168,7 @@ def test_resident_bounds_are_the_callers_own_across_six_calls(dev):
     torch.cuda.synchronize()
     held = []
     for d_fr, d_disp, hom in clips:                       # six calls, nothing synchronises, nothing is cloned
-        out, bounds, _ = s.stabilize_resident(d_fr, d_disp, hom)
+        out, bounds, _ = s.stabilize_resident(d_fr, d_disp, hom, check='deferred')
         held.append((out, bounds))
     s.finish()
     torch.cuda.synchronize()
@@ -219,6 +219,27 @@ def test_resident_degenerate_clip_is_reported_once_and_later_clips_pass(dev, mod
     assert torch.equal(clip(d_stab, check=True), want)
     clip(d_bad, check='never')
     s.finish()                                              # never looked at
+    # the public default is the synchronous check; the error is a type of its own that names the clip; and a
+    # deferred verdict is raised BEFORE anything of the next clip -- its sweep included -- is queued
+    import inspect
+    from meshflow_amd import DegenerateMeshError
+    assert inspect.signature(s.stabilize_resident).parameters['check'].default is True
+    with pytest.raises(DegenerateMeshError) as err:
+        clip(d_bad, check=True)
+    assert err.value.clip_serial == s.resident_serial and err.value.cells >= 1 and isinstance(err.value, ValueError)
+    clip(d_stab)
+    clip(d_bad)                                             # deferred, serial k: its slot comes up again two clips on
+    bad_serial = s.resident_serial
+    clip(d_stab)
+    swept, serial = s._resident.get('swept'), s.resident_serial
+    with pytest.raises(DegenerateMeshError) as err:
+        s.stabilize_resident(d_fr, d_good, hom, check='deferred')
+    assert err.value.clip_serial == bad_serial
+    assert s._resident.get('swept') is swept and s.resident_serial == serial       # no sweep queued, no clip issued
+    out, bounds, _ = s.stabilize_resident(d_fr, d_good, hom)                         # the same call again goes through (default: checked at once)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    s.finish()
 
 
 def test_resident_table_cache_is_bounded(dev):
@@ -300,7 +321,7 @@ def test_resident_pipelines_of_several_threads_on_streams_of_their_own():
             with torch.cuda.stream(stream):
                 queue = []
                 for _ in range(100):
-                    queue.append(s.stabilize_resident(d_frames, d_disp, hom))
+                    queue.append(s.stabilize_resident(d_frames, d_disp, hom, check='deferred'))
                     if len(queue) >= 4:
                         out, b, st = queue.pop(0)
                         stream.synchronize()

@@ -23,6 +23,6 @@ for rnd in range(4):
         r = s.stabilize_clip(frames, disp, hom, crop=True)
         del r
     for _ in range(500):
-        s.stabilize_resident(d_frames, d_disp, hom)
+        s.stabilize_resident(d_frames, d_disp, hom, check='deferred')
     s.finish(); torch.cuda.synchronize()
     snap(f'after {50 * (rnd + 1)} host clips + {500 * (rnd + 1)} resident clips')
