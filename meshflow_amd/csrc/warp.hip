@@ -98,6 +98,15 @@ constexpr int LDS_WINDOW_BYTES = MF_STAGE_CHUNKS * 16;
 // in the border colour; the row of frame row H lands behind row 11, inside the window's own bytes.
 constexpr int LDS_WINDOW_PAD = 176;
 
+// LDS pointer of a __shared__ object WITHOUT the generic -> LDS conversion (which comes with a null check: s_mov src_shared_base + s_cmp +
+// s_cselect, three scalar instructions per global->LDS copy, and the scalar unit is as loaded as the vector unit here): the low
+// 32 bits of a generic address into LDS are the LDS address.
+typedef __attribute__((address_space(3))) uint8_t* lds_bytes_t;
+__device__ __forceinline__ lds_bytes_t lds_ptr(const void* shared_object)
+{
+    return (lds_bytes_t)(uintptr_t)(uint32_t)(uintptr_t)shared_object;
+}
+
 // a * b + c on the 24-bit multiplier.  The empty asm makes `c` opaque so that the compiler keeps two chained
 // v_mad_u32_u24 instead of re-associating them into mul + mul + add3 (no instruction is emitted by it, so the
 // compiler still pads every hazard itself).
@@ -638,6 +647,13 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(pv.x), "s"(pv.w), "s"(rg) : "memory");
     MF_EXP_STAMP(exp_t1);
 #endif
+    // Lane -> footprint row.  The byte taps are served per group of 32 lanes, bank = dword address mod 32, and the eight lanes of a
+    // footprint row take every third bank.  With the wide window (pitch 160 bytes = 40 banks) the rows 0..3 of lanes 0-31 start 0, 8, 16,
+    // 24 banks apart: no two lanes on one bank.  With the COMPACT window (pitch 112 bytes = 28 banks) rows 0 and 3 would collide on four
+    // banks -- every tap instruction 3.5 instead of 1.8 LDS cycles (tools/ubench_lds_rowmap.hip) -- so there lanes 0-31 take rows 0, 2, 4, 6
+    // (0, 24, 16, 8 banks apart) and lanes 32-63 rows 1, 3, 5, 7 (set where the COMPACT copy is issued: wave-uniform).  Every lane still
+    // owns four pixels of ONE row.
+    uint32_t row = (uint32_t)lane >> 3;
     if (staged) {
         // Source region -> LDS, asynchronously (global_load_lds: no VGPRs, no ds_write).  Two layouts, chosen by the plan:
         //   COMPACT (hot footprints whose taps fit 9 rows x 112 bytes: ~3/4 of them): ONE load, lane i fetches the i-th 16-byte
@@ -647,8 +663,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         // chunk i sits at row i / P, byte 16 (i % P) of the window = byte (i / P) (row_bytes - 16 P) + 16 i from gbase;
         // uniform base + opaque 32-bit lane offset keeps the address arithmetic 32-bit (saddr + voffset form)
         const uint8_t* __restrict__ gbase = src + ((uint64_t)src_dwords << 2);
-        // (one generic -> LDS conversion: each comes with a null check)
-        __attribute__((address_space(3))) uint8_t* const window = (__attribute__((address_space(3))) uint8_t*)&s_src[0];
+        const lds_bytes_t window = lds_ptr(&s_src[0]);
 #ifndef MF_NO_BORDER
         if (rg & MF_REGION_BORDER) {
             // BORDER window: the 12 rows only (its last row may be the frame's last: there is no 13th to fetch) -- chunks 0..63, then 64..119
@@ -666,6 +681,9 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
             uint32_t o0 = __umul24(((uint32_t)lane * 37u) >> 8, g.row_bytes - (uint32_t)MF_COMPACT_PITCH) + ((uint32_t)lane << 4);
             asm("" : "+v"(o0));
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o0), (__attribute__((address_space(3))) void*)window, 16, 0, 0);
+#ifndef MF_NO_ROWMAP
+            row = (((uint32_t)lane >> 2) & 6u) | ((uint32_t)lane >> 5);
+#endif
         } else
 #endif
         {
@@ -682,18 +700,8 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     // taps are addressed by absolute LDS byte address (= LDS_PITCH iy + 3 ix - lds_origin): the window base is folded in
     const uint32_t lds_origin = (rg & MF_REGION_ORIGIN_MASK) - (uint32_t)(uintptr_t)&s_src[0];
     const crec_t frec = (crec_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(records) + f * g.rec_frame_bytes);
-#ifndef MF_NO_ROWMAP
-    // Lane -> footprint row.  The byte taps are served per group of 32 lanes, bank = dword address mod 32, and the eight lanes of a
-    // footprint row take every third bank.  With the wide window (pitch 160 bytes = 40 banks) the rows 0..3 of lanes 0-31 start 0, 8, 16,
-    // 24 banks apart: no two lanes on one bank.  With the COMPACT window (pitch 112 bytes = 28 banks) rows 0 and 3 would collide on four
-    // banks -- every tap instruction 3.5 instead of 1.8 LDS cycles (tools/ubench_lds_rowmap.hip) -- so there lanes 0-31 take rows 0, 2, 4, 6
-    // (0, 24, 16, 8 banks apart) and lanes 32-63 rows 1, 3, 5, 7.  Wave-uniform choice; every lane still owns four pixels of ONE row.
     const bool compact = STAGE_OK && !SCAN && (rg & MF_REGION_COMPACT) != 0;
-    const int y = ya + (int)(compact ? ((((uint32_t)lane >> 2) & 6u) | ((uint32_t)lane >> 5)) : ((uint32_t)lane >> 3));
-#else
-    const bool compact = STAGE_OK && !SCAN && (rg & MF_REGION_COMPACT) != 0;
-    const int y = ya + (lane >> 3);
-#endif
+    const int y = ya + (int)row;
     const int x0 = xa + (lane & 7) * 4;                                  // first of this lane's 4 pixels
     const double xs0 = (double)x0, yy = (double)y;
 
@@ -892,9 +900,9 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
             const uint8_t* __restrict__ g0 = (const uint8_t*)(uintptr_t)b0;
             const uint8_t* __restrict__ g1 = (const uint8_t*)(uintptr_t)b1;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + lo4),
-                                             (__attribute__((address_space(3))) void*)&s_hi[0][0][0], 4, 0, 0);
+                                             (__attribute__((address_space(3))) void*)lds_ptr(&s_hi[0][0][0]), 4, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g1 + lo4),
-                                             (__attribute__((address_space(3))) void*)&s_hi[0][1][0], 4, 0, 0);
+                                             (__attribute__((address_space(3))) void*)lds_ptr(&s_hi[0][1][0]), 4, 0, 0);
         }
         const cedge_t eb = fedge + k0 * MF_EDGE_FLOATS + 3u * (pv.z & 3u);
 #ifndef MF_NO_FASTPAIR
@@ -1008,7 +1016,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
                     asm("" : "+s"(bi));
                     const uint8_t* __restrict__ gi = (const uint8_t*)(uintptr_t)bi;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gi + lo4),
-                                                     (__attribute__((address_space(3))) void*)&s_hi[0][i][0], 4, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)lds_ptr(&s_hi[0][i][0]), 4, 0, 0);
                 }
             }
         }
@@ -1148,7 +1156,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
                     const uint32_t k = (d >> (16 * (e & 1))) & 0xFFFu;
                     const uint8_t* __restrict__ g = (const uint8_t*)(uintptr_t)(frec + k * MF_CELL_DOUBLES + MF_CELL_OFF_HI);
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + lo4),
-                                                     (__attribute__((address_space(3))) void*)&s_hi[wave][e][0], 4, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)lds_ptr(&s_hi[wave][e][0]), 4, 0, 0);
                 }
             }
             uint32_t own[4];                                            // byte offset of the owner's matrix row (OWN_ROW * entry)
@@ -1760,7 +1768,8 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
 
 int launch_crop_scan(const TableView& tv, int n, int W, int H, int R, int C, int32_t* crop, hipStream_t st)
 {
-    if (n <= 0 || n > 65535 * 64 || W < 2 || H < 2 || W > 32767 || H > 32767 || R <= 0 || C <= 0 || R > MAX_MESH || C > MAX_MESH) {
+    // (any number of frames, like launch_warp: the launches below take per_launch frames at a time)
+    if (n <= 0 || W < 2 || H < 2 || W > 32767 || H > 32767 || R <= 0 || C <= 0 || R > MAX_MESH || C > MAX_MESH) {
         set_error("mf_crop_scan_f64: unsupported shape n=%d W=%d H=%d R=%d C=%d", n, W, H, R, C);
         return MF_ERR_INVALID_ARG;
     }

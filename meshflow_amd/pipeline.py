@@ -38,17 +38,19 @@ class HostClip:
             first = np.asarray(frames[0])
             if first.ndim != 3 or first.shape[2] != 3:
                 raise ValueError('frames must be num_frames arrays of shape (H, W, 3)')
-            _need_u8(first)
-            self.array = None
-            self.frames = frames
             self.height, self.width = first.shape[:2]
+            # EVERY frame is checked here, before anything is issued (dtype uint8, the first frame's shape; C-contiguous -- a frame that
+            # is not gets a contiguous copy, the others are taken as they are): a bad frame k fails in the constructor, not mid-clip
+            self.array = None
+            self.frames = [_as_frame(f, self.height, self.width) for f in frames]
         self.num_frames = num_frames
 
     def upload(self, d_frames, i0, i1):
-        """Blocking copy of frames i0..i1-1 into d_frames[i0:i1] on the calling thread's current stream."""
+        """Blocking copy of frames i0..i1-1 into d_frames[i0:i1] on the calling thread's current stream (streaming.py's decode-side
+        staging; the clip methods of the stabilizer go through csrc/hostpipe.hip instead)."""
         import torch
         if self.array is not None:
             d_frames[i0:i1].copy_(torch.from_numpy(self.array[i0:i1]))
         else:
             for i in range(i0, i1):
-                d_frames[i].copy_(torch.from_numpy(_as_frame(self.frames[i], self.height, self.width)))
+                d_frames[i].copy_(torch.from_numpy(self.frames[i]))

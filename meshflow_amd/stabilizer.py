@@ -47,8 +47,7 @@ def _warp_host_c(self, clip, unstab, stab, crop=False, keep_uncropped=True):
     from . import _lib, pipeline
     dev = self._torch_device()
     n, H, W = clip.num_frames, clip.height, clip.width
-    frames = [clip.array[i] for i in range(n)] if clip.array is not None else \
-        [pipeline._as_frame(f, H, W) for f in clip.frames]
+    frames = [clip.array[i] for i in range(n)] if clip.array is not None else clip.frames      # (validated by HostClip, every one of them)
     fb = H * W * 3
     want_out = keep_uncropped or not crop
     out = np.empty((n, H, W, 3), dtype=np.uint8) if want_out else None
@@ -358,8 +357,7 @@ class MeshFlowStabilizer:
         n = len(uncropped_frames)
         clip = pipeline.HostClip(uncropped_frames, n)
         H, W = clip.height, clip.width
-        frames = [clip.array[i] for i in range(n)] if clip.array is not None else \
-            [pipeline._as_frame(f, H, W) for f in clip.frames]
+        frames = [clip.array[i] for i in range(n)] if clip.array is not None else clip.frames       # (every frame validated by HostClip)
         left, top, right, bottom = (int(v) for v in crop_boundaries)
         out = np.empty((n, H, W, 3), dtype=np.uint8)
         fb = H * W * 3

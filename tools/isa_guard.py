@@ -2,7 +2,7 @@
 the instruction listing of one execution path of it (what used to be hand-kept under profiles/*_isa.txt).
 
     python tools/isa_guard.py [lib.so]                       checks; prints resources and what was verified; exit code 1 on a violation
-    python tools/isa_guard.py [lib.so] --walk hot-compact    + every instruction a wavefront issues on a named path (or --walk TNNT... by hand)
+    python tools/isa_guard.py [lib.so] --walk NNTN...        + every instruction a wavefront issues on ONE path: T / N per conditional branch met
 
 Why.  Two places in csrc/warp.hip issue loads the COMPILER DOES NOT KNOW ABOUT:
   * the speculative matrix load -- `s_load_dwordx16` + `s_load_dwordx2` from inline asm at the top of the kernel.  Scalar loads return
@@ -261,16 +261,20 @@ def walk(k, decisions):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith('--')]
-    so = args[0] if args else os.path.join(REPO, 'meshflow_amd', 'libmeshflow_hip.so')
+    argv = sys.argv[1:]
+    decisions = None
+    if '--walk' in argv:
+        at = argv.index('--walk')
+        decisions = argv[at + 1]
+        del argv[at:at + 2]
+    so = argv[0] if argv else os.path.join(REPO, 'meshflow_amd', 'libmeshflow_hip.so')
     try:
         for line in check_library(so):
             print('ok  ' + line)
     except AssertionError as e:
         print('VIOLATION  ' + str(e))
         raise SystemExit(1)
-    if '--walk' in sys.argv:
-        decisions = sys.argv[sys.argv.index('--walk') + 1]
+    if decisions is not None:
         kernels = disassemble(so)
         k = next(v for s, v in kernels.items() if s.startswith(WARP_TRUE))
         lines, n, cyc, d = walk(k, decisions)
