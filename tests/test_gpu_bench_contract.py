@@ -152,3 +152,25 @@ def test_bench_failed_rank_gives_nonzero_exit():
                            '--warmup', '0'], cwd=REPO, capture_output=True, text=True, timeout=600, env=env)
     assert proc.returncode != 0
     assert not [l for l in proc.stdout.splitlines() if l.strip().startswith('{')]
+
+
+def test_bench_eight_ranks_under_the_drivers_own_launcher():
+    """The SCALE run's shape at N = 8 on the one-GPU test box: the driver's launcher line with eight gloo ranks sharing the GPU, `bench.py`'s
+    own step (frame-range shard, replicated sweep over all 8 x 6 frames, 16-byte all-reduce), gather and sharded drain.  The gathered clip's
+    per-frame checksums and the clip rectangle equal ONE process doing the whole 48-frame clip."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['MESHFLOW_DIST_BACKEND'] = 'gloo'
+    port = 29900 + os.getpid() % 90
+    common = ['--workload', 'small', '--steps', '2', '--warmup', '1', '--cpu-frames', '0', '--checksum']
+    proc = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+                           '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '8', '--frames', '6'] + common,
+                          cwd=REPO, capture_output=True, text=True, timeout=1500, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    d = json.loads(lines[0])
+    _contract(d, 8, 2, 1)
+    assert d['communicator']['world_size'] == 8 and d['communicator']['backend'] == 'gloo' and '48 total' in d['config']['workload']
+    assert d['gather_to_rank0_ms'] > 0 and 'gather_error' not in d and d['frames_checksum_range'] == [0, 48] and len(d['frames_checksum']) == 48
+    one = _run('--frames', '48', '--no-e2e', '--no-workloads', *common[2:])
+    assert one['frames_checksum'] == d['frames_checksum'] and one['crop_bounds'] == d['crop_bounds']
