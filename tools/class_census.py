@@ -58,6 +58,20 @@ def main():
         for name, m in (('hot', hot), ('pair', pair), ('  pair lane-uniform (FAST)', pair & ((y & 1) != 0)), ('  pair vertical edge', pair & ((y & 2) != 0)),
                         ('multi', multi), ('border', border), ('rest', rest)):
             print(f'   {name:28s} {m.mean():8.4f} of the footprints, COMPACT {compact[m].mean() if m.any() else 0:.4f} of them')
+        # the multi class by list length and by how many of its entries carry a two-edge code (bit 3 of the 6-bit code in e[4 + i])
+        w = plan[:, 3]
+        cnt = ((z >> 6) & 3) + 1
+        codes = np.stack([z & 0x3F, (z >> 16) & 0x3F, w & 0x3F, (w >> 16) & 0x3F], axis=1)
+        ent = np.stack([x & 0xFFFF, x >> 16, y & 0xFFFF, y >> 16], axis=1)
+        is_in = (ent & 0x8000) != 0
+        for k in (2, 3, 4):
+            mk = multi & (cnt == k)
+            if not mk.any():
+                continue
+            two = ((codes[mk][:, :k] & 8) != 0) & ~is_in[mk][:, :k]
+            last_in = is_in[mk][np.arange(mk.sum()), k - 1]
+            print(f'   multi with {k} cells: {mk.mean():.4f} of the footprints ({mk.sum() / max(multi.sum(), 1):.3f} of multi); last entry IN {last_in.mean():.3f}; '
+                  f'two-edge entries per list: ' + ', '.join(f'{j}: {(two.sum(1) == j).mean():.3f}' for j in range(k + 1)))
 
 
 if __name__ == '__main__':
