@@ -474,63 +474,20 @@ __device__ __forceinline__ void taps_clamped(uint32_t a00, uint32_t a01, uint32_
                  : "v"(a00), "v"(a01), "v"(a10), "v"(a11) : "memory");
 }
 
-#ifdef MF_TAPS_U16
-// EXPERIMENT (tools/ab_warp.py): the taps as 16-bit LDS loads -- three per tap row (bytes 0-1 = B0 G0, 2-3 = R0 B1, 4-5 = G1 R1) instead of
-// six byte loads, at whatever byte alignment the row starts (3 ix) -- and one v_perm_b32 per channel and row instead of one v_or_b32:
-// 24 LDS instructions per lane instead of 48, 24 four-cycle VALU instructions instead of 24 two-cycle ones.
-struct TapRegs16 { uint32_t r[6]; };
-#define MF_TAP16_LOADS(R0, R1, R2, R3, R4, R5, A, P0, P2, P4)                                                                        \
-    "ds_read_u16 " R0 ", " A " offset:0\n\tds_read_u16 " R1 ", " A " offset:2\n\tds_read_u16 " R2 ", " A " offset:4\n\t"              \
-    "ds_read_u16 " R3 ", " A " offset:" P0 "\n\tds_read_u16 " R4 ", " A " offset:" P2 "\n\tds_read_u16 " R5 ", " A " offset:" P4 "\n\t"
-#define MF_TAP16_PAIR_ASM(P0, P2, P4)                                                                                                \
-    asm volatile(MF_TAP16_LOADS("%0", "%1", "%2", "%3", "%4", "%5", "%12", P0, P2, P4)                                               \
-                 MF_TAP16_LOADS("%6", "%7", "%8", "%9", "%10", "%11", "%13", P0, P2, P4)                                             \
-                 "s_waitcnt lgkmcnt(0)"                                                                                             \
-                 : "=&v"(t.r[0]), "=&v"(t.r[1]), "=&v"(t.r[2]), "=&v"(t.r[3]), "=&v"(t.r[4]), "=&v"(t.r[5]),                        \
-                   "=&v"(u.r[0]), "=&v"(u.r[1]), "=&v"(u.r[2]), "=&v"(u.r[3]), "=&v"(u.r[4]), "=&v"(u.r[5])                         \
-                 : "v"(at0), "v"(at1) : "memory")
-template <int PITCH>
-__device__ __forceinline__ void taps_pair16(uint32_t at0, uint32_t at1, TapRegs16& t, TapRegs16& u)
-{
-    if (PITCH == MF_STAGE_PITCH) MF_TAP16_PAIR_ASM("160", "162", "164");
-    else MF_TAP16_PAIR_ASM("112", "114", "116");
-}
-__device__ __forceinline__ void blend_pixel16(uint32_t bxj, uint32_t byj, const TapRegs16& t, uint32_t& oB, uint32_t& oG, uint32_t& oR)
-{
-    // r[0] = B0 | G0 << 8, r[1] = R0 | B1 << 8, r[2] = G1 | R1 << 8 (row iy; r[3..5] row iy + 1): per channel X0 | X1 << 16
-    const uint32_t selB = 0x0C050C00u, selG = 0x0C040C01u;        // v_perm_b32(S0, S1, sel): bytes 0-3 = S1, 4-7 = S0, 0x0C = zero
-    const uint32_t tB = __builtin_amdgcn_perm(t.r[1], t.r[0], selB), tG = __builtin_amdgcn_perm(t.r[2], t.r[0], selG), tR = __builtin_amdgcn_perm(t.r[2], t.r[1], selB);
-    const uint32_t bB = __builtin_amdgcn_perm(t.r[4], t.r[3], selB), bG = __builtin_amdgcn_perm(t.r[5], t.r[3], selG), bR = __builtin_amdgcn_perm(t.r[5], t.r[4], selB);
-    const uint32_t fy = byj & 31u, wy = 32u - fy;
-    const uint32_t vB = umad24(bB, fy, __umul24(tB, wy));
-    const uint32_t vG = umad24(bG, fy, __umul24(tG, wy));
-    const uint32_t vR = umad24(bR, fy, __umul24(tR, wy));
-    const uint32_t fx = bxj & 31u;
-    const uint32_t wq = umad24(fx, 0x3FFFC0u, 2048u);
-    oB = udot2(vB, wq, 32768u);
-    oG = udot2(vG, wq, 32768u);
-    oR = udot2(vR, wq, 32768u);
-}
-#endif
-
-// (two pixels' loads in flight at a time: 24 registers; a software pipeline with counted lgkmcnt waits measured the same)
+// (two pixels' loads in flight at a time: 24 registers; a software pipeline with counted lgkmcnt waits measured the same.  Round 6: the
+// taps as 16-bit loads -- three per tap row instead of six byte loads, one v_perm_b32 per channel and row instead of a v_or_b32 -- are
+// byte-identical and 3.9 x slower: a ds_read_u16 at an ODD byte address costs 56 cycles per wave64 instruction against 1.9 at an even
+// one, and a tap row starts at byte 3 ix; tools/ubench_lds_u16.hip, profiles/r06_ubench_lds_u16.txt.)
 template <int PITCH = LDS_PITCH>
 __device__ __forceinline__ void gather_blend_sums(const uint32_t (&bx)[4], const uint32_t (&by)[4], uint32_t lds_origin,
                                                   uint32_t (&oB)[4], uint32_t (&oG)[4], uint32_t (&oR)[4])
 {
 #pragma unroll
     for (int j = 0; j < 4; j += 2) {
-#ifdef MF_TAPS_U16
-        TapRegs16 t0, t1;
-        taps_pair16<PITCH>(tap_address<PITCH>(bx[j], by[j], lds_origin), tap_address<PITCH>(bx[j + 1], by[j + 1], lds_origin), t0, t1);
-        blend_pixel16(bx[j], by[j], t0, oB[j], oG[j], oR[j]);
-        blend_pixel16(bx[j + 1], by[j + 1], t1, oB[j + 1], oG[j + 1], oR[j + 1]);
-#else
         TapRegs t0, t1;
         taps_pair<PITCH>(tap_address<PITCH>(bx[j], by[j], lds_origin), tap_address<PITCH>(bx[j + 1], by[j + 1], lds_origin), t0, t1);
         blend_pixel(bx[j], by[j], t0, oB[j], oG[j], oR[j]);
         blend_pixel(bx[j + 1], by[j + 1], t1, oB[j + 1], oG[j + 1], oR[j + 1]);
-#endif
     }
 }
 template <int PITCH = LDS_PITCH>
@@ -742,7 +699,10 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o1), (__attribute__((address_space(3))) void*)(window + 1024), 16, 0, 0);
         }
     }
-    if (!SCAN && (MF_EXP_SKIP & 64)) { asm volatile("" :: "s"(pv.x), "s"(pv.y), "s"(pv.z), "s"(pv.w)); return; }
+    // (a wavefront must not END with its global->LDS copy in flight: on this stack that is a GPU memory access fault -- tools/phase_variant_check.py --
+    // so the timing-only returns below wait for it; `MF_EXP_RETURN` = that wait + return)
+#define MF_EXP_RETURN do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; } while (0)
+    if (!SCAN && (MF_EXP_SKIP & 64)) { asm volatile("" :: "s"(pv.x), "s"(pv.y), "s"(pv.z), "s"(pv.w)); MF_EXP_RETURN; }
     // taps are addressed by absolute LDS byte address (= LDS_PITCH iy + 3 ix - lds_origin): the window base is folded in
     const uint32_t lds_origin = (rg & MF_REGION_ORIGIN_MASK) - (uint32_t)(uintptr_t)&s_src[0];
     const crec_t frec = (crec_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(records) + f * g.rec_frame_bytes);
@@ -755,7 +715,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         // The plan certifies everything (~2/3 of the footprints at config-2 geometry): ONE cell owns all 256 pixels, its
         // denominator allows the trimmed reciprocal (UNIT), the footprint lies inside the frame, its window is staged and every
         // tap is at least two pixels inside the frame (DEEP: no crop flag either).  Straight-line code, all lanes active.
-        if (MF_EXP_SKIP & 1) return;
+        if (MF_EXP_SKIP & 1) MF_EXP_RETURN;
 #ifdef MF_EXP_TWICE
         {   // the per-pixel work a second time (rows + 8), stored over the first result
             float u2[4], v2[4];
@@ -827,7 +787,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         // clamping, no per-tap selects (cv2.remap BORDER_CONSTANT, mfs.py:1063-1069).  Pixels the cell does not cover get the border
         // colour (the map template's (W+1, H+1), mfs.py:983-984) and take no part in the crop scan; a pixel inside the float32 error
         // band of an edge sends the wavefront to the general code.
-        if (MF_EXP_SKIP & 2) return;
+        if (MF_EXP_SKIP & 2) MF_EXP_RETURN;
         const uint32_t k0 = pv.x & 0xFFFu;
         uint32_t cov = 0xFu;
         bool decided = true;
@@ -936,7 +896,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         // config 3): the later cell wins wherever ONE of its mask edges passes -- one float32 fma per pixel -- and the other cell
         // owns what is left; denominators, window and interior as on the hot path.  Both inverse homographies go to LDS by
         // global->LDS DMA (one 80-byte load per cell, scalar base address), and every pixel reads its owner's row.
-        if (MF_EXP_SKIP & 4) return;
+        if (MF_EXP_SKIP & 4) MF_EXP_RETURN;
         const uint32_t k0 = pv.x & 0xFFFu, k1 = (pv.x >> 16) & 0xFFFu;
         if (lane < 20) {
             uint32_t lo4 = (uint32_t)lane << 2;
@@ -1049,7 +1009,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         // Two to four cells, each MIXED one with one or two coded mask edges (the four cells around a mesh vertex, three of them, or a
         // pair the pair path did not take); window, interior and denominators certified, coverage not: a pixel that no listed cell
         // takes -- or one inside the float32 error band of an edge -- sends the wavefront to the general code.
-        if (MF_EXP_SKIP & 8) return;
+        if (MF_EXP_SKIP & 8) MF_EXP_RETURN;
         const int ne = (int)((pv.z >> MF_PLAN_COUNT_SHIFT) & 3u) + 1;
         if (lane < 20) {
             uint32_t lo4 = (uint32_t)lane << 2;
@@ -1138,7 +1098,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     }
 
     // Everything else: more candidate cells, uncertified denominators, frame borders, uncovered pixels.
-    if (!SCAN && (MF_EXP_SKIP & 16)) return;
+    if (!SCAN && (MF_EXP_SKIP & 16)) MF_EXP_RETURN;
     uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
     const uint32_t limit = (int)f == n - 1 ? g.frame_bytes : 0xFFFFFFFFu;   // only the last frame has nothing behind it
     const float fWm1 = (float)(W - 1), fHm1 = (float)(H - 1);
