@@ -2,6 +2,7 @@
 the instruction listing of one execution path of it (what used to be hand-kept under profiles/*_isa.txt).
 
     python tools/isa_guard.py [lib.so]                       checks; prints resources and what was verified; exit code 1 on a violation
+    python tools/isa_guard.py lib.so --hazards-only          experiment builds (paths compiled out): only the in-flight scalar-load hazard
     python tools/isa_guard.py [lib.so] --walk NNTN...        + every instruction a wavefront issues on ONE path: T / N per conditional branch met
 
 Why.  Two places in csrc/warp.hip issue loads the COMPILER DOES NOT KNOW ABOUT:
@@ -179,6 +180,19 @@ def check_resources(md, name):
     return ', '.join(f'{key} {got[key]} (<= {LIMITS[key]})' for key in LIMITS)
 
 
+def check_hazards_only(so_path):
+    """For EXPERIMENT builds (tools/phase_profile.sh: code paths compiled out, the speculative load possibly with them): only the hazard
+    itself -- no 16-dword scalar load of either warp kernel has a destination register rewritten before an s_waitcnt lgkmcnt(0)."""
+    report = []
+    for sym, k in disassemble(so_path).items():
+        x16 = [i for i, ins in enumerate(k.code) if ins.startswith('s_load_dwordx16')]
+        for i in x16:
+            n = 2 if k.code[i + 1].startswith('s_load_dwordx2') and k.code[i + 1].replace(',', ' ').split()[2] == k.code[i].replace(',', ' ').split()[2] else 1
+            _check_scalar_load(k, i, n)
+        report.append(f'{sym[:40]}...: {len(x16)} s_load_dwordx16, none rewritten in flight')
+    return report
+
+
 def check_library(so_path):
     """All checks on one built library; returns the report lines (raises AssertionError on a violation)."""
     kernels = disassemble(so_path)
@@ -268,8 +282,12 @@ def main():
         decisions = argv[at + 1]
         del argv[at:at + 2]
     so = argv[0] if argv else os.path.join(REPO, 'meshflow_amd', 'libmeshflow_hip.so')
+    hazards_only = '--hazards-only' in argv
+    if hazards_only:
+        argv.remove('--hazards-only')
+        so = argv[0] if argv else so
     try:
-        for line in check_library(so):
+        for line in (check_hazards_only(so) if hazards_only else check_library(so)):
             print('ok  ' + line)
     except AssertionError as e:
         print('VIOLATION  ' + str(e))
