@@ -595,10 +595,8 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
                                                const WarpGeom& g, const uint8_t* __restrict__ frames,
                                                const double* __restrict__ records, uint8_t* __restrict__ out,
                                                const float* __restrict__ edges, int n, int W,
-                                               int H, int C, uint32_t border, int32_t* __restrict__ crop, int32_t* __restrict__ clip,
-                                               uint32_t pf_fp = 0xFFFFFFFFu, uint32_t pf_f = 0u)
+                                               int H, int C, uint32_t border, int32_t* __restrict__ crop, int32_t* __restrict__ clip)
 {
-    (void)pf_fp; (void)pf_f;
     // inverse homographies of the footprint's candidate cells: [entry][Hi0..Hi8, pad] (80-byte rows)
     __shared__ __attribute__((aligned(16))) double s_hi[1][9][10];                // row 8: the "no cell" matrix, see OWN_NONE
     // source region of the footprint: MF_STAGE_ROWS rows of MF_STAGE_PITCH bytes (+ slack for the third dword of the last tap)
@@ -639,6 +637,9 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         asm volatile("s_load_dwordx16 %0, %2, 0x48\n\ts_load_dwordx2 %1, %2, 0x88" : "=&s"(hg_lo), "=&s"(hg_hi) : "s"(gaddr));     // (early clobber: the address pair is read by both loads)
     }
 #endif
+    // (Round 6, measured and dropped -- profiles/r06_ab_prefetch.txt, profiles/README.md: touching the window lines of the footprint this
+    // block index takes one or two frames on, to have them in the XCD's L2: +12...24 %; testing t >= per_frame BEHIND the plan's loads so
+    // that all kernel arguments arrive in one scalar round trip instead of two: +-0.)
     const uint32_t fp = f * g.per_frame + t;                              // the footprint's slot in plan / regions
     typedef const __attribute__((address_space(4))) uint32_t* cword_t;
     const cword_t pw = (cword_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(plan) + 16u * fp);
@@ -646,17 +647,6 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
     const uint4 pv = make_uint4(pw[0], pw[1], pw[2], pw[3]);             // wave-uniform: scalar loads
     typedef const __attribute__((address_space(4))) uint64_t* cword2_t;
     const uint64_t region = *(cword2_t)rw;                               // both words in one load (the second is needed right after the first)
-#ifdef MF_PREFETCH
-    // CROSS-WAVEFRONT WINDOW PREFETCH (experiment).  Every wavefront's window is a first touch -- HBM traffic is 1.04 x the algorithmic
-    // bytes -- so its global->LDS copy takes ~3,400 cycles under load and a hot wavefront waits 1,500 of its 6,100 cycles for it (config 2,
-    // profiles/r06_phase_profile.txt).  The workgroup with the same blockIdx.x MF_PREFETCH frames on runs on the SAME XCD (same L2) one or
-    // two generations of wavefronts later: this wavefront touches that footprint's window lines now (one 4-byte global->LDS load per
-    // 128-byte line into a dummy LDS slot, issued LAST before the window wait, which becomes vmcnt(1): loads return in order).
-    __shared__ uint32_t s_pf[64];
-    const bool pf_on = STAGE_OK && !SCAN && pf_fp != 0xFFFFFFFFu;
-    uint64_t region2 = 0;
-    if (pf_on) region2 = *(cword2_t)(cword_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(regions) + 8u * pf_fp);
-#endif
     const uint32_t rg = (uint32_t)region, src_dwords = (uint32_t)(region >> 32);
     const uint8_t* __restrict__ src = frames + (uint64_t)f * g.frame_bytes;
     const bool staged = STAGE_OK && !SCAN && (rg & MF_REGION_STAGED) != 0;
@@ -714,28 +704,6 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + o1), (__attribute__((address_space(3))) void*)(window + 1024), 16, 0, 0);
         }
     }
-#ifdef MF_PREFETCH
-    const bool pf_go = pf_on && ((uint32_t)region2 & MF_REGION_STAGED) != 0;
-    const auto window_wait = [&]() {
-        if (pf_go) {
-            const bool pc = ((uint32_t)region2 & MF_REGION_COMPACT) != 0;
-            // COMPACT: rows 0..9, bytes 0 and 108 of each (a 112-byte row meets at most two 128-byte lines); wide: rows 0..12, bytes 0, 76, 156
-            const uint32_t l = (uint32_t)lane;
-            const uint32_t prow = pc ? (l >> 1) : ((l * 171u) >> 9), which = pc ? (l & 1u) : (l - 3u * ((l * 171u) >> 9));
-            uint32_t off = __umul24(prow, g.row_bytes) + (pc ? which * 108u : which * 76u + (which & 2u) * 2u);
-            asm("" : "+v"(off));
-            const uint8_t* __restrict__ base2 = frames + (uint64_t)pf_f * g.frame_bytes + ((uint64_t)(uint32_t)(region2 >> 32) << 2);
-            if (l < (pc ? 19u : 38u))
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base2 + off), (__attribute__((address_space(3))) void*)lds_ptr(&s_pf[0]), 4, 0, 0);
-            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    };
-#define MF_WINDOW_WAIT() window_wait()
-#else
-#define MF_WINDOW_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#endif
     // (a wavefront must not END with its global->LDS copy in flight: on this stack that is a GPU memory access fault -- tools/phase_variant_check.py --
     // so the timing-only returns below wait for it; `MF_EXP_RETURN` = that wait + return)
 #define MF_EXP_RETURN do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; } while (0)
@@ -795,7 +763,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         asm volatile("" :: "v"(bx[0]), "v"(bx[1]), "v"(bx[2]), "v"(bx[3]), "v"(by[0]), "v"(by[1]), "v"(by[2]), "v"(by[3]));
         MF_EXP_STAMP(exp_t2);
 #endif
-        MF_WINDOW_WAIT();                                                // the window has landed in LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the window has landed in LDS
         MF_EXP_STAMP(exp_t3);
         uint8_t* __restrict__ dst = out + (uint64_t)f * g.frame_bytes;
         const uint3 d = gather_blend_window(compact, bx, by, lds_origin);
@@ -883,7 +851,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
             }
             uint32_t bx[4], by[4];
             fixed_point(u, v, bx, by);
-            MF_WINDOW_WAIT();                                            // the window has landed in LDS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the window has landed in LDS
             // Paint what lies just outside the frame: whole pixels (B, G, R) at the LDS address the gather will form for them -- tap
             // (ix, iy) sits at LDS_PITCH iy + 3 ix - lds_origin.  Column -1 / W for the rows -1 .. 12 of the window (14 lanes each), row
             // -1 / H for the columns that lie completely inside a window row (at most 53 lanes; no tap needs any other).  LDS operations of a wavefront execute
@@ -970,7 +938,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
                 const float lo = fminf(g0, g3), hi = fmaxf(g0, g3);
                 const bool first = lo > EDGE_BAND, second = hi < -EDGE_BAND;         // (NaN coefficients: neither)
                 if (__ballot(!(first || second)) != 0) return false;
-                MF_WINDOW_WAIT();                                        // matrices and window have landed in LDS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // matrices and window have landed in LDS
                 typedef const __attribute__((address_space(3))) double* lds_d;
                 uint32_t hrow = (uint32_t)(uintptr_t)&s_hi[0][0][0] + (first ? 0u : OWN_ROW);
                 asm("" : "+v"(hrow));                                    // (one address register + immediate offsets, not a select per load)
@@ -1020,7 +988,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         }
         // (a pixel inside the float32 error band of the edge, or NaN coefficients: the general code below decides exactly)
         if (__ballot(!(near > EDGE_BAND)) == 0) {
-            MF_WINDOW_WAIT();                                            // matrices and window have landed in LDS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // matrices and window have landed in LDS
             float u[4], v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1091,7 +1059,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         }
         const uint32_t worst = max(max(own[0], own[1]), max(own[2], own[3]));
         if (__ballot(!(near > EDGE_BAND) || worst == OWN_NONE) == 0) {
-            MF_WINDOW_WAIT();                                            // matrices and window have landed in LDS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // matrices and window have landed in LDS
             float u[4], v[4];
             bool have = false;
 #ifndef MF_NO_FASTMULTI
@@ -1308,7 +1276,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
             // (c) coordinates, once per pixel, owner's matrix from LDS.  Optimistic: the
             // trimmed reciprocal is applied straight away (keeps one pixel's intermediates live instead of four) and the
             // rare footprint with a denominator outside [0.5, 2) is redone with the generic division.
-            MF_WINDOW_WAIT();                                          // the matrices (and the window, issued before them) have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the matrices (and the window, issued before them) have landed
             uint32_t eor = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1394,7 +1362,7 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
             fast = __ballot(active && !deep) == 0;
         }
         uint3 d;                                                        // the lane's 12 output bytes
-        if (staged) MF_WINDOW_WAIT();                                  // the window has landed in LDS
+        if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window has landed in LDS
         if (fast) {
             // fast path (wave-uniform): every pixel of the footprint samples the deep interior
             if (active) {
@@ -1559,14 +1527,7 @@ __global__ __launch_bounds__(64) MF_WARP_ATTR void warp_kernel(const FootPlan* _
     const uint32_t t = (blockIdx.x & 7u) * g.per_xcd + (blockIdx.x >> 3);
 #endif
     if (t >= g.per_frame) return;
-#ifdef MF_PREFETCH
-    const uint32_t f2 = f + (uint32_t)MF_PREFETCH;
-    const uint32_t t2 = ((blockIdx.x + f2) & 7u) * g.per_xcd + (blockIdx.x >> 3);
-    const uint32_t pf_fp = (f2 < (uint32_t)n && t2 < g.per_frame) ? f2 * g.per_frame + t2 : 0xFFFFFFFFu;
-    footprint_body<STAGE_OK, false>(f, t, plan, regions, g, frames, records, out, edges, n, W, H, C, border, crop, clip, pf_fp, f2);
-#else
     footprint_body<STAGE_OK, false>(f, t, plan, regions, g, frames, records, out, edges, n, W, H, C, border, crop, clip);
-#endif
 }
 
 // The crop-boundary scan WITHOUT the pixels (mfs.py:1075-1106 depends on the coordinate maps only, i.e. on the cell table): fills
