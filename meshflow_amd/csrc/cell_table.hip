@@ -418,6 +418,16 @@ __device__ __forceinline__ void plan_one_footprint(EdgeOf edge_of, HiOf hi_of, M
             if (cnt < 4) ent[0] |= entry; else ent[1] |= entry;
             ++cnt;
             if (all_in) closed = true;
+        }
+    }
+    // Second loop, over the LISTED cells only (round 6): the corner mapping below is the expensive half of a candidate's work and only listed
+    // cells need it.  In one loop the lanes of a wavefront reached it at different trip numbers -- the cells come in DESCENDING order, so a
+    // footprint inside one cell first dismisses the neighbours below and to the right whose boxes it meets, one to three trips -- and the block
+    // ran in nearly every trip for a few lanes each; now all lanes map the corners of their first listed cell together, then of the second.
+    // Same cells in the same order, same operations: the same plans (tools/compare_tables.py).
+    for (int i = 0; i < cnt && !overflow; ++i) {
+        const int k = (int)(((i < 4 ? ent[0] : ent[1]) >> (16 * (i & 3))) & 0xFFFu);
+        {
             // source position of the four footprint corners under this cell's inverse homography (float32 is ample:
             // the window keeps 1/16 pixel of slack, the float32 error at coordinates up to 8192 is below 0.01)
             float h[9];
@@ -627,7 +637,14 @@ constexpr int kPlanStageCells = MF_PLAN_STAGE_CELLS;          // cells (whole me
 // when they do not fit, from global.  (The staging -- three dependent global round trips and three barriers per workgroup -- was a
 // quarter of a workgroup's life at one footprint per thread: 1 / 2 / 4 / 6 / 8 per thread: cell table + plan 104.8 / 94.5 / 91.3 / 103 /
 // 104 us at config 2, 266 / 248 / 231 / 250 / 397 at config 3; twice the staged cells: slower, 115 / 296.)
-__global__ __launch_bounds__(256) void footprint_plan_kernel(const float* __restrict__ uedges, const float* __restrict__ edges,
+// Six wavefronts per SIMD: what the workgroup's 26 KB of LDS admit (six workgroups per CU) -- the kernel needs 85 registers by itself, the cap to
+// 80 costs no scratch and, with the candidate loop split in two (plan_one_footprint), is worth 3-5 % of table + plan (round 6:
+// 88.5 -> 86.3 (split) -> 83.7 us at config 2, 224.9 -> 219.9 -> 208.3 at config 3; tables byte-identical, tools/compare_tables.py).
+#ifndef MF_PLAN_WAVES
+#define MF_PLAN_WAVES 6
+#endif
+#define MF_PLAN_ATTR __attribute__((amdgpu_waves_per_eu(MF_PLAN_WAVES, MF_PLAN_WAVES)))
+__global__ __launch_bounds__(256) MF_PLAN_ATTR void footprint_plan_kernel(const float* __restrict__ uedges, const float* __restrict__ edges,
                                                              const double* __restrict__ records, const CellBox* __restrict__ boxes,
                                                              const int32_t* __restrict__ reach,
                                                              const int32_t* __restrict__ grid, int n, int W, int H, int R,

@@ -61,16 +61,27 @@ for step in range(steps):
     want, rect, wbad = expect(frames, disp, want_stab, R, C)
     if op == 'resident':
         serial[m] += 1
+        # round 6: the public default checks at once (the error belongs to THIS call); pipelined callers pass check='deferred'
+        deferred = bool(rng.integers(2))
+        issued_before = s.resident_serial
         try:
-            out, bounds, d_stab = s.stabilize_resident(torch.from_numpy(frames).to(dev), torch.from_numpy(disp).to(dev), hom)
-        except ValueError:                                # the deferred verdict of an EARLIER clip (two calls back): must have been degenerate
+            out, bounds, d_stab = s.stabilize_resident(torch.from_numpy(frames).to(dev), torch.from_numpy(disp).to(dev), hom,
+                                                       check='deferred' if deferred else True)
+        except ValueError as e:
+            if s.resident_serial != issued_before:            # THIS clip was issued and its own verdict came back at once
+                if deferred or not wbad or getattr(e, 'clip_serial', None) != s.resident_serial:
+                    bad += 1; print(step, 'a synchronous verdict that is not this clip\'s:', e)
+                continue
+            # nothing was issued: the deferred verdict of an EARLIER clip (its table slot came up again): must have been degenerate
             old = [p for p in pending[m] if p[1]]
             if not old:
                 bad += 1; print(step, 'a deferred verdict without a degenerate clip before it')
             pending[m] = [p for p in pending[m] if not p[1] or p is not old[0]]
             serial[m] -= 1
             continue
-        pending[m].append((serial[m], bool(wbad)))
+        if wbad and not deferred:
+            bad += 1; print(step, 'a degenerate clip passed the synchronous check')
+        pending[m].append((serial[m], bool(wbad) and deferred))
         pending[m] = pending[m][-2:] if not any(d for _, d in pending[m][:-2]) else pending[m]
         stab = d_stab.cpu().numpy()
         if not np.allclose(stab, want_stab, rtol=0, atol=1e-9):
