@@ -637,7 +637,10 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
         asm volatile("s_load_dwordx16 %0, %2, 0x48\n\ts_load_dwordx2 %1, %2, 0x88" : "=&s"(hg_lo), "=&s"(hg_hi) : "s"(gaddr));     // (early clobber: the address pair is read by both loads)
     }
 #endif
-    // (Round 6, measured and dropped -- profiles/r06_ab_prefetch.txt, profiles/README.md: touching the window lines of the footprint this
+    // (Round 6, measured and dropped: RE-ENTRY -- the wavefront jumps back to the kernel's first instruction as the next virtual workgroup, 2 or 4
+    // footprints per wavefront with the product's code per trip: half / three quarters of the dispatches and of the end-of-life store waits gone,
+    // byte-identical, +-0 -- so neither the launch rate nor a wavefront's latency limits the kernel, profiles/r06_ab_reentry.txt;
+    // and -- profiles/r06_ab_prefetch.txt, profiles/README.md: touching the window lines of the footprint this
     // block index takes one or two frames on, to have them in the XCD's L2: +12...24 %; testing t >= per_frame BEHIND the plan's loads so
     // that all kernel arguments arrive in one scalar round trip instead of two: +-0.)
     const uint32_t fp = f * g.per_frame + t;                              // the footprint's slot in plan / regions
@@ -770,13 +773,19 @@ __device__ __forceinline__ void footprint_body(const uint32_t f, const uint32_t 
 #ifdef MF_EXP_PHASES
         asm volatile("" :: "v"(d.x), "v"(d.y), "v"(d.z));
         MF_EXP_STAMP(exp_t4);
+        // (the store, then the wait s_endpgm performs anyway -- a wavefront ends only when its store is acknowledged --, stamped: the TAIL of its life)
+        *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MF_EXP_STAMP(exp_t5);
         if ((fp & 63u) == 0u && lane == 0) {
             atomicAdd(&mf_exp_phase[0], 1ull);
             atomicAdd(&mf_exp_phase[1], exp_t1 - exp_t0);
             atomicAdd(&mf_exp_phase[2], exp_t2 - exp_t1);
             atomicAdd(&mf_exp_phase[3], exp_t3 - exp_t2);
             atomicAdd(&mf_exp_phase[4], exp_t4 - exp_t3);
+            atomicAdd(&mf_exp_phase[5], exp_t5 - exp_t4);
         }
+        return;
 #endif
         *reinterpret_cast<uint3*>(dst + ((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u) = d;     // (STAGED implies W % 4 == 0)
         return;

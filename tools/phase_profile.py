@@ -114,9 +114,10 @@ def main():
         tp = timed(phases, 5)
         phases.mf_exp_phase_read(buf, 1)
         nwave = max(int(buf[0]), 1)
-        p = [buf[k] / nwave for k in range(1, 5)]
-        print(f'   life of a HOT wavefront (s_memtime ticks = 100 MHz x ... see the note; instrumented kernel {tp:.4f} ms, {nwave} sampled wavefronts):')
-        for label, v in zip(('entry -> plan + region words arrived', 'window copy issued, matrix arrived, coordinates + fixed point done', 'wait for the window (s_waitcnt vmcnt(0))', 'taps (48 byte loads) + blend'), p):
+        p = [buf[k] / nwave for k in range(1, 6)]
+        print(f'   life of a HOT wavefront (shader cycles (s_memtime); instrumented kernel {tp:.4f} ms, {nwave} sampled wavefronts):')
+        for label, v in zip(('entry -> plan + region words arrived', 'window copy issued, matrix arrived, coordinates + fixed point done', 'wait for the window (s_waitcnt vmcnt(0))', 'taps (48 byte loads) + blend',
+                             'store issued -> acknowledged (what s_endpgm waits for)'), p):
             print(f'      {label:70s} {v:10.1f}')
         print(f'      {"sum":70s} {sum(p):10.1f}')
         del frames, out, table
