@@ -50,8 +50,32 @@ def load(openmp=False):
     lib.mfo_vertex_motion.argtypes = [_dp, _dp, _i32p, _dp] + [ctypes.c_int] * 7 + [_fp, _dp]
     lib.mfo_vertex_motion.restype = ctypes.c_int
     assert lib.mfo_cell_doubles() == CELL_DOUBLES
+    if openmp:
+        # OpenMP's default is one thread per CPU the HOST shows (hundreds on the GPU boxes, whose containers may use 16): cap it to what
+        # this process may really use -- affinity mask and cgroup quota --, at most 32.  (bench.py's cpu_baseline sets its own count.)
+        lib.mfo_set_threads(max(1, min(_usable_cpus(), 32)))
     _LIBS[name] = lib
     return lib
+
+
+def _usable_cpus():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path, parse in (('/sys/fs/cgroup/cpu.max', lambda t: t.split()), ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', lambda t: [t.strip(), None])):
+        try:
+            with open(path) as fh:
+                quota, period = parse(fh.read())
+            if period is None:
+                with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fh:
+                    period = fh.read().strip()
+            if quota not in ('max', '-1'):
+                n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
 
 
 def _p(a, t):
