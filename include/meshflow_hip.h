@@ -200,6 +200,10 @@ int mf_selftest_recip(uint64_t n, uint64_t seed, uint64_t* mismatches);
  * Synchronous. */
 int mf_selftest_fast64(uint64_t n, uint64_t seed, uint64_t counters[3]);
 
+/* ... and how far the cheap chain's float64 values lie from the exact chain's on the same cases: *max_ulps receives the largest
+ * distance in float64 ulps (the certified bound is 118, the guard's window 512).  Synchronous. */
+int mf_selftest_fast64_margin(uint64_t n, uint64_t seed, double* max_ulps);
+
 /* ---- host-buffer convenience wrappers (synchronous; H2D, kernels, D2H on an internal stream) ----
  * These are what a ctypes stub inside the reference's two methods would call.
  * kernel_ms (optional) receives the device time of the kernels alone, measured with HIP events.

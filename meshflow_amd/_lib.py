@@ -51,6 +51,7 @@ SIGNATURES = {
     'mf_selftest_sqrt': (_i, [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     'mf_selftest_recip': (_i, [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     'mf_selftest_fast64': (_i, [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
+    'mf_selftest_fast64_margin': (_i, [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double)]),
     'mf_jacobi_f64_host': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_float)]),
     'mf_warp_u8c3_host': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     'mf_warp_u8c3_host_frames': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(ctypes.c_float)]),

@@ -237,6 +237,18 @@ int mf_selftest_fast64(uint64_t n, uint64_t seed, uint64_t* counters)
     return rc;
 }
 
+int mf_selftest_fast64_margin(uint64_t n, uint64_t seed, double* max_ulps)
+{
+    if (!max_ulps) { set_error("mf_selftest_fast64_margin: null"); return MF_ERR_INVALID_ARG; }
+    void* d = nullptr;
+    MF_HIP_TRY(hipMalloc(&d, 4 * sizeof(uint64_t)));
+    hipError_t e = hipMemset(d, 0, 4 * sizeof(uint64_t));
+    int rc = e == hipSuccess ? launch_selftest_fast64(n, seed, (unsigned long long*)d, nullptr, (unsigned long long*)d + 3) : hip_fail(e, "hipMemset");
+    if (rc == MF_OK) rc = hip_fail(hipMemcpy(max_ulps, (const uint64_t*)d + 3, sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
+    (void)hipFree(d);
+    return rc;
+}
+
 // ---- host-buffer wrappers ------------------------------------------------------------------------
 
 namespace {

@@ -247,7 +247,7 @@ int launch_warp(const uint8_t* frames, uint8_t* out, const TableView& tv, int n,
 int launch_crop_scan(const TableView& tv, int n, int W, int H, int R, int C, int32_t* crop, hipStream_t st);
 int check_d16_zero_fill(hipStream_t st);          // warp.hip: one-time device check the byte-tap kernels rely on
 int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t st);
-int launch_selftest_fast64(unsigned long long n, unsigned long long seed, unsigned long long* d_counters, hipStream_t st);
+int launch_selftest_fast64(unsigned long long n, unsigned long long seed, unsigned long long* d_counters, hipStream_t st, unsigned long long* d_margin = nullptr);
 size_t crop_resize_workspace_bytes(int W, int H);
 int launch_crop_resize(const uint8_t* frames, uint8_t* out, int n, int W, int H, int left, int top, int right,
                        int bottom, void* work, hipStream_t st);

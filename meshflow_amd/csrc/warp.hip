@@ -116,6 +116,14 @@ __device__ __forceinline__ uint32_t umad24(uint32_t a, uint32_t b, uint32_t c)
     return __umul24(a, b) + c;
 }
 
+// min(a, b, c) in ONE instruction (the compiler re-associates a chain of min() into more v_min_u32 than needed)
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // bits [5..28] of the raw float 32u + 1.5*2^23 are (sx >> 5) + MAGIC_HI for 0 <= sx < 2^22
 constexpr uint32_t MAGIC_HI = (0x4B400000u >> 5) & 0xFFFFFFu;
 
@@ -264,12 +272,13 @@ __device__ __forceinline__ void cell_coords(crec_t rec, double xs0, double yy, i
 #ifndef MF_NO_FAST64
 // FAST COORDINATES.  cv2.perspectiveTransform's float64 chain -- (x h0 + y h1) + h2 with every product and sum rounded, the
 // correctly rounded 1 / w, the rounded product -- only matters through its float32 conversion.  A cheaper float64 chain (fused
-// affine forms, a reciprocal good to an ulp) lands within a few dozen float64 ulps of the exact chain's value (bound: DESIGN.md
-// section 4.3, certified per footprint by the plan: MF_PLAN_FAST64), so both convert to the SAME float32 unless the cheap value lies
-// within that distance of a float32 rounding midpoint, i.e. unless the low 29 mantissa bits are within FAST64_WINDOW of 0x10000000.
+// affine forms, ONE reciprocal of the lane's four denominators refined by ONE Newton step) lands within 118 float64 ulps of the exact
+// chain's value (bound: DESIGN.md section 4.3, certified per footprint by the plan: MF_PLAN_FAST64; mf_selftest_fast64_margin measures
+// the distance), so both convert to the SAME float32 unless the cheap value lies within that distance of a float32 rounding midpoint,
+// i.e. unless the low 29 mantissa bits are within FAST64_WINDOW (4.3 x the bound) of 0x10000000.
 // midpoint_key() is below FAST64_NEAR exactly then (one v_lshl_add_u32 on the low dword); a wavefront with any such value redoes its
-// coordinates with the exact chain (about one wavefront in 2,000 at config-2 geometry).
-constexpr uint32_t FAST64_WINDOW = 256u;
+// coordinates with the exact chain (about one wavefront in 1,000 at config-2 geometry).
+constexpr uint32_t FAST64_WINDOW = 512u;
 // (low dword << 3) + const: the 29 dropped mantissa bits, shifted to the top of the register and offset so that the window around the
 // midpoint pattern 0x10000000 maps to [0, 16 FAST64_WINDOW) -- ONE v_lshl_add_u32 per value; the smallest key of a lane decides.
 constexpr uint32_t FAST64_NEAR = 16u * FAST64_WINDOW;
@@ -279,28 +288,29 @@ __device__ __forceinline__ uint32_t midpoint_key(double a)
 }
 
 // Quotients n_j / w_j and m_j / w_j of a lane's four pixels on the cheap chain, whatever matrices the forms came from: ONE reciprocal
-// for the four denominators -- R = 1 / (w0 w1 w2 w3) by v_rcp_f64 + two Newton steps (0.07 < product < 13.1), then 1 / w0 = (R w2 w3) w1
+// for the four denominators -- R = 1 / (w0 w1 w2 w3) by v_rcp_f64 + ONE Newton step (0.07 < product < 13.1), then 1 / w0 = (R w2 w3) w1
 // and so on: nine multiplications; the rounding errors of the w_j themselves cancel (the same values sit in the product), what remains
-// is 5 roundings per reciprocal.  Returns the smallest midpoint key of the eight values.
+// is 5 roundings per reciprocal plus what the Newton step leaves: v_rcp_f64 is good to 2^-24.36 (tools/ubench_semantics.hip: 2^26
+// evenly spaced mantissas x 8 exponents, profiles/r06_ubench_semantics.txt), one step squares that: 2^-48.7 = 20 u (u = 2^-53) -- a
+// second step (rounds 5-6a) took it to 1 u for two more float64 instructions per lane.  Returns the smallest midpoint key of the eight values.
 __device__ __forceinline__ uint32_t cheap_quotients(const double (&w)[4], const double (&n)[4], const double (&m)[4], float (&u)[4], float (&v)[4],
-                                                    uint32_t* keys = nullptr)
+                                                    uint32_t* keys = nullptr, double* raw = nullptr)
 {
     const double q01 = w[0] * w[1], q23 = w[2] * w[3], pr = q01 * q23;
     double r = __builtin_amdgcn_rcp(pr);
     double e = __builtin_fma(-pr, r, 1.0);
     r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-pr, r, 1.0);
-    r = __builtin_fma(r, e, r);
     const double ra = r * q23, rb = r * q01;
     const double g[4] = { ra * w[1], ra * w[0], rb * w[3], rb * w[2] };
-    uint32_t key = 0xFFFFFFFFu;
+    uint32_t key = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const double a = n[j] * g[j], b = m[j] * g[j];
         u[j] = (float)a;
         v[j] = (float)b;
-        key = min(key, min(midpoint_key(a), midpoint_key(b)));
+        key = j == 0 ? min(midpoint_key(a), midpoint_key(b)) : umin3(key, midpoint_key(a), midpoint_key(b));
         if (keys) { keys[2 * j] = midpoint_key(a); keys[2 * j + 1] = midpoint_key(b); }
+        if (raw) { raw[2 * j] = a; raw[2 * j + 1] = b; }
     }
     return key;
 }
@@ -309,7 +319,8 @@ __device__ __forceinline__ uint32_t cheap_quotients(const double (&w)[4], const 
 // transposed lane mapping of the pair path); returns the smallest midpoint key (< FAST64_NEAR = some value too close to a float32 midpoint).
 // `keys` (self-test only): the eight midpoint keys, u then v per pixel.
 template <bool VERT>
-__device__ __forceinline__ uint32_t coords_fast_dir(const double (&Hi)[9], double xs0, double yy0, float (&u)[4], float (&v)[4], uint32_t* keys = nullptr)
+__device__ __forceinline__ uint32_t coords_fast_dir(const double (&Hi)[9], double xs0, double yy0, float (&u)[4], float (&v)[4], uint32_t* keys = nullptr,
+                                                    double* raw = nullptr)
 {
     const double t0 = VERT ? yy0 : xs0, o = VERT ? xs0 : yy0;                        // stepping coordinate, the other one
     const double a0 = Hi[VERT ? 1 : 0], a3 = Hi[VERT ? 4 : 3], a6 = Hi[VERT ? 7 : 6];   // coefficients of the stepping coordinate
@@ -323,7 +334,7 @@ __device__ __forceinline__ uint32_t coords_fast_dir(const double (&Hi)[9], doubl
         n[j] = __builtin_fma((double)j, a0, n[0]);
         m[j] = __builtin_fma((double)j, a3, m[0]);
     }
-    return cheap_quotients(w, n, m, u, v, keys);
+    return cheap_quotients(w, n, m, u, v, keys, raw);
 }
 // The hot path's coordinates by the cheap chain; false (wave-uniform) when some value is too close to a float32 midpoint.
 __device__ __forceinline__ bool coords_fast(const double (&Hi)[9], double xs0, double yy, float (&u)[4], float (&v)[4], uint32_t* keys = nullptr)
@@ -441,6 +452,10 @@ __device__ __forceinline__ void taps_pair(uint32_t at0, uint32_t at1, TapRegs& t
     else MF_TAP_PAIR_ASM("112", "113", "114", "115", "116", "117");
 }
 
+// (Round 6, measured and dropped, profiles/r06_ab_trims.txt: the four weights as two packed pairs -- v_pk_mad_u16 with the clamp bit for
+// 64 (32 - fx)(32 - fy) = 65536 -> 65535, v_pk_mul_lo_u16 -- and two chained v_dot2_u32_u16 per channel instead of v_mul + v_mad + dot2:
+// 16 issue cycles per wavefront less by the table, byte-identical, +0.7...1.6 % SLOWER; and the tap address as two hand-placed
+// v_mad_u32_u24: 8 cycles less, -0.3 % / -0.3 % / +1.6 %.  At the board's power cap time follows energy, not the issue-cycle table.)
 __device__ __forceinline__ void blend_pixel(uint32_t bxj, uint32_t byj, const TapRegs& t, uint32_t& oB, uint32_t& oG, uint32_t& oR)
 {
     // vertical lerp of both 16-bit fields at once (each <= 255 * 32: no carry between them)
@@ -1623,12 +1638,14 @@ int launch_selftest_recip(unsigned long long n, unsigned long long seed, unsigne
 // Self-test of the cheap coordinate chain (coords_fast) against cv2.perspectiveTransform's own arithmetic on hashed matrices
 // and positions that satisfy the plan's MF_PLAN_FAST64 / UNIT / DEEP premises: `missed` counts float32 results that differ from
 // the exact chain's WITHOUT their midpoint key raising the flag (must be 0), `flagged` the values whose key did (the fallback rate).
-__global__ void selftest_fast64_kernel(unsigned long long n, unsigned long long seed, unsigned long long* counters)
+// (`margin`, optional: the largest distance between a cheap value and the exact chain's, in float64 ulps of the latter, as double bits)
+__global__ void selftest_fast64_kernel(unsigned long long n, unsigned long long seed, unsigned long long* counters, unsigned long long* margin)
 {
 #ifdef MF_NO_FAST64
-    (void)n; (void)seed; (void)counters;          // (A/B build without the cheap chain: nothing to test)
+    (void)n; (void)seed; (void)counters; (void)margin;          // (A/B build without the cheap chain: nothing to test)
 #else
     unsigned long long missed = 0, flagged = 0, tested = 0;
+    double far = 0.0;
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
         unsigned long long z = (i + seed) * 0x9E3779B97F4A7C15ull;
@@ -1661,13 +1678,16 @@ __global__ void selftest_fast64_kernel(unsigned long long n, unsigned long long 
         if (!ok) continue;
         float u[4], v[4];
         uint32_t keys[8];
-        if (vert) (void)coords_fast_dir<true>(Hi, x0d, y0d, u, v, keys);
-        else (void)coords_fast_dir<false>(Hi, x0d, y0d, u, v, keys);
+        double raw[8];
+        if (vert) (void)coords_fast_dir<true>(Hi, x0d, y0d, u, v, keys, raw);
+        else (void)coords_fast_dir<false>(Hi, x0d, y0d, u, v, keys, raw);
         for (int j = 0; j < 4; ++j) {
             const double x = vert ? x0d : x0d + j, y = vert ? y0d + j : y0d;
             const double w = (x * Hi[6] + y * Hi[7]) + Hi[8];
             const double iw = 1.0 / w;
-            const float ue = (float)(((x * Hi[0] + y * Hi[1]) + Hi[2]) * iw), ve = (float)(((x * Hi[3] + y * Hi[4]) + Hi[5]) * iw);
+            const double ued = ((x * Hi[0] + y * Hi[1]) + Hi[2]) * iw, ved = ((x * Hi[3] + y * Hi[4]) + Hi[5]) * iw;
+            const float ue = (float)ued, ve = (float)ved;
+            far = fmax(far, fmax(ldexp(fabs(raw[2 * j] - ued), 52 - ilogb(ued)), ldexp(fabs(raw[2 * j + 1] - ved), 52 - ilogb(ved))));
             tested += 2;
             if (keys[2 * j] < FAST64_NEAR) ++flagged; else if (__float_as_uint(ue) != __float_as_uint(u[j])) ++missed;
             if (keys[2 * j + 1] < FAST64_NEAR) ++flagged; else if (__float_as_uint(ve) != __float_as_uint(v[j])) ++missed;
@@ -1676,12 +1696,13 @@ __global__ void selftest_fast64_kernel(unsigned long long n, unsigned long long 
     if (missed) atomicAdd(&counters[0], missed);
     if (flagged) atomicAdd(&counters[1], flagged);
     if (tested) atomicAdd(&counters[2], tested);
+    if (margin) atomicMax(margin, (unsigned long long)__double_as_longlong(far));       // (non-negative doubles order like their bits)
 #endif
 }
 
-int launch_selftest_fast64(unsigned long long n, unsigned long long seed, unsigned long long* d_counters, hipStream_t st)
+int launch_selftest_fast64(unsigned long long n, unsigned long long seed, unsigned long long* d_counters, hipStream_t st, unsigned long long* d_margin)
 {
-    hipLaunchKernelGGL(selftest_fast64_kernel, dim3(2048), dim3(256), 0, st, n, seed, d_counters);
+    hipLaunchKernelGGL(selftest_fast64_kernel, dim3(2048), dim3(256), 0, st, n, seed, d_counters, d_margin);
     return hip_fail(hipGetLastError(), "selftest_fast64_kernel launch");
 }
 

@@ -406,7 +406,11 @@ def test_fast_coordinate_chain_never_differs_unflagged(dev):
     missed, flagged, tested = c[0], c[1], c[2]
     assert tested > (1 << 31)                  # most draws satisfy the premises (8 values per case)
     assert missed == 0
-    assert flagged / tested < 2e-5             # guard window 512 of 2^29 low-mantissa patterns: ~1e-6 per value
+    assert flagged / tested < 2e-5             # guard window +-512 of 2^29 low-mantissa patterns: ~2e-6 per value
+    # ... and the cheap values themselves stay far inside the window: the certified bound is 118 float64 ulps
+    far = ctypes.c_double(-1.0)
+    _lib.check(_lib.lib.mf_selftest_fast64_margin(1 << 28, 4242, ctypes.byref(far)))
+    assert 0.0 < far.value <= 118.0, far.value
 
 
 def test_degenerate_mesh_is_reported(dev):
