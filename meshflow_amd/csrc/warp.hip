@@ -455,7 +455,7 @@ __device__ __forceinline__ void taps_pair(uint32_t at0, uint32_t at1, TapRegs& t
 // (Round 6, measured and dropped, profiles/r06_ab_trims.txt: the four weights as two packed pairs -- v_pk_mad_u16 with the clamp bit for
 // 64 (32 - fx)(32 - fy) = 65536 -> 65535, v_pk_mul_lo_u16 -- and two chained v_dot2_u32_u16 per channel instead of v_mul + v_mad + dot2:
 // 16 issue cycles per wavefront less by the table, byte-identical, +0.7...1.6 % SLOWER; and the tap address as two hand-placed
-// v_mad_u32_u24: 8 cycles less, -0.3 % / -0.3 % / +1.6 %.  The issue-cycle table does not predict the time at the board's power cap.)
+// v_mad_u32_u24: 8 cycles less, -0.3 % / -0.3 % / +1.6 %.  Neither the issue-cycle table nor the energy table (profiles/r03_ubench_power.txt) predicts that; cause not identified.)
 __device__ __forceinline__ void blend_pixel(uint32_t bxj, uint32_t byj, const TapRegs& t, uint32_t& oB, uint32_t& oG, uint32_t& oR)
 {
     // vertical lerp of both 16-bit fields at once (each <= 255 * 32: no carry between them)
