@@ -43,9 +43,15 @@ int launch_radius(const double* b, double* x, const double* taps, const double* 
         hipStream_t side = nullptr;
         if (!no_tail && S > simds && r > 0 && 4 * r <= simds && jacobi_side_fork(st, &side) == MF_OK) {
             static const int tail_waves = [] { const char* v = getenv("MF_JACOBI_TAIL_WAVES"); return v && *v ? atoi(v) : 4; }();   // tuning aid
-            int rc = tail_waves == 8 ? launch_wave<OMEGA, 2, 8>(b, x, taps, lam, inv_on, F, S, iters, side, S - r, r)
-                                     : launch_wave<OMEGA, 3, 4>(b, x, taps, lam, inv_on, F, S, iters, side, S - r, r);
-            if (rc == MF_OK) rc = launch_wave<OMEGA, K, 1>(b, x, taps, lam, inv_on, F, S, iters, st, 0, S - r);
+            // The PIECES go to the caller's stream and the main launch to the side stream: behind another kernel a launch on the caller's
+            // stream starts at once and one on the side stream ~6 us later (a cross-queue event), and the pieces must be the OLDER wavefronts
+            // of their SIMDs -- then they are done in 180 us; as the younger ones they crawl beside the main wavefronts for the whole
+            // sweep and the sweep takes 200 us longer (rocprofv3 trace of tools/graph_probe.py, profiles/r06_graph_probe.txt).
+            static const bool main_first = [] { const char* v = getenv("MF_JACOBI_MAIN_FIRST"); return v && *v == '1'; }();          // tuning aid
+            hipStream_t s_piece = main_first ? side : st, s_main = main_first ? st : side;
+            int rc = tail_waves == 8 ? launch_wave<OMEGA, 2, 8>(b, x, taps, lam, inv_on, F, S, iters, s_piece, S - r, r)
+                                     : launch_wave<OMEGA, 3, 4>(b, x, taps, lam, inv_on, F, S, iters, s_piece, S - r, r);
+            if (rc == MF_OK) rc = launch_wave<OMEGA, K, 1>(b, x, taps, lam, inv_on, F, S, iters, s_main, 0, S - r);
             const int rj = jacobi_side_join(st);
             return rc != MF_OK ? rc : rj;
         }
