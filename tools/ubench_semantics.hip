@@ -1,6 +1,7 @@
 // What two gfx950 instructions DO (not how fast they are), for the round-6 trims of the warp kernel's blend and coordinate chain:
 //   1. v_pk_mad_u16 with the clamp bit: does it SATURATE each 16-bit half at 65535?  (the blend's weight 64 (32 - fx) (32 - fy) is 65536
 //      for fx = fy = 0 and has to become 65535 there.)  Also op_sel_hi = [1, 0, 1]: the low half of src1 used for both halves.
+//   3. v_mfma_f64_16x16x4_f64: its issue cost (is the float64 matrix rate of gfx950 above the vector rate?  No: 64 cycles for 1,024 multiply-adds).
 //   2. v_rcp_f64: its largest relative error over 2^26 evenly spaced mantissas (times a few exponents), and the error left after ONE
 //      Newton step r' = r + r (1 - x r) -- what the cheap coordinate chain would keep if it dropped its second step.
 // Build: make -C tools ubench_semantics      Run: tools/ubench_semantics
@@ -45,6 +46,23 @@ __global__ void rcp_error_kernel(unsigned long long* __restrict__ worst, int exp
     atomicMax(&worst[0], (unsigned long long)__double_as_longlong(e0));
     atomicMax(&worst[1], (unsigned long long)__double_as_longlong(e1));
     atomicMax(&worst[2], (unsigned long long)__double_as_longlong(e2));
+}
+
+// issue cost of v_mfma_f64_16x16x4_f64 (1,024 multiply-adds): 4 independent accumulators, 256 instructions per wavefront, one wavefront per SIMD
+typedef double d4 __attribute__((ext_vector_type(4)));
+__global__ void mfma_f64_kernel(double* out, unsigned long long* ticks)
+{
+    d4 acc[4] = {};
+    const double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -94,6 +112,24 @@ int main()
         for (int k = 0; k < 3; ++k) { memcpy(&e[k], &hw[k], 8); }
         printf("v_rcp_f64 over 2^%u mantissas x exponents 2^-4..2^3: max |1 - x r| = %.4g = 2^%.2f; after one Newton step %.4g = 2^%.2f (%.1f ulp of 2^-52); after two %.4g = 2^%.2f\n",
                bits, e[0], log2(e[0]), e[1], log2(e[1]), e[1] / ldexp(1.0, -52), e[2], log2(e[2]));
+    }
+    {
+        double* dout; unsigned long long* dt;
+        const int blocks = 1024;                                     // one wavefront per SIMD
+        CHECK(hipMalloc(&dout, blocks * 64 * sizeof(double))); CHECK(hipMalloc(&dt, blocks * sizeof(unsigned long long)));
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        mfma_f64_kernel<<<blocks, 64>>>(dout, dt);
+        CHECK(hipEventRecord(e0));
+        for (int r = 0; r < 20; ++r) mfma_f64_kernel<<<blocks, 64>>>(dout, dt);
+        CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        static unsigned long long ht[1024];
+        CHECK(hipMemcpy(ht, dt, sizeof ht, hipMemcpyDeviceToHost));
+        double mean = 0; for (int i = 0; i < blocks; ++i) mean += (double)ht[i]; mean /= blocks;
+        const double flops = 20.0 * blocks * 256.0 * 2.0 * 16 * 16 * 4;
+        printf("v_mfma_f64_16x16x4_f64: %.1f shader cycles per instruction (256 back to back per wavefront, 4 accumulators) = %.1f multiply-adds per cycle and SIMD (the vector unit: 16); "
+               "20 short launches, one wavefront per SIMD: %.1f TFLOP/s float64 (vector float64 peak: 78.6)\n",
+               mean / 256.0, 1024.0 / (mean / 256.0), flops / (ms * 1e-3) / 1e12);
     }
     return 0;
 }
