@@ -449,7 +449,9 @@ class MeshFlowStabilizer:
     #      stream, gated so that the NEXT clip's sweep runs beside THIS clip's table + plan (both leave most of the chip idle) and has
     #      ended when the warp starts.  Kernels that run beside the warp kernel cost it more than they take by themselves.
     #   k >= 1: the clip cut into k frame ranges, tables + crop scan + rectangle on the prep stream BESIDE the warp (warp(j) waits for
-    #      table(j) only): the rectangle is known earliest, the clip takes 2-8 % longer.
+    #      table(j) only): the rectangle is known earliest; at the round-6 kernels a config-2 clip takes 1.88 ms this way against 1.19 (the
+    #      side kernels are the YOUNGER wavefronts beside the warp -- cell table 273 us instead of 16, plan 468 instead of 70 -- and the
+    #      stand-alone crop scan repeats the coordinate arithmetic; it was 2-8 % in round 4, before the in-order path lost a third of its time).
     resident_chunks = 0
     resident_rectangle = 'fused'     # 'early': rectangle from the table on the prep stream (a sharded run's all-reduce hides behind the warp)
     # What the NEXT clip's sweep (prep stream) waits for.  'table': this clip has reached its cell table -- a short sweep (config 2: 48 us)
